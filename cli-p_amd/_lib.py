@@ -1,0 +1,104 @@
+"""ctypes binding of libclipmi.so (the C ABI declared in include/clipmi.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, this raises. The product
+path never routes through oracle/ or a CPU implementation.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libclipmi.so")
+
+ABI_VERSION = 1
+F32, BF16, U8 = 0, 1, 2
+
+# every symbol include/clipmi.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "clipmi_encode_image_workspace_bytes", "clipmi_encode_image",
+    "clipmi_encode_text_workspace_bytes", "clipmi_encode_text",
+    "clipmi_topk_ip_workspace_bytes", "clipmi_topk_ip",
+    "clipmi_merge_topk_workspace_bytes", "clipmi_merge_topk",
+    "clipmi_l2_normalize_rows", "clipmi_last_error", "clipmi_abi_version",
+    "clipmi_dbg_gemm_bf16", "clipmi_dbg_layernorm", "clipmi_dbg_attention",
+]
+
+
+class Tower(C.Structure):
+    """Mirror of `struct clipmi_tower` (include/clipmi.h) — keep field order identical."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "abi_version", "kind", "width", "layers", "heads", "mlp", "embed", "tokens",
+        "patch", "res", "patch_k", "vocab")] + [(n, C.c_uint64) for n in (
+        "blob_bytes",
+        "off_patch_w", "off_cls", "off_pos", "off_ln_pre_w", "off_ln_pre_b",
+        "off_tok_emb",
+        "off_layers", "layer_stride",
+        "lo_ln1_w", "lo_ln1_b", "lo_qkv_w", "lo_qkv_b", "lo_out_w", "lo_out_b",
+        "lo_ln2_w", "lo_ln2_b", "lo_fc_w", "lo_fc_b", "lo_proj_w", "lo_proj_b",
+        "off_ln_post_w", "off_ln_post_b", "off_out_proj")]
+
+
+class ClipmiError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libclipmi.so (once). Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ClipmiError(
+            f"{LIB_PATH} is missing: build the HIP library first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+    TP = C.POINTER(Tower)
+    L.clipmi_last_error.restype = C.c_char_p
+    L.clipmi_abi_version.restype = i32
+    L.clipmi_encode_image_workspace_bytes.restype = sz
+    L.clipmi_encode_image_workspace_bytes.argtypes = [TP, i32]
+    L.clipmi_encode_image.restype = i32
+    L.clipmi_encode_image.argtypes = [TP, vp, vp, i32, i32, vp, i32, vp, sz, vp]
+    L.clipmi_encode_text_workspace_bytes.restype = sz
+    L.clipmi_encode_text_workspace_bytes.argtypes = [TP, i32]
+    L.clipmi_encode_text.restype = i32
+    L.clipmi_encode_text.argtypes = [TP, vp, vp, i32, vp, i32, vp, sz, vp]
+    L.clipmi_topk_ip_workspace_bytes.restype = sz
+    L.clipmi_topk_ip_workspace_bytes.argtypes = [i64, i32, i32, i32]
+    L.clipmi_topk_ip.restype = i32
+    L.clipmi_topk_ip.argtypes = [vp, i32, i64, i32, vp, i32, i32, i64, vp, vp, vp, sz, vp]
+    L.clipmi_merge_topk_workspace_bytes.restype = sz
+    L.clipmi_merge_topk_workspace_bytes.argtypes = [i32, i32, i32]
+    L.clipmi_merge_topk.restype = i32
+    L.clipmi_merge_topk.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, sz, vp]
+    L.clipmi_l2_normalize_rows.restype = i32
+    L.clipmi_l2_normalize_rows.argtypes = [vp, i64, i32, vp]
+    L.clipmi_dbg_gemm_bf16.restype = i32
+    L.clipmi_dbg_gemm_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.clipmi_dbg_layernorm.restype = i32
+    L.clipmi_dbg_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    L.clipmi_dbg_attention.restype = i32
+    L.clipmi_dbg_attention.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    if L.clipmi_abi_version() != ABI_VERSION:
+        raise ClipmiError(f"libclipmi.so ABI {L.clipmi_abi_version()} != binding {ABI_VERSION}: rebuild")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().clipmi_last_error().decode("utf-8", "replace")
+        raise ClipmiError(f"{what} failed (code {rc}): {msg}")
+
+
+def last_error():
+    return lib().clipmi_last_error().decode("utf-8", "replace")
+
+
+def stream_ptr(device=None):
+    """Raw hipStream_t of torch's current stream, so the library enqueues where torch does."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

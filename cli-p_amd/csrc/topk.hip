@@ -1,0 +1,487 @@
+// topk.hip — exact flat inner-product top-K over a packed [N][E] f32 matrix (gfx950).
+//
+// Replaces `index.search(features, k + offset + 1)` (reference query-index.py:111) with an exact
+// streaming pass. HBM-bound: the matrix is read once per batch of <= 16
+// queries; scores are produced by v_mfma_f32_16x16x4_f32 (exact f32, one fmaf chain per
+// (row, query) in a FIXED order, restated in oracle/topk_oracle.c) and selected per wavefront
+// with a threshold filter + bounded candidate buffer in LDS.
+//
+// Score order ("score order" in DESIGN.md): for row r, query q, E = 16*NT:
+//     acc = 0; for t in [0,NT) for c in [0,4) for g in [0,4): k = 16t + 4g + c;
+//         acc = fmaf(db[r][k], q[k], acc)
+// (t,c) is one MFMA instruction; g is the MFMA's internal k index (lane >> 4).
+//
+// Ordering rule everywhere (wave select, block merge, cross-rank merge, oracle):
+//     a beats b  <=>  a.score > b.score || (a.score == b.score && a.id < b.id); NaN never selected.
+#include "common.hpp"
+#include <float.h>
+
+namespace clipmi {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned INVALID_ID = 0xFFFFFFFFu;
+constexpr int SAMPLE_ROWS = 4096;       // rows of the threshold pre-pass
+constexpr int SAMPLE_MIN_N = 65536;     // below this the pre-pass is not worth its launches
+constexpr int MAX_QA = 16;              // queries per pass = one MFMA tile of columns
+constexpr int LDS_LIMIT = 160 * 1024 - 512;
+
+__device__ __forceinline__ bool beats(float sa, unsigned ia, float sb, unsigned ib) {
+    return sa > sb || (sa == sb && ia < ib);
+}
+
+// LDS traffic of ONE wave is processed in issue order; this only has to stop the compiler from
+// moving LDS accesses across the point and to drain the wave's outstanding LDS operations.
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Keep the best min(n, K) of the n candidates in buf[0..n) (n = *cnt_p, wave-uniform), sorted by
+// the ordering rule, using rank counting: rank(e) = #{j : cand_j beats cand_e}. Ids are unique,
+// so ranks are a permutation. All 64 lanes of the wave must call this together.
+__device__ void wave_compact(uint2* buf, uint2* scratch, int* cnt_p, float* thr_p, int K, int lane) {
+    const int n = *cnt_p;
+    for (int e = lane; e < n; e += 64) {
+        const uint2 me = buf[e];
+        const float ms = __uint_as_float(me.x);
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const uint2 o = buf[j];
+            rank += beats(__uint_as_float(o.x), o.y, ms, me.y) ? 1 : 0;
+        }
+        if (rank < K) scratch[rank] = me;
+    }
+    wave_lds_sync();
+    const int m = n < K ? n : K;
+    for (int e = lane; e < m; e += 64) buf[e] = scratch[e];
+    if (lane == 0) {
+        *cnt_p = m;
+        *thr_p = (n >= K) ? __uint_as_float(scratch[K - 1].x) : -INFINITY;
+    }
+    wave_lds_sync();
+}
+
+struct ScanArgs {
+    const float* db;        // [nrows][E]
+    long long nrows;        // >= 1
+    const float* q;         // first query of this group, [QA][E]
+    int QA;                 // active queries in this pass, 1..16
+    int K;
+    int C;                  // candidate capacity per (wave, query): multiple of 64, >= K + 64
+    int wave_bytes;         // LDS bytes per wave
+    const float* thr_in;    // [QA] initial thresholds (valid lower bounds) or nullptr
+    uint2* part;            // [QA][NL][K] partial lists, NL = gridDim.x * waves
+};
+
+template <int E>
+__global__ void __launch_bounds__(256) scan_topk_f32_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = E / 16;      // float4 per lane per 16-row tile
+    constexpr int NCH = NT / 8;     // chunks of 8 float4
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int col = lane & 15;      // query column of this lane (B operand / accumulator column)
+    const int g = lane >> 4;        // MFMA k index supplied by this lane; accumulator row group
+
+    // query image, one 1-KiB lane-linear piece per t: entry [t*64 + lane] = q[col][16t+4g .. +3]
+    f32x4* qimg = reinterpret_cast<f32x4*>(smem);
+    for (int idx = tid; idx < NT * 64; idx += blockDim.x) {
+        const int t = idx >> 6, l = idx & 63, c_ = l & 15, g_ = l >> 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c_ < a.QA) v = *reinterpret_cast<const f32x4*>(a.q + (size_t)c_ * E + 16 * t + 4 * g_);
+        qimg[idx] = v;
+    }
+    char* wbase = smem + NT * 1024 + (size_t)wave * a.wave_bytes;
+    uint2* buf = reinterpret_cast<uint2*>(wbase);            // [QA][C]
+    uint2* scratch = buf + (size_t)a.QA * a.C;                // [C]
+    int* cnt = reinterpret_cast<int*>(scratch + a.C);         // [16]
+    float* thr = reinterpret_cast<float*>(cnt + 16);          // [16]
+    if (lane < 16) {
+        cnt[lane] = 0;
+        thr[lane] = (lane < a.QA) ? (a.thr_in ? a.thr_in[lane] : -INFINITY) : INFINITY;
+    }
+    __syncthreads();
+
+    const bool active = col < a.QA;
+    float tau = thr[col];
+    const int C = a.C, K = a.K;
+
+    const long long ntiles = (a.nrows + 15) >> 4;
+    const long long wg = (long long)blockIdx.x * nwaves + wave;
+    const long long tw = (long long)gridDim.x * nwaves;
+    const long long last_row = a.nrows - 1;
+
+    long long tile = wg;
+    if (tile < ntiles) {
+        f32x4 T[NT];
+        {
+            long long r = tile * 16 + col;
+            r = r > last_row ? last_row : r;
+            const float* p = a.db + r * E + 4 * g;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) T[t] = *reinterpret_cast<const f32x4*>(p + 16 * t);
+        }
+        while (true) {
+            const long long nxt = tile + tw;
+            const bool has_next = nxt < ntiles;
+            long long rn = (has_next ? nxt : tile) * 16 + col;
+            rn = rn > last_row ? last_row : rn;
+            const float* pn = a.db + rn * E + 4 * g;
+
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int t = 8 * c + j;
+                    const f32x4 bq = qimg[t * 64 + lane];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t].x, bq.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t].y, bq.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t].z, bq.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t].w, bq.w, acc, 0, 0, 0);
+                }
+                // this chunk's registers are free: refill them with the next tile (stays in
+                // flight across the candidate step below and the first chunks of the next pass).
+                // The sched_barriers pin the refill HERE: left alone, hipcc sinks all refills
+                // behind the tile's last MFMA and the wave then waits out the full HBM latency.
+                // The empty asm consumes the chunk's last MFMA result and clobbers memory, so no
+                // refill load can be hoisted above an MFMA that still reads the old registers
+                // (which would cost a register copy behind a vmcnt(0) at the loop head).
+                asm volatile("" : "+a"(acc) : : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int t = 8 * c + j;
+                    T[t] = *reinterpret_cast<const f32x4*>(pn + 16 * t);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+
+            // accumulator: column = query `col`, rows = tile*16 + 4g + r
+            const long long row0 = tile * 16 + 4 * g;
+            bool p0 = active && (row0 + 0 <= last_row) && (acc.x >= tau);
+            bool p1 = active && (row0 + 1 <= last_row) && (acc.y >= tau);
+            bool p2 = active && (row0 + 2 <= last_row) && (acc.z >= tau);
+            bool p3 = active && (row0 + 3 <= last_row) && (acc.w >= tau);
+            if (__ballot(p0 | p1 | p2 | p3)) {
+                uint2* qb = buf + (size_t)col * C;
+                if (p0) { int pos = atomicAdd(&cnt[col], 1); qb[pos] = make_uint2(__float_as_uint(acc.x), (unsigned)(row0 + 0)); }
+                if (p1) { int pos = atomicAdd(&cnt[col], 1); qb[pos] = make_uint2(__float_as_uint(acc.y), (unsigned)(row0 + 1)); }
+                if (p2) { int pos = atomicAdd(&cnt[col], 1); qb[pos] = make_uint2(__float_as_uint(acc.z), (unsigned)(row0 + 2)); }
+                if (p3) { int pos = atomicAdd(&cnt[col], 1); qb[pos] = make_uint2(__float_as_uint(acc.w), (unsigned)(row0 + 3)); }
+                wave_lds_sync();
+                const bool need = active && (g == 0) && (cnt[col] > C - 16);
+                unsigned long long mask = __ballot(need);
+                if (mask) {
+                    while (mask) {
+                        const int qq = __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                        wave_compact(buf + (size_t)qq * C, scratch, &cnt[qq], &thr[qq], K, lane);
+                    }
+                    tau = thr[col];
+                }
+            }
+            if (!has_next) break;
+            tile = nxt;
+        }
+    }
+
+    // sort + cap every active query's list, then publish it
+    const long long NL = tw;
+    for (int qq = 0; qq < a.QA; ++qq) {
+        wave_compact(buf + (size_t)qq * C, scratch, &cnt[qq], &thr[qq], K, lane);
+        const int n = cnt[qq];
+        uint2* dst = a.part + ((size_t)qq * NL + wg) * K;
+        for (int e = lane; e < K; e += 64)
+            dst[e] = e < n ? buf[(size_t)qq * C + e] : make_uint2(__float_as_uint(-INFINITY), INVALID_ID);
+    }
+}
+
+// wave-synchronous push of <= 64 candidates of ONE query (all lanes same buffer)
+__device__ __forceinline__ void wave_push1(uint2* buf, uint2* scratch, int* cnt_p, float* thr_p, float& tau,
+                                           bool pass, float s, unsigned id, int K, int C, int lane) {
+    const unsigned long long m = __ballot(pass);
+    if (!m) return;
+    const int base = *cnt_p;
+    const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (pass) buf[pos] = make_uint2(__float_as_uint(s), id);
+    wave_lds_sync();
+    if (lane == 0) *cnt_p = base + __builtin_popcountll(m);
+    wave_lds_sync();
+    if (*cnt_p > C - 64) {
+        wave_compact(buf, scratch, cnt_p, thr_p, K, lane);
+        tau = *thr_p;
+    }
+}
+
+// One block per query: merge NL partial lists of K slots each (INVALID_ID = empty slot) into
+// the final sorted top-K. out_s/out_i may be null (threshold-only pre-pass).
+__global__ void __launch_bounds__(256) merge_partial_kernel(const uint2* __restrict__ part, long long NL, int K, int C,
+                                                            long long id_base, float* out_s, long long* out_i,
+                                                            float* thr_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = blockIdx.x;
+    const int wave_bytes = 2 * C * 8 + 128;
+    auto wbuf = [&](int w) { return reinterpret_cast<uint2*>(smem + (size_t)w * wave_bytes); };
+    uint2* buf = wbuf(wave);
+    uint2* scratch = buf + C;
+    int* cnt_p = reinterpret_cast<int*>(scratch + C);
+    float* thr_p = reinterpret_cast<float*>(cnt_p + 1);
+    if (lane == 0) { *cnt_p = 0; *thr_p = -INFINITY; }
+    wave_lds_sync();
+    float tau = -INFINITY;
+
+    const long long total = NL * K;
+    const uint2* src = part + (size_t)q * total;
+    for (long long base = (long long)wave * 64; base < total; base += 256) {
+        const long long idx = base + lane;
+        uint2 c = make_uint2(0u, INVALID_ID);
+        if (idx < total) c = src[idx];
+        const float s = __uint_as_float(c.x);
+        const bool pass = (c.y != INVALID_ID) && (s >= tau);
+        wave_push1(buf, scratch, cnt_p, thr_p, tau, pass, s, c.y, K, C, lane);
+    }
+    wave_compact(buf, scratch, cnt_p, thr_p, K, lane);
+    __syncthreads();
+    if (wave == 0) {
+        tau = *thr_p;
+        for (int w = 1; w < 4; ++w) {
+            const uint2* ob = wbuf(w);
+            const int on = *reinterpret_cast<const int*>(ob + 2 * C);
+            for (int b = 0; b < on; b += 64) {
+                const int e = b + lane;
+                uint2 c = make_uint2(0u, INVALID_ID);
+                if (e < on) c = ob[e];
+                const float s = __uint_as_float(c.x);
+                const bool pass = (e < on) && (s >= tau);
+                wave_push1(buf, scratch, cnt_p, thr_p, tau, pass, s, c.y, K, C, lane);
+            }
+        }
+        wave_compact(buf, scratch, cnt_p, thr_p, K, lane);
+        const int n = *cnt_p;
+        if (out_s) {
+            for (int e = lane; e < K; e += 64) {
+                if (e < n) {
+                    out_s[(size_t)q * K + e] = __uint_as_float(buf[e].x);
+                    out_i[(size_t)q * K + e] = id_base + (long long)buf[e].y;
+                } else {
+                    out_s[(size_t)q * K + e] = -FLT_MAX;
+                    out_i[(size_t)q * K + e] = -1;
+                }
+            }
+        }
+        if (thr_out && lane == 0) thr_out[q] = (n >= K) ? __uint_as_float(buf[K - 1].x) : -INFINITY;
+    }
+}
+
+__global__ void fill_empty_kernel(float* out_s, long long* out_i, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { out_s[i] = -FLT_MAX; out_i[i] = -1; }
+}
+
+// Cross-rank merge: R lists of K (score f32, id i64; id < 0 = empty) per query, rank counting
+// straight from LDS. One block per query.
+__global__ void __launch_bounds__(256) merge_lists_i64_kernel(const float* __restrict__ scores, const long long* __restrict__ ids,
+                                                              int R, int Q, int K, float* out_s, long long* out_i) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int n = R * K;
+    long long* sid = reinterpret_cast<long long*>(smem);          // [n]
+    float* ss = reinterpret_cast<float*>(sid + n);                 // [n]
+    int* nvalid = reinterpret_cast<int*>(ss + n);
+    if (tid == 0) *nvalid = 0;
+    __syncthreads();
+    int myvalid = 0;
+    for (int e = tid; e < n; e += blockDim.x) {
+        const int r = e / K, k = e - r * K;
+        const size_t src = ((size_t)r * Q + q) * K + k;
+        const long long id = ids[src];
+        const float s = scores[src];
+        const bool ok = id >= 0 && s == s;
+        sid[e] = ok ? id : -1;
+        ss[e] = s;
+        myvalid += ok ? 1 : 0;
+    }
+    atomicAdd(nvalid, myvalid);
+    __syncthreads();
+    for (int e = tid; e < n; e += blockDim.x) {
+        const long long mi = sid[e];
+        if (mi < 0) continue;
+        const float ms = ss[e];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const long long oi = sid[j];
+            const float os = ss[j];
+            rank += (oi >= 0 && (os > ms || (os == ms && oi < mi))) ? 1 : 0;
+        }
+        if (rank < K) {
+            out_s[(size_t)q * K + rank] = ms;
+            out_i[(size_t)q * K + rank] = mi;
+        }
+    }
+    const int nv = *nvalid;
+    for (int e = (nv < K ? nv : K) + tid; e < K; e += blockDim.x) {
+        out_s[(size_t)q * K + e] = -FLT_MAX;
+        out_i[(size_t)q * K + e] = -1;
+    }
+}
+
+struct Plan {
+    int C, waves, QA, grid, grid_sample;
+    size_t lds_scan, lds_merge;
+    long long NL, NL_sample;
+    bool sample;
+    size_t part_elems;     // uint2 elements in the partial-list area
+};
+
+// Shared by workspace sizing and launch so both always agree.
+bool make_plan(long long N, int E, int Q, int K, Plan& p) {
+    if (N < 0 || Q < 1 || K < 1 || (E != 512 && E != 768)) return false;
+    p.C = (int)align_up((size_t)K + 64, 64);
+    const int qimg = (E / 16) * 1024;
+    const int qwant = Q < MAX_QA ? Q : MAX_QA;
+    p.waves = 0;
+    for (int w = 4; w >= 1; w >>= 1) {
+        const long long per_wave = (LDS_LIMIT - qimg) / w - 128;
+        const long long fit = per_wave / ((long long)p.C * 8) - 1;     // queries that fit beside scratch
+        if (fit >= 1) { p.waves = w; p.QA = (int)(fit < qwant ? fit : qwant); break; }
+    }
+    if (p.waves == 0) return false;
+    if ((size_t)2 * p.C * 8 + 128 > (size_t)LDS_LIMIT / 4) return false;   // merge kernel: 4 waves
+    const int wave_bytes = (p.QA + 1) * p.C * 8 + 128;
+    p.lds_scan = (size_t)qimg + (size_t)p.waves * wave_bytes;
+    p.lds_merge = (size_t)4 * (2 * p.C * 8 + 128);
+    const long long ntiles = (N + 15) / 16;
+    int per_cu = (int)(LDS_BYTES / p.lds_scan);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    long long grid = (ntiles + p.waves - 1) / p.waves;
+    if (grid > (long long)NUM_CU * per_cu) grid = (long long)NUM_CU * per_cu;
+    if (grid < 1) grid = 1;
+    p.grid = (int)grid;
+    p.NL = grid * p.waves;
+    p.sample = N >= SAMPLE_MIN_N;
+    p.grid_sample = (SAMPLE_ROWS / 16 + p.waves - 1) / p.waves;
+    p.NL_sample = (long long)p.grid_sample * p.waves;
+    const long long nl = p.NL > p.NL_sample ? p.NL : p.NL_sample;
+    p.part_elems = (size_t)p.QA * nl * K;
+    return true;
+}
+
+template <int E>
+int launch_scan(const ScanArgs& a, int grid, int waves, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL(scan_topk_f32_kernel<E>, dim3(grid), dim3(waves * 64), lds, st, a);
+    CLIPMI_CHECK_LAUNCH("scan_topk_f32_kernel");
+    return 0;
+}
+
+int opt_in_lds(const void* fn, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return set_err(CLIPMI_EHIP, "hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
+    }
+    return 0;
+}
+
+}  // namespace
+}  // namespace clipmi
+
+using namespace clipmi;
+
+extern "C" size_t clipmi_topk_ip_workspace_bytes(int64_t N, int E, int Q, int K) {
+    Plan p;
+    if (!make_plan(N, E, Q, K, p)) {
+        set_err(CLIPMI_EINVAL, "topk_ip: unsupported N=%lld E=%d Q=%d K=%d (E in {512,768}, 1 <= K <= ~2400)",
+                (long long)N, E, Q, K);
+        return 0;
+    }
+    return align_up(p.part_elems * sizeof(uint2), 256) + 256 /*thr*/ + 256;
+}
+
+extern "C" int clipmi_topk_ip(const void* db_dev, int db_dtype, int64_t N, int E, const float* q_dev, int Q, int K,
+                              int64_t id_base, float* out_score_dev, int64_t* out_id_dev, void* ws_dev,
+                              size_t ws_bytes, void* stream) {
+    if (db_dtype != CLIPMI_F32) return set_err(CLIPMI_EUNSUPPORTED, "topk_ip: db_dtype %d (only CLIPMI_F32)", db_dtype);
+    if (!q_dev || !out_score_dev || !out_id_dev) return set_err(CLIPMI_EINVAL, "topk_ip: NULL pointer");
+    if (N >= (1ll << 32) - 1) return set_err(CLIPMI_EINVAL, "topk_ip: N=%lld exceeds 2^32-2 rows per shard", (long long)N);
+    Plan p;
+    if (!make_plan(N, E, Q, K, p))
+        return set_err(CLIPMI_EINVAL, "topk_ip: unsupported N=%lld E=%d Q=%d K=%d", (long long)N, E, Q, K);
+    hipStream_t st = as_stream(stream);
+    if (N == 0) {
+        const long long n = (long long)Q * K;
+        hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out_score_dev,
+                           (long long*)out_id_dev, n);
+        CLIPMI_CHECK_LAUNCH("fill_empty_kernel");
+        return 0;
+    }
+    if (!db_dev || !ws_dev) return set_err(CLIPMI_EINVAL, "topk_ip: NULL db or workspace");
+    if (ws_bytes < clipmi_topk_ip_workspace_bytes(N, E, Q, K))
+        return set_err(CLIPMI_EWORKSPACE, "topk_ip: workspace %zu < %zu", ws_bytes,
+                       clipmi_topk_ip_workspace_bytes(N, E, Q, K));
+    Arena ar(ws_dev, ws_bytes);
+    uint2* part = ar.take<uint2>(p.part_elems);
+    float* thr0 = ar.take<float>(16);
+
+    const void* scan_fn = E == 512 ? (const void*)scan_topk_f32_kernel<512> : (const void*)scan_topk_f32_kernel<768>;
+    if (int rc = opt_in_lds(scan_fn, p.lds_scan)) return rc;
+    if (int rc = opt_in_lds((const void*)merge_partial_kernel, p.lds_merge)) return rc;
+
+    for (int q0 = 0; q0 < Q; q0 += p.QA) {
+        const int qa = (Q - q0) < p.QA ? (Q - q0) : p.QA;
+        ScanArgs a;
+        a.db = static_cast<const float*>(db_dev);
+        a.q = q_dev + (size_t)q0 * E;
+        a.QA = qa;
+        a.K = K;
+        a.C = p.C;
+        a.wave_bytes = (p.QA + 1) * p.C * 8 + 128;
+        a.part = part;
+        a.thr_in = nullptr;
+        if (p.sample) {
+            a.nrows = SAMPLE_ROWS;
+            int rc = E == 512 ? launch_scan<512>(a, p.grid_sample, p.waves, p.lds_scan, st)
+                              : launch_scan<768>(a, p.grid_sample, p.waves, p.lds_scan, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(merge_partial_kernel, dim3(qa), dim3(256), p.lds_merge, st, part, p.NL_sample, K, p.C,
+                               (long long)0, (float*)nullptr, (long long*)nullptr, thr0);
+            CLIPMI_CHECK_LAUNCH("merge_partial_kernel(sample)");
+            a.thr_in = thr0;
+        }
+        a.nrows = N;
+        int rc = E == 512 ? launch_scan<512>(a, p.grid, p.waves, p.lds_scan, st)
+                          : launch_scan<768>(a, p.grid, p.waves, p.lds_scan, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(merge_partial_kernel, dim3(qa), dim3(256), p.lds_merge, st, part, p.NL, K, p.C,
+                           (long long)id_base, out_score_dev + (size_t)q0 * K, (long long*)out_id_dev + (size_t)q0 * K,
+                           (float*)nullptr);
+        CLIPMI_CHECK_LAUNCH("merge_partial_kernel");
+    }
+    return 0;
+}
+
+extern "C" size_t clipmi_merge_topk_workspace_bytes(int R, int Q, int K) {
+    (void)R; (void)Q; (void)K;
+    return 256;   // the merge works out of LDS; a non-zero size keeps callers' allocation paths uniform
+}
+
+extern "C" int clipmi_merge_topk(const float* scores_dev, const int64_t* ids_dev, int R, int Q, int K,
+                                 float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes,
+                                 void* stream) {
+    (void)ws_dev; (void)ws_bytes;
+    if (!scores_dev || !ids_dev || !out_score_dev || !out_id_dev) return set_err(CLIPMI_EINVAL, "merge_topk: NULL pointer");
+    if (R < 1 || Q < 1 || K < 1) return set_err(CLIPMI_EINVAL, "merge_topk: R=%d Q=%d K=%d", R, Q, K);
+    const size_t lds = (size_t)R * K * 12 + 16;
+    if (lds > (size_t)LDS_LIMIT) return set_err(CLIPMI_EUNSUPPORTED, "merge_topk: R*K=%d too large for one LDS pass", R * K);
+    if (int rc = opt_in_lds((const void*)merge_lists_i64_kernel, lds)) return rc;
+    hipLaunchKernelGGL(merge_lists_i64_kernel, dim3(Q), dim3(256), lds, as_stream(stream), scores_dev,
+                       (const long long*)ids_dev, R, Q, K, out_score_dev, (long long*)out_id_dev);
+    CLIPMI_CHECK_LAUNCH("merge_lists_i64_kernel");
+    return 0;
+}

@@ -1,0 +1,219 @@
+"""Flat inner-product index: the host-side mirror of the faiss objects the reference scripts use.
+
+Reference call sites (paths under the reference tree):
+  build-index.py:80-81   faiss.IndexFlatIP(512) / IndexIVFFlat(..., METRIC_INNER_PRODUCT)
+  build-index.py:96,99   index.train(images) / index.add(images)
+  build-index.py:109     faiss.write_index(index, "images.index")
+  query-index.py:29-30   faiss.read_index("images.index"); index.nprobe = 32
+  query-index.py:111     D, I = index.search(features, k + offset + 1)
+
+Search here is EXACT (the reference's IVF list scan is approximate): `train` is a
+no-op and `nprobe` is accepted and ignored. The packed [N][d] f32 matrix lives in HBM; search
+calls clipmi_topk_ip through the C ABI. Multi-GPU: one process per GPU, rows split contiguously
+by rank, per-rank top-K, ONE all-gather (RCCL when the tensors are on the GPU), then the same
+K-way merge on every rank (clipmi_merge_topk) — SURVEY.md §8e.
+"""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import torch
+
+from . import _lib
+
+MAGIC = b"CLIPMIIX"   # own packed file format, see write_index
+METRIC_INNER_PRODUCT = 0
+
+
+def shard_bounds(n_total, world_size, rank):
+    """Contiguous row split: rank r owns [lo, hi). Every rank computes the same bounds."""
+    base, rem = divmod(int(n_total), int(world_size))
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def merge_lists_host(scores, ids, K):
+    """Host restatement of the merge rule for the CPU (gloo) path of ShardedFlatIP tests:
+    scores f32 [R,Q,K], ids i64 [R,Q,K] -> (f32 [Q,K], i64 [Q,K]); score desc, id asc, -1 = empty."""
+    R, Q, _ = scores.shape
+    out_s = np.full((Q, K), -np.finfo(np.float32).max, dtype=np.float32)
+    out_i = np.full((Q, K), -1, dtype=np.int64)
+    for q in range(Q):
+        s = scores[:, q, :].reshape(-1)
+        i = ids[:, q, :].reshape(-1)
+        ok = (i >= 0) & ~np.isnan(s)
+        s, i = s[ok], i[ok]
+        order = np.lexsort((i, -s.astype(np.float64)))[:K]
+        out_s[q, :len(order)] = s[order]
+        out_i[q, :len(order)] = i[order]
+    return out_s, out_i
+
+
+class IndexFlatIP:
+    """Exact inner-product index over f32 vectors resident in HBM."""
+
+    def __init__(self, d, device="cuda:0"):
+        if d not in (512, 768):
+            raise ValueError("IndexFlatIP: d must be 512 (ViT-B/32) or 768 (ViT-L/14)")
+        self.d = int(d)
+        self.device = torch.device(device)
+        self.nprobe = 1          # accepted for drop-in compatibility (query-index.py:30,51); ignored
+        self.is_trained = True
+        self.metric_type = METRIC_INNER_PRODUCT
+        self.id_base = 0         # global id of local row 0 (non-zero on shards)
+        self._chunks = []
+        self._db = None
+        self._ws = None
+
+    # -- build side ---------------------------------------------------------------------------
+    def train(self, x):
+        """No-op: exact search needs no k-means (build-index.py:96,105)."""
+        return None
+
+    def add(self, x):
+        """Append rows (numpy f32 [n,d] as in build-index.py:99,107, or a torch tensor)."""
+        t = torch.as_tensor(x) if not isinstance(x, torch.Tensor) else x
+        if t.dim() != 2 or t.shape[1] != self.d:
+            raise ValueError(f"add: expected [n,{self.d}], got {tuple(t.shape)}")
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        self._chunks.append(t)
+        self._db = None
+
+    @property
+    def ntotal(self):
+        return sum(c.shape[0] for c in self._chunks)
+
+    def matrix(self):
+        """The packed [N][d] f32 device matrix (rows in add order = LMDB key order, build-index.py:75-89)."""
+        if self._db is None:
+            if not self._chunks:
+                self._db = torch.empty((0, self.d), dtype=torch.float32, device=self.device)
+            elif len(self._chunks) == 1:
+                self._db = self._chunks[0]
+            else:
+                self._db = torch.cat(self._chunks, dim=0)
+                self._chunks = [self._db]
+        return self._db
+
+    # -- query side ---------------------------------------------------------------------------
+    def search_device(self, q, K):
+        """q: f32 [Q,d] device tensor -> (scores f32 [Q,K], ids i64 [Q,K]) device tensors. Async."""
+        L = _lib.lib()
+        db = self.matrix()
+        if self.device.type != "cuda":
+            raise _lib.ClipmiError("IndexFlatIP.search needs the HIP path (device is not a GPU); no CPU fallback")
+        q = q.to(device=self.device, dtype=torch.float32).contiguous()
+        Q = q.shape[0]
+        N = db.shape[0]
+        need = L.clipmi_topk_ip_workspace_bytes(N, self.d, Q, K)
+        if need == 0:
+            raise _lib.ClipmiError("topk_ip: " + _lib.last_error())
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out_s = torch.empty((Q, K), dtype=torch.float32, device=self.device)
+        out_i = torch.empty((Q, K), dtype=torch.int64, device=self.device)
+        rc = L.clipmi_topk_ip(db.data_ptr(), _lib.F32, N, self.d, q.data_ptr(), Q, K, self.id_base,
+                              out_s.data_ptr(), out_i.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                              _lib.stream_ptr(self.device))
+        _lib.check(rc, "clipmi_topk_ip")
+        return out_s, out_i
+
+    def search(self, x, K):
+        """D, I = index.search(features, K) (query-index.py:111): numpy in, numpy out."""
+        q = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)) if not isinstance(x, torch.Tensor) else x
+        if q.dim() != 2 or q.shape[1] != self.d:
+            raise ValueError(f"search: expected [Q,{self.d}], got {tuple(q.shape)}")
+        s, i = self.search_device(q, int(K))
+        return s.cpu().numpy(), i.cpu().numpy()
+
+
+class ShardedFlatIP:
+    """Rank-local shard + the one all-gather merge. One process per GPU.
+
+    Each rank holds rows [lo, hi) of the global matrix (`shard_bounds`), searches them with
+    global ids, all-gathers the [Q,K] partials and merges. On GPUs the collective is RCCL
+    (`backend="nccl"`) over xGMI and the merge is clipmi_merge_topk; on the gloo/CPU path (tests
+    of the host logic, no GPU) `local_search` must be supplied and the merge is merge_lists_host.
+    """
+
+    def __init__(self, local_index, n_total, group=None, local_search=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.local = local_index
+        self.n_total = int(n_total)
+        self.lo, self.hi = shard_bounds(n_total, self.world, self.rank)
+        if local_index is not None:
+            local_index.id_base = self.lo
+        self._local_search = local_search
+        self.nprobe = 1
+
+    def search_device(self, q, K):
+        dist = self.dist
+        if self._local_search is not None:           # CPU/gloo test path: host merge
+            s, i = self._local_search(q, K, self.lo)
+            s = torch.as_tensor(s)
+            i = torch.as_tensor(i)
+        else:
+            s, i = self.local.search_device(q, K)
+        gs = [torch.empty_like(s) for _ in range(self.world)]
+        gi = [torch.empty_like(i) for _ in range(self.world)]
+        # one exchange step: scores and ids travel as one packed message per rank
+        packed = torch.cat([s.view(torch.int32).to(torch.int64).reshape(-1), i.reshape(-1)])
+        gathered = [torch.empty_like(packed) for _ in range(self.world)]
+        dist.all_gather(gathered, packed, group=self.group)
+        n = s.numel()
+        for r in range(self.world):
+            gs[r] = gathered[r][:n].to(torch.int32).view(torch.float32).reshape(s.shape)
+            gi[r] = gathered[r][n:].reshape(i.shape)
+        S = torch.stack(gs).contiguous()
+        I = torch.stack(gi).contiguous()
+        Q = s.shape[0]
+        if S.is_cuda:
+            L = _lib.lib()
+            out_s = torch.empty((Q, K), dtype=torch.float32, device=S.device)
+            out_i = torch.empty((Q, K), dtype=torch.int64, device=S.device)
+            ws = torch.empty(256, dtype=torch.uint8, device=S.device)
+            rc = L.clipmi_merge_topk(S.data_ptr(), I.data_ptr(), self.world, Q, K, out_s.data_ptr(),
+                                     out_i.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(S.device))
+            _lib.check(rc, "clipmi_merge_topk")
+            return out_s, out_i
+        ms, mi = merge_lists_host(S.numpy(), I.numpy(), K)
+        return torch.from_numpy(ms), torch.from_numpy(mi)
+
+    def search(self, x, K):
+        q = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)) if not isinstance(x, torch.Tensor) else x
+        s, i = self.search_device(q, int(K))
+        return s.cpu().numpy(), i.cpu().numpy()
+
+
+def write_index(index, path):
+    """faiss.write_index stand-in (build-index.py:109). Own packed format, little-endian:
+    8-byte magic, u32 version, u32 d, u64 ntotal, then ntotal*d f32 rows. (A faiss-readable
+    IndexFlatIP writer is SURVEY.md §8f next-3.)"""
+    db = index.matrix().cpu().numpy()
+    with open(path, "wb") as f:
+        f.write(MAGIC + struct.pack("<IIQ", 1, index.d, db.shape[0]))
+        f.write(np.ascontiguousarray(db, dtype="<f4").tobytes())
+
+
+def read_index(path, device="cuda:0"):
+    """faiss.read_index stand-in (query-index.py:29)."""
+    with open(path, "rb") as f:
+        head = f.read(24)
+        if head[:8] != MAGIC:
+            raise ValueError(f"{path}: not a clipmi index file")
+        ver, d, n = struct.unpack("<IIQ", head[8:])
+        if ver != 1:
+            raise ValueError(f"{path}: unsupported version {ver}")
+        data = np.fromfile(f, dtype="<f4", count=n * d)
+    if data.size != n * d:
+        raise ValueError(f"{path}: truncated ({data.size} of {n * d} floats)")
+    idx = IndexFlatIP(d, device=device)
+    if n:
+        idx.add(data.reshape(n, d))
+    return idx

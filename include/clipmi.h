@@ -1,0 +1,174 @@
+/*
+ * clipmi.h — C ABI of libclipmi.so, the MI355X (gfx950) CLIP index-and-search hot path.
+ *
+ * The reference (ps-auxw/CLI-P) has no FFI of its own: its "interface" for this path is the
+ * set of Python calls its two scripts make on third-party objects. Each entry
+ * point below names the reference call site it stands in for, as `file:line` under the
+ * reference tree. The Python mirror of those call shapes lives in `cli-p_amd/`; the binding a
+ * maintainer would add to the reference scripts is shown in INTEGRATION.md.
+ *
+ * Contract for every entry point:
+ *   - plain C types only; every `*_dev` pointer is a DEVICE (HBM) pointer owned by the caller;
+ *   - the library never allocates, frees or synchronises: all work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream) and is graph-capturable;
+ *   - scratch memory is a caller-owned workspace whose size the matching *_workspace_bytes()
+ *     function returns (0 from that function = unsupported arguments, see clipmi_last_error);
+ *   - return value 0 = enqueued; non-zero = a CLIPMI_E* code, nothing was enqueued (or, for
+ *     CLIPMI_EHIP, a launch failed); the message is in clipmi_last_error() (thread-local);
+ *   - re-entrant: no global mutable state apart from that thread-local error string.
+ */
+#ifndef CLIPMI_H
+#define CLIPMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLIPMI_ABI_VERSION 1
+
+enum {
+    CLIPMI_OK = 0,
+    CLIPMI_EINVAL = 1,   /* bad argument (shape, dtype, NULL pointer, K out of range ...) */
+    CLIPMI_EWORKSPACE = 2, /* workspace too small */
+    CLIPMI_EHIP = 3,     /* a HIP call failed */
+    CLIPMI_EUNSUPPORTED = 4
+};
+
+/* element types of buffers crossing the ABI */
+enum {
+    CLIPMI_F32 = 0,
+    CLIPMI_BF16 = 1,
+    CLIPMI_U8 = 2
+};
+
+/*
+ * One transformer tower (vision or text) as a POD view into ONE packed device blob.
+ * Produced on the host by the packer (cli-p_amd/weights.py) from tensors with OpenAI CLIP
+ * state-dict names (SURVEY.md §8b "weight-file contract"); replaces the model object that
+ * `clip.load("ViT-B/32", device=device, jit=False)` returns (build-index.py:18,
+ * query-index.py:21). All offsets are bytes from the blob base, 256-byte aligned.
+ * GEMM weights are bf16, row-major [out_features][in_features] (PyTorch Linear layout, so the
+ * contraction index is contiguous for both operands); LayerNorm parameters, biases and
+ * embeddings are f32.
+ */
+typedef struct clipmi_tower {
+    int32_t abi_version;   /* CLIPMI_ABI_VERSION */
+    int32_t kind;          /* 0 = vision, 1 = text */
+    int32_t width;         /* W: 768 (ViT-B/32 vision), 512 (text) */
+    int32_t layers;
+    int32_t heads;         /* W / 64 */
+    int32_t mlp;           /* 4 W */
+    int32_t embed;         /* E: 512 */
+    int32_t tokens;        /* L: 50 for ViT-B/32 (49 patches + CLS); 77 for text */
+    /* vision only */
+    int32_t patch;         /* P: 32 */
+    int32_t res;           /* R: 224 */
+    int32_t patch_k;       /* 3*P*P rounded up to a multiple of 64 (zero-padded columns) */
+    /* text only */
+    int32_t vocab;         /* 49408 */
+
+    uint64_t blob_bytes;
+
+    /* vision: conv1.weight as bf16 [W][patch_k]; class_embedding f32 [W];
+       positional_embedding f32 [L][W]; ln_pre f32 */
+    uint64_t off_patch_w, off_cls, off_pos, off_ln_pre_w, off_ln_pre_b;
+    /* text: token_embedding.weight f32 [vocab][W]; positional_embedding uses off_pos */
+    uint64_t off_tok_emb;
+
+    /* per layer l: base = off_layers + l * layer_stride, then the intra-layer offsets */
+    uint64_t off_layers, layer_stride;
+    uint64_t lo_ln1_w, lo_ln1_b;      /* f32 [W] */
+    uint64_t lo_qkv_w, lo_qkv_b;      /* attn.in_proj_weight bf16 [3W][W], in_proj_bias f32 [3W] */
+    uint64_t lo_out_w, lo_out_b;      /* attn.out_proj bf16 [W][W], f32 [W] */
+    uint64_t lo_ln2_w, lo_ln2_b;
+    uint64_t lo_fc_w, lo_fc_b;        /* mlp.c_fc bf16 [4W][W], f32 [4W] */
+    uint64_t lo_proj_w, lo_proj_b;    /* mlp.c_proj bf16 [W][4W], f32 [W] */
+
+    /* vision: ln_post + visual.proj stored TRANSPOSED as bf16 [E][W];
+       text: ln_final + text_projection stored TRANSPOSED as bf16 [E][W] */
+    uint64_t off_ln_post_w, off_ln_post_b, off_out_proj;
+} clipmi_tower;
+
+/* ---- a3/a4: model.encode_image(image) and the row L2-normalise that follows it ----------
+ * Replaces build-index.py:49 (`model.encode_image(image)`) and, with normalize != 0,
+ * build-index.py:50 (`image_features / image_features.norm(dim=-1, keepdim=True)`).
+ *   pixels_dev : [B][3][R][R], NCHW. CLIPMI_F32 / CLIPMI_BF16 = already normalised (the output
+ *                of the reference `transform`, build-index.py:48); CLIPMI_U8 = raw 0..255 RGB,
+ *                the /255, -mean, /std of CLIP's transform is fused into the patch kernel.
+ *   out_dev    : f32 [B][E] (the layout build-index.py:51 serialises: 2048 B per row for E=512)
+ */
+size_t clipmi_encode_image_workspace_bytes(const clipmi_tower* t, int B);
+int clipmi_encode_image(const clipmi_tower* t, const void* blob_dev,
+                        const void* pixels_dev, int pix_dtype, int B,
+                        float* out_dev, int normalize,
+                        void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ---- a9/a10: model.encode_text(texts) + normalize() -------------------------------------
+ * Replaces query-index.py:108 (`model.encode_text(texts)`; `normalize`, query-index.py:13-17,
+ * when normalize != 0 — per ROW here; identical to the reference for its Q = 1).
+ *   ids_dev : int32 [Q][L] token ids as produced by clip.tokenize (query-index.py:107);
+ *             the pooled row is the first argmax of each row (the EOT token).
+ *   out_dev : f32 [Q][E]
+ */
+size_t clipmi_encode_text_workspace_bytes(const clipmi_tower* t, int Q);
+int clipmi_encode_text(const clipmi_tower* t, const void* blob_dev,
+                       const int32_t* ids_dev, int Q,
+                       float* out_dev, int normalize,
+                       void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ---- a12: index.search(features, k + offset + 1) ----------------------------------------
+ * Replaces query-index.py:111 (`D, I = index.search(features, K)`), as EXACT flat inner-product
+ * search over this rank's shard of the packed matrix that build-index.py:68-107 assembles.
+ *   db_dev     : [N][E] row-major, CLIPMI_F32 (E in {512, 768})
+ *   q_dev      : f32 [Q][E]
+ *   out_score  : f32 [Q][K] descending; out_id: int64 [Q][K] = id_base + row; ties broken by
+ *                ascending id; slots beyond min(K, N) hold score -FLT_MAX and id -1
+ *   Scores are bit-exact f32: for each (row, query) one fmaf chain in the fixed order
+ *   documented in DESIGN.md ("score order") and restated in oracle/topk_oracle.c.
+ */
+size_t clipmi_topk_ip_workspace_bytes(int64_t N, int E, int Q, int K);
+int clipmi_topk_ip(const void* db_dev, int db_dtype, int64_t N, int E,
+                   const float* q_dev, int Q, int K, int64_t id_base,
+                   float* out_score_dev, int64_t* out_id_dev,
+                   void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ---- multi-GPU merge of per-shard partial results (no reference counterpart: the reference
+ * is single-process). Inputs are R lists per query as gathered by one
+ * all-gather: scores f32 [R][Q][K], ids int64 [R][Q][K] (id -1 = empty slot). Same ordering
+ * rule (score desc, id asc), so the result equals single-GPU exact top-K.
+ */
+size_t clipmi_merge_topk_workspace_bytes(int R, int Q, int K);
+int clipmi_merge_topk(const float* scores_dev, const int64_t* ids_dev, int R, int Q, int K,
+                      float* out_score_dev, int64_t* out_id_dev,
+                      void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ---- a4/a10 stand-alone: rows of x[n][E] scaled to unit L2 norm in place (rows with
+ * norm < 1e-9 are left unchanged, as query-index.py:13-17 does). */
+int clipmi_l2_normalize_rows(float* x_dev, int64_t n, int E, void* stream);
+
+/* thread-local message of the last failing call on this thread ("" if none) */
+const char* clipmi_last_error(void);
+int clipmi_abi_version(void);
+
+/* ---- test/bench hooks: the individual kernels behind encode_*, exported so that parity
+ * tests and bench.py can launch and time them one at a time. Not part of the drop-in surface.
+ */
+/* C[M][N] = A[M][K](bf16) . W[N][K]^T(bf16) with fused epilogue `epi`:
+ *   0: out bf16 = acc + bias        1: out bf16 = quickgelu(acc + bias)
+ *   2: out f32 += acc + bias (residual, in place)    3: out f32 = acc (bias may be NULL)  */
+int clipmi_dbg_gemm_bf16(const void* a_dev, const void* w_dev, const float* bias_dev,
+                         void* out_dev, int M, int N, int K, int epi, void* stream);
+/* rows of f32 x[M][W] -> LayerNorm(eps 1e-5) -> bf16 (out_bf16 != 0) or f32 */
+int clipmi_dbg_layernorm(const float* x_dev, const float* w_dev, const float* b_dev,
+                         void* out_dev, int M, int W, int out_bf16, void* stream);
+/* qkv bf16 [B*L][3W] -> softmax(q k^T / 8 (+causal)) v -> bf16 [B*L][W], head dim 64 */
+int clipmi_dbg_attention(const void* qkv_dev, void* out_dev, int B, int L, int heads,
+                         int causal, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIPMI_H */

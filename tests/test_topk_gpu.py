@@ -1,0 +1,153 @@
+"""-m gpu parity of clipmi_topk_ip / clipmi_merge_topk (through the C ABI) against
+oracle/topk_oracle.c: scores AND ids bit-exact (integer/index work)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import unit_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(clipmi, gpu, db, q, K, id_base=0):
+    idx = clipmi.IndexFlatIP(db.shape[1] if db.ndim == 2 else q.shape[1], device=gpu)
+    if db.shape[0]:
+        idx.add(db)
+    idx.id_base = id_base
+    D, I = idx.search(q, K)
+    return D, I
+
+
+def _assert_exact(D, I, Ds, Is, tag):
+    bad = np.nonzero((I != Is) | (D.view(np.uint32) != Ds.view(np.uint32)))
+    assert bad[0].size == 0, (f"{tag}: {bad[0].size} mismatching slots, first at q={bad[0][0]} k={bad[1][0]}: "
+                              f"got ({D[bad[0][0], bad[1][0]]!r}, {I[bad[0][0], bad[1][0]]}) "
+                              f"want ({Ds[bad[0][0], bad[1][0]]!r}, {Is[bad[0][0], bad[1][0]]})")
+
+
+@pytest.mark.parametrize("N,Q,K", [(1, 1, 1), (15, 1, 5), (16, 3, 16), (17, 16, 51), (1000, 5, 51),
+                                   (4096, 3, 51), (4099, 16, 11), (20000, 17, 51), (70001, 16, 51),
+                                   (70001, 1, 101), (131072, 33, 51), (5000, 2, 300)])
+def test_topk_matches_oracle(clipmi, gpu, topk_oracle, N, Q, K):
+    rng = np.random.default_rng(N * 131 + Q * 7 + K)
+    db = unit_rows(rng, N, 512)
+    q = unit_rows(rng, Q, 512)
+    D, I = _run(clipmi, gpu, db, q, K, id_base=1000)
+    Ds, Is = topk_oracle.topk(db, q, K, id_base=1000)
+    _assert_exact(D, I, Ds, Is, f"N={N} Q={Q} K={K}")
+
+
+def test_topk_golden_ties_and_duplicates(clipmi, gpu, topk_oracle):
+    """SURVEY.md §8c fixture (iv): planted duplicate rows (identical vectors = duplicate photos)
+    and an exact tie group; ties must resolve by ascending id."""
+    import os, sys
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold)
+    import topk_case
+    g = np.load(os.path.join(gold, "topk_ties.npz"))
+    db, q = topk_case.build()
+    assert np.array_equal(q, g["q"]) and float(db.astype(np.float64).sum()) == float(g["db_checksum"])
+    D, I = _run(clipmi, gpu, db, q, topk_case.K)
+    _assert_exact(D, I, g["D"], g["I"], "golden ties")
+
+
+def test_topk_fewer_rows_than_k(clipmi, gpu, topk_oracle):
+    rng = np.random.default_rng(5)
+    db = unit_rows(rng, 7, 512)
+    q = unit_rows(rng, 2, 512)
+    D, I = _run(clipmi, gpu, db, q, 51)
+    Ds, Is = topk_oracle.topk(db, q, 51)
+    _assert_exact(D, I, Ds, Is, "N<K")
+    assert (I[:, 7:] == -1).all() and (D[:, 7:] == -np.finfo(np.float32).max).all()
+
+
+def test_topk_empty_index(clipmi, gpu):
+    idx = clipmi.IndexFlatIP(512, device=gpu)
+    D, I = idx.search(np.ones((2, 512), np.float32), 5)
+    assert (I == -1).all()
+
+
+def test_topk_adversarial_order(clipmi, gpu, topk_oracle):
+    """Rows sorted so that every later row beats all earlier ones: the sample threshold is
+    useless and every wave keeps compacting. Still exact."""
+    rng = np.random.default_rng(11)
+    N = 80000
+    q = unit_rows(rng, 2, 512)
+    db = unit_rows(rng, N, 512)
+    s = db @ q[0]
+    db = db[np.argsort(s, kind="stable")]
+    D, I = _run(clipmi, gpu, db, q, 51)
+    Ds, Is = topk_oracle.topk(db, q, 51)
+    _assert_exact(D, I, Ds, Is, "adversarial")
+
+
+def test_topk_e768(clipmi, gpu, topk_oracle):
+    rng = np.random.default_rng(12)
+    db = unit_rows(rng, 3000, 768)
+    q = unit_rows(rng, 4, 768)
+    D, I = _run(clipmi, gpu, db, q, 51)
+    Ds, Is = topk_oracle.topk(db, q, 51)
+    _assert_exact(D, I, Ds, Is, "E=768")
+
+
+def test_topk_nan_inf_rows(clipmi, gpu, topk_oracle):
+    rng = np.random.default_rng(13)
+    db = unit_rows(rng, 500, 512)
+    db[3, 7] = np.nan
+    db[10, :] = 0
+    db[11, 0] = np.inf
+    q = np.abs(unit_rows(rng, 2, 512)) + 0.01
+    D, I = _run(clipmi, gpu, db, q, 20)
+    Ds, Is = topk_oracle.topk(db, q, 20)
+    _assert_exact(D, I, Ds, Is, "nan/inf")
+    assert 3 not in I
+
+
+def test_sharded_equals_single(clipmi, gpu, topk_oracle):
+    """Size-independent property at scale: split N rows into R contiguous shards, search each
+    with its id_base, merge with clipmi_merge_topk == single-pass result == oracle merge."""
+    rng = np.random.default_rng(21)
+    N, Q, K, R = 300000, 16, 51, 8
+    db = torch.from_numpy(unit_rows(rng, N, 512)).to(gpu)
+    q = unit_rows(rng, Q, 512)
+    # plant duplicates across shard boundaries
+    db[N // R] = db[5]
+    db[N - 1] = db[5]
+    full = clipmi.IndexFlatIP(512, device=gpu)
+    full.add(db)
+    D, I = full.search(q, K)
+    parts_s, parts_i = [], []
+    for r in range(R):
+        lo, hi = clipmi.shard_bounds(N, R, r)
+        sh = clipmi.IndexFlatIP(512, device=gpu)
+        sh.add(db[lo:hi])
+        sh.id_base = lo
+        s, i = sh.search(q, K)
+        parts_s.append(s)
+        parts_i.append(i)
+    S = torch.from_numpy(np.stack(parts_s)).to(gpu)
+    Iall = torch.from_numpy(np.stack(parts_i)).to(gpu)
+    L = clipmi._lib.lib()
+    out_s = torch.empty((Q, K), dtype=torch.float32, device=gpu)
+    out_i = torch.empty((Q, K), dtype=torch.int64, device=gpu)
+    ws = torch.empty(256, dtype=torch.uint8, device=gpu)
+    rc = L.clipmi_merge_topk(S.data_ptr(), Iall.data_ptr(), R, Q, K, out_s.data_ptr(), out_i.data_ptr(),
+                             ws.data_ptr(), ws.numel(), None)
+    clipmi._lib.check(rc, "merge")
+    _assert_exact(out_s.cpu().numpy(), out_i.cpu().numpy(), D, I, "sharded vs single")
+    Ms, Mi = topk_oracle.merge(np.stack(parts_s), np.stack(parts_i), K)
+    _assert_exact(out_s.cpu().numpy(), out_i.cpu().numpy(), Ms, Mi, "merge vs oracle merge")
+    # spot-check the single-pass result against the oracle on a row subset containing all hits
+    rows = np.unique(I.reshape(-1))
+    sc = topk_oracle.scores(db[rows].cpu().numpy(), q[0])
+    got = {int(i): s for i, s in zip(I[0], D[0])}
+    for r_, s_ in zip(rows, sc):
+        if int(r_) in got:
+            assert np.float32(got[int(r_)]).view(np.uint32) == np.float32(s_).view(np.uint32)
+
+
+def test_topk_errors(clipmi, gpu):
+    idx = clipmi.IndexFlatIP(512, device=gpu)
+    idx.add(np.zeros((4, 512), np.float32))
+    with pytest.raises(clipmi.ClipmiError):
+        idx.search(np.zeros((1, 512), np.float32), 100000)
