@@ -21,8 +21,6 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr unsigned INVALID_ID = 0xFFFFFFFFu;
-constexpr int SAMPLE_ROWS = 4096;       // rows of the threshold pre-pass
 constexpr int SAMPLE_MIN_N = 65536;     // below this the pre-pass is not worth its launches
 constexpr int MAX_QA = 16;              // queries per pass = one MFMA tile of columns
 constexpr int LDS_LIMIT = 160 * 1024 - 512;
@@ -72,7 +70,9 @@ struct ScanArgs {
     int C;                  // candidate capacity per (wave, query): multiple of 64, >= K + 64
     int wave_bytes;         // LDS bytes per wave
     const float* thr_in;    // [QA] initial thresholds (valid lower bounds) or nullptr
-    uint2* part;            // [QA][NL][K] partial lists, NL = gridDim.x * waves
+    uint2* cand;            // [QA][cap] dense candidate lists (unsorted), cap >= NL * C
+    unsigned* gcnt;         // [16] entries used per query; zeroed on the stream before the launch
+    long long cap;
 };
 
 template <int E>
@@ -191,94 +191,156 @@ __global__ void __launch_bounds__(256) scan_topk_f32_kernel(ScanArgs a) {
         }
     }
 
-    // sort + cap every active query's list, then publish it
-    const long long NL = tw;
-    for (int qq = 0; qq < a.QA; ++qq) {
-        wave_compact(buf + (size_t)qq * C, scratch, &cnt[qq], &thr[qq], K, lane);
-        const int n = cnt[qq];
-        uint2* dst = a.part + ((size_t)qq * NL + wg) * K;
-        for (int e = lane; e < K; e += 64)
-            dst[e] = e < n ? buf[(size_t)qq * C + e] : make_uint2(__float_as_uint(-INFINITY), INVALID_ID);
-    }
-}
-
-// wave-synchronous push of <= 64 candidates of ONE query (all lanes same buffer)
-__device__ __forceinline__ void wave_push1(uint2* buf, uint2* scratch, int* cnt_p, float* thr_p, float& tau,
-                                           bool pass, float s, unsigned id, int K, int C, int lane) {
-    const unsigned long long m = __ballot(pass);
-    if (!m) return;
-    const int base = *cnt_p;
-    const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-    if (pass) buf[pos] = make_uint2(__float_as_uint(s), id);
-    wave_lds_sync();
-    if (lane == 0) *cnt_p = base + __builtin_popcountll(m);
-    wave_lds_sync();
-    if (*cnt_p > C - 64) {
-        wave_compact(buf, scratch, cnt_p, thr_p, K, lane);
-        tau = *thr_p;
-    }
-}
-
-// One block per query: merge NL partial lists of K slots each (INVALID_ID = empty slot) into
-// the final sorted top-K. out_s/out_i may be null (threshold-only pre-pass).
-__global__ void __launch_bounds__(256) merge_partial_kernel(const uint2* __restrict__ part, long long NL, int K, int C,
-                                                            long long id_base, float* out_s, long long* out_i,
-                                                            float* thr_out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = blockIdx.x;
-    const int wave_bytes = 2 * C * 8 + 128;
-    auto wbuf = [&](int w) { return reinterpret_cast<uint2*>(smem + (size_t)w * wave_bytes); };
-    uint2* buf = wbuf(wave);
-    uint2* scratch = buf + C;
-    int* cnt_p = reinterpret_cast<int*>(scratch + C);
-    float* thr_p = reinterpret_cast<float*>(cnt_p + 1);
-    if (lane == 0) { *cnt_p = 0; *thr_p = -INFINITY; }
-    wave_lds_sync();
-    float tau = -INFINITY;
-
-    const long long total = NL * K;
-    const uint2* src = part + (size_t)q * total;
-    for (long long base = (long long)wave * 64; base < total; base += 256) {
-        const long long idx = base + lane;
-        uint2 c = make_uint2(0u, INVALID_ID);
-        if (idx < total) c = src[idx];
-        const float s = __uint_as_float(c.x);
-        const bool pass = (c.y != INVALID_ID) && (s >= tau);
-        wave_push1(buf, scratch, cnt_p, thr_p, tau, pass, s, c.y, K, C, lane);
-    }
-    wave_compact(buf, scratch, cnt_p, thr_p, K, lane);
+    // publish the block's surviving candidates (unsorted, possibly more than K per wave): ONE
+    // returning atomic per (block, query), issued by 16 lanes at once — per-wave serial atomics
+    // here cost ~200 us of same-address contention at the end of a 1M-row scan
     __syncthreads();
-    if (wave == 0) {
-        tau = *thr_p;
-        for (int w = 1; w < 4; ++w) {
-            const uint2* ob = wbuf(w);
-            const int on = *reinterpret_cast<const int*>(ob + 2 * C);
-            for (int b = 0; b < on; b += 64) {
-                const int e = b + lane;
-                uint2 c = make_uint2(0u, INVALID_ID);
-                if (e < on) c = ob[e];
-                const float s = __uint_as_float(c.x);
-                const bool pass = (e < on) && (s >= tau);
-                wave_push1(buf, scratch, cnt_p, thr_p, tau, pass, s, c.y, K, C, lane);
-            }
-        }
-        wave_compact(buf, scratch, cnt_p, thr_p, K, lane);
-        const int n = *cnt_p;
-        if (out_s) {
-            for (int e = lane; e < K; e += 64) {
-                if (e < n) {
-                    out_s[(size_t)q * K + e] = __uint_as_float(buf[e].x);
-                    out_i[(size_t)q * K + e] = id_base + (long long)buf[e].y;
-                } else {
-                    out_s[(size_t)q * K + e] = -FLT_MAX;
-                    out_i[(size_t)q * K + e] = -1;
-                }
-            }
-        }
-        if (thr_out && lane == 0) thr_out[q] = (n >= K) ? __uint_as_float(buf[K - 1].x) : -INFINITY;
+    unsigned* gbase = reinterpret_cast<unsigned*>(smem);            // query image is dead now
+    auto wave_cnt = [&](int w) {
+        return reinterpret_cast<int*>(smem + NT * 1024 + (size_t)w * a.wave_bytes + (size_t)(a.QA + 1) * a.C * 8);
+    };
+    if (wave == 0 && lane < a.QA) {
+        unsigned total = 0;
+        for (int w = 0; w < nwaves; ++w) total += (unsigned)wave_cnt(w)[lane];
+        gbase[lane] = total ? atomicAdd(&a.gcnt[lane], total) : 0u;
     }
+    __syncthreads();
+    for (int qq = 0; qq < a.QA; ++qq) {
+        const int n = cnt[qq];
+        if (n == 0) continue;
+        unsigned base = gbase[qq];
+        for (int w = 0; w < wave; ++w) base += (unsigned)wave_cnt(w)[qq];
+        uint2* dst = a.cand + (size_t)qq * a.cap + base;
+        for (int e = lane; e < n; e += 64) dst[e] = buf[(size_t)qq * C + e];
+    }
+}
+
+// Composite 64-bit key: larger = better under the ordering rule. High word = order-preserving
+// image of the f32 score (-0 folded into +0), low word = ~id (smaller id wins ties). Keys of
+// distinct rows are distinct, so "the K largest keys" is exactly the rule's top-K.
+__device__ __forceinline__ unsigned long long ckey(uint2 c) {
+    const float s = __uint_as_float(c.x) + 0.0f;
+    unsigned u = __float_as_uint(s);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(~c.y);
+}
+
+constexpr int SEL_THREADS = 512;
+
+// One block per query: exact top-K of a dense, unsorted candidate list by MSB-first radix
+// select on the composite key (8-bit digits, starting at the highest bit in which the list's
+// keys differ), then a rank-count sort of the K survivors. All passes stream the list from
+// global memory (it is L2-resident: a few thousand 8-byte entries).
+__global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* __restrict__ cand,
+                                                                 const unsigned* __restrict__ gcnt, long long cap,
+                                                                 int K, long long id_base, float* out_s,
+                                                                 long long* out_i, float* thr_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* red = reinterpret_cast<unsigned long long*>(smem);   // [16] min, [16] max
+    unsigned* hist = reinterpret_cast<unsigned*>(red + 32);                  // [256]
+    unsigned* wsum = hist + 256;                                             // [8]
+    unsigned* ctl = wsum + 8;                                                // [8] b, above, nsel
+    uint2* sel = reinterpret_cast<uint2*>(ctl + 8);                          // [K]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    long long M = gcnt[q];
+    if (M > cap) M = cap;
+    const uint2* src = cand + (size_t)q * cap;
+    const int need = (int)(M < K ? M : K);
+
+    unsigned long long T = 0;     // select keys >= T
+    if (M > K) {
+        unsigned long long kmin = ~0ull, kmax = 0ull;
+        for (long long e = tid; e < M; e += SEL_THREADS) {
+            const unsigned long long k = ckey(src[e]);
+            kmin = k < kmin ? k : kmin;
+            kmax = k > kmax ? k : kmax;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned long long a = __shfl_xor(kmin, o), b = __shfl_xor(kmax, o);
+            kmin = a < kmin ? a : kmin;
+            kmax = b > kmax ? b : kmax;
+        }
+        if (lane == 0) { red[wave] = kmin; red[16 + wave] = kmax; }
+        __syncthreads();
+        for (int w = 0; w < SEL_THREADS / 64; ++w) {
+            kmin = red[w] < kmin ? red[w] : kmin;
+            kmax = red[16 + w] > kmax ? red[16 + w] : kmax;
+        }
+        const unsigned long long diff = kmin ^ kmax;          // != 0: M >= 2 distinct keys
+        int hi_shift = 64 - __builtin_clzll(diff);              // low bits not fixed yet, 1..64
+        unsigned long long prefix = hi_shift >= 64 ? 0ull : ((kmax >> hi_shift) << hi_shift);
+        unsigned r = (unsigned)K;                               // wanted: the r largest keys matching prefix
+        while (hi_shift > 0) {
+            const int w = hi_shift < 8 ? hi_shift : 8;
+            const int shift = hi_shift - w;
+            const unsigned dmask = (1u << w) - 1u;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            for (long long e = tid; e < M; e += SEL_THREADS) {
+                const unsigned long long k = ckey(src[e]);
+                const bool match = hi_shift >= 64 || (k >> hi_shift) == (prefix >> hi_shift);
+                if (match) atomicAdd(&hist[(unsigned)(k >> shift) & dmask], 1u);
+            }
+            __syncthreads();
+            // inclusive suffix sums S[t] = sum_{u >= t} hist[u] over 256 bins (waves 0..3)
+            unsigned h = 0, S = 0;
+            if (tid < 256) {
+                h = hist[tid];
+                S = h;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned v = __shfl_down(S, o);
+                    if (lane + o < 64) S += v;
+                }
+                if (lane == 0) wsum[wave] = S;
+            }
+            __syncthreads();
+            if (tid < 256) {
+                for (int w2 = wave + 1; w2 < 4; ++w2) S += wsum[w2];
+                const unsigned above = S - h;                    // count in bins > tid
+                if (S >= r && above < r) { ctl[0] = (unsigned)tid; ctl[1] = above; ctl[2] = h; }
+            }
+            __syncthreads();
+            const unsigned b = ctl[0], above = ctl[1], cb = ctl[2];
+            prefix |= (unsigned long long)b << shift;
+            hi_shift = shift;
+            r -= above;
+            __syncthreads();
+            if (cb == r) break;                                  // the whole bin is selected
+        }
+        T = prefix;
+    }
+
+    if (tid == 0) ctl[4] = 0;
+    __syncthreads();
+    for (long long e = tid; e < M; e += SEL_THREADS) {
+        const uint2 c = src[e];
+        if (ckey(c) >= T) {
+            const unsigned pos = atomicAdd(&ctl[4], 1u);
+            if (pos < (unsigned)need) sel[pos] = c;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < need; e += SEL_THREADS) {
+        const uint2 me = sel[e];
+        const unsigned long long mk = ckey(me);
+        int rank = 0;
+        for (int j = 0; j < need; ++j) rank += ckey(sel[j]) > mk ? 1 : 0;
+        if (out_s) {
+            out_s[(size_t)q * K + rank] = __uint_as_float(me.x);
+            out_i[(size_t)q * K + rank] = id_base + (long long)me.y;
+        }
+        if (thr_out && rank == K - 1) thr_out[q] = __uint_as_float(me.x);
+    }
+    if (out_s)
+        for (int e = need + tid; e < K; e += SEL_THREADS) {
+            out_s[(size_t)q * K + e] = -FLT_MAX;
+            out_i[(size_t)q * K + e] = -1;
+        }
+    if (thr_out && need < K && tid == 0) thr_out[q] = -INFINITY;
 }
 
 __global__ void fill_empty_kernel(float* out_s, long long* out_i, long long n) {
@@ -335,10 +397,9 @@ __global__ void __launch_bounds__(256) merge_lists_i64_kernel(const float* __res
 
 struct Plan {
     int C, waves, QA, grid, grid_sample;
-    size_t lds_scan, lds_merge;
-    long long NL, NL_sample;
+    size_t lds_scan, lds_sel;
+    long long NL, NL_sample, cap, sample_rows;
     bool sample;
-    size_t part_elems;     // uint2 elements in the partial-list area
 };
 
 // Shared by workspace sizing and launch so both always agree.
@@ -354,10 +415,10 @@ bool make_plan(long long N, int E, int Q, int K, Plan& p) {
         if (fit >= 1) { p.waves = w; p.QA = (int)(fit < qwant ? fit : qwant); break; }
     }
     if (p.waves == 0) return false;
-    if ((size_t)2 * p.C * 8 + 128 > (size_t)LDS_LIMIT / 4) return false;   // merge kernel: 4 waves
+    p.lds_sel = 32 * 8 + (256 + 8 + 8) * 4 + (size_t)K * 8;
+    if (p.lds_sel > (size_t)LDS_LIMIT) return false;
     const int wave_bytes = (p.QA + 1) * p.C * 8 + 128;
     p.lds_scan = (size_t)qimg + (size_t)p.waves * wave_bytes;
-    p.lds_merge = (size_t)4 * (2 * p.C * 8 + 128);
     const long long ntiles = (N + 15) / 16;
     int per_cu = (int)(LDS_BYTES / p.lds_scan);
     per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
@@ -366,11 +427,15 @@ bool make_plan(long long N, int E, int Q, int K, Plan& p) {
     if (grid < 1) grid = 1;
     p.grid = (int)grid;
     p.NL = grid * p.waves;
+    // threshold pre-pass over the first S rows: S ~ sqrt(N*K) balances the two select passes
     p.sample = N >= SAMPLE_MIN_N;
-    p.grid_sample = (SAMPLE_ROWS / 16 + p.waves - 1) / p.waves;
+    long long S = 4096;
+    while (S < 65536 && S * S < N * (long long)K) S *= 2;
+    p.sample_rows = S;
+    p.grid_sample = (int)((S / 16 + p.waves - 1) / p.waves);
     p.NL_sample = (long long)p.grid_sample * p.waves;
     const long long nl = p.NL > p.NL_sample ? p.NL : p.NL_sample;
-    p.part_elems = (size_t)p.QA * nl * K;
+    p.cap = nl * p.C;
     return true;
 }
 
@@ -397,11 +462,11 @@ using namespace clipmi;
 extern "C" size_t clipmi_topk_ip_workspace_bytes(int64_t N, int E, int Q, int K) {
     Plan p;
     if (!make_plan(N, E, Q, K, p)) {
-        set_err(CLIPMI_EINVAL, "topk_ip: unsupported N=%lld E=%d Q=%d K=%d (E in {512,768}, 1 <= K <= ~2400)",
+        set_err(CLIPMI_EINVAL, "topk_ip: unsupported N=%lld E=%d Q=%d K=%d (E in {512,768}, 1 <= K <= ~7000)",
                 (long long)N, E, Q, K);
         return 0;
     }
-    return align_up(p.part_elems * sizeof(uint2), 256) + 256 /*thr*/ + 256;
+    return align_up((size_t)p.QA * p.cap * sizeof(uint2), 256) + 256 /*gcnt*/ + 256 /*thr*/ + 256;
 }
 
 extern "C" int clipmi_topk_ip(const void* db_dev, int db_dtype, int64_t N, int E, const float* q_dev, int Q, int K,
@@ -422,16 +487,16 @@ extern "C" int clipmi_topk_ip(const void* db_dev, int db_dtype, int64_t N, int E
         return 0;
     }
     if (!db_dev || !ws_dev) return set_err(CLIPMI_EINVAL, "topk_ip: NULL db or workspace");
-    if (ws_bytes < clipmi_topk_ip_workspace_bytes(N, E, Q, K))
-        return set_err(CLIPMI_EWORKSPACE, "topk_ip: workspace %zu < %zu", ws_bytes,
-                       clipmi_topk_ip_workspace_bytes(N, E, Q, K));
+    const size_t need_ws = clipmi_topk_ip_workspace_bytes(N, E, Q, K);
+    if (ws_bytes < need_ws) return set_err(CLIPMI_EWORKSPACE, "topk_ip: workspace %zu < %zu", ws_bytes, need_ws);
     Arena ar(ws_dev, ws_bytes);
-    uint2* part = ar.take<uint2>(p.part_elems);
+    uint2* cand = ar.take<uint2>((size_t)p.QA * p.cap);
+    unsigned* gcnt = ar.take<unsigned>(16);
     float* thr0 = ar.take<float>(16);
 
     const void* scan_fn = E == 512 ? (const void*)scan_topk_f32_kernel<512> : (const void*)scan_topk_f32_kernel<768>;
     if (int rc = opt_in_lds(scan_fn, p.lds_scan)) return rc;
-    if (int rc = opt_in_lds((const void*)merge_partial_kernel, p.lds_merge)) return rc;
+    if (int rc = opt_in_lds((const void*)select_topk_kernel, p.lds_sel)) return rc;
 
     for (int q0 = 0; q0 < Q; q0 += p.QA) {
         const int qa = (Q - q0) < p.QA ? (Q - q0) : p.QA;
@@ -442,26 +507,32 @@ extern "C" int clipmi_topk_ip(const void* db_dev, int db_dtype, int64_t N, int E
         a.K = K;
         a.C = p.C;
         a.wave_bytes = (p.QA + 1) * p.C * 8 + 128;
-        a.part = part;
+        a.cand = cand;
+        a.gcnt = gcnt;
+        a.cap = p.cap;
         a.thr_in = nullptr;
         if (p.sample) {
-            a.nrows = SAMPLE_ROWS;
+            // pre-pass: exact K-th best score of the first S rows = a valid lower bound for the
+            // K-th best of all rows; the main pass then only buffers scores >= that bound
+            a.nrows = p.sample_rows;
+            if (hipMemsetAsync(gcnt, 0, 64, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
             int rc = E == 512 ? launch_scan<512>(a, p.grid_sample, p.waves, p.lds_scan, st)
                               : launch_scan<768>(a, p.grid_sample, p.waves, p.lds_scan, st);
             if (rc) return rc;
-            hipLaunchKernelGGL(merge_partial_kernel, dim3(qa), dim3(256), p.lds_merge, st, part, p.NL_sample, K, p.C,
+            hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, cand, gcnt, p.cap, K,
                                (long long)0, (float*)nullptr, (long long*)nullptr, thr0);
-            CLIPMI_CHECK_LAUNCH("merge_partial_kernel(sample)");
+            CLIPMI_CHECK_LAUNCH("select_topk_kernel(sample)");
             a.thr_in = thr0;
         }
         a.nrows = N;
+        if (hipMemsetAsync(gcnt, 0, 64, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
         int rc = E == 512 ? launch_scan<512>(a, p.grid, p.waves, p.lds_scan, st)
                           : launch_scan<768>(a, p.grid, p.waves, p.lds_scan, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(merge_partial_kernel, dim3(qa), dim3(256), p.lds_merge, st, part, p.NL, K, p.C,
+        hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, cand, gcnt, p.cap, K,
                            (long long)id_base, out_score_dev + (size_t)q0 * K, (long long*)out_id_dev + (size_t)q0 * K,
                            (float*)nullptr);
-        CLIPMI_CHECK_LAUNCH("merge_partial_kernel");
+        CLIPMI_CHECK_LAUNCH("select_topk_kernel");
     }
     return 0;
 }

@@ -1,0 +1,241 @@
+"""Weight handling for the CLIP towers: architecture table, seeded random state-dicts with OpenAI
+CLIP key names, local checkpoint loading, and the packer that turns a state-dict into ONE device
+blob + the POD `clipmi_tower` descriptor the C ABI consumes (include/clipmi.h).
+
+Stands in for `clip.load("ViT-B/32", device=device, jit=False)` (reference build-index.py:18,
+query-index.py:21). The upstream loader downloads weights; there is no network here, so weights
+come from a LOCAL file with OpenAI key names (SURVEY.md §8b "weight-file contract") or from
+`random_state_dict` (synthetic benchmarks and parity tests).
+"""
+import math
+
+import torch
+
+from . import _lib
+
+ARCHS = {
+    # name: vision(width, layers, patch, res), text(width, layers, heads, ctx, vocab), embed
+    "ViT-B/32": dict(v_width=768, v_layers=12, patch=32, res=224,
+                     t_width=512, t_layers=12, ctx=77, vocab=49408, embed=512),
+    "ViT-B/16": dict(v_width=768, v_layers=12, patch=16, res=224,
+                     t_width=512, t_layers=12, ctx=77, vocab=49408, embed=512),
+    "ViT-L/14": dict(v_width=1024, v_layers=24, patch=14, res=224,
+                     t_width=768, t_layers=12, ctx=77, vocab=49408, embed=768),
+    "ViT-L/14@336px": dict(v_width=1024, v_layers=24, patch=14, res=336,
+                           t_width=768, t_layers=12, ctx=77, vocab=49408, embed=768),
+    # 2-layer toy used by kernel-level tests (SURVEY.md §8c fixture (i))
+    "toy": dict(v_width=128, v_layers=2, patch=32, res=64,
+                t_width=128, t_layers=2, ctx=16, vocab=512, embed=64),
+}
+
+
+def _resblocks(sd, prefix, width, layers, g, gain, attn_std, proj_std, fc_std):
+    def rn(*shape, std=1.0):
+        return torch.randn(*shape, generator=g, dtype=torch.float32) * std
+    for i in range(layers):
+        p = f"{prefix}.resblocks.{i}"
+        sd[f"{p}.ln_1.weight"] = 1.0 + 0.1 * rn(width)
+        sd[f"{p}.ln_1.bias"] = 0.1 * rn(width)
+        sd[f"{p}.attn.in_proj_weight"] = rn(3 * width, width, std=attn_std * gain)
+        sd[f"{p}.attn.in_proj_bias"] = 0.02 * rn(3 * width)
+        sd[f"{p}.attn.out_proj.weight"] = rn(width, width, std=proj_std * gain)
+        sd[f"{p}.attn.out_proj.bias"] = 0.02 * rn(width)
+        sd[f"{p}.ln_2.weight"] = 1.0 + 0.1 * rn(width)
+        sd[f"{p}.ln_2.bias"] = 0.1 * rn(width)
+        sd[f"{p}.mlp.c_fc.weight"] = rn(4 * width, width, std=fc_std * gain)
+        sd[f"{p}.mlp.c_fc.bias"] = 0.02 * rn(4 * width)
+        sd[f"{p}.mlp.c_proj.weight"] = rn(width, 4 * width, std=proj_std * gain)
+        sd[f"{p}.mlp.c_proj.bias"] = 0.02 * rn(width)
+
+
+def random_state_dict(arch="ViT-B/32", seed=0, gain=3.0):
+    """Seeded random weights with OpenAI CLIP state-dict names and shapes. Standard deviations
+    follow the published CLIP initialisation (width^-0.5 families) times `gain` on the matrices,
+    plus non-trivial LayerNorm parameters and biases so that no term of the forward is vacuous.
+    torch's CPU generator is deterministic for a fixed torch version (the image pins 2.10)."""
+    a = ARCHS[arch]
+    g = torch.Generator(device="cpu")
+    g.manual_seed(int(seed))
+
+    def rn(*shape, std=1.0):
+        return torch.randn(*shape, generator=g, dtype=torch.float32) * std
+
+    sd = {}
+    W, P, R = a["v_width"], a["patch"], a["res"]
+    L = (R // P) ** 2 + 1
+    scale = W ** -0.5
+    sd["visual.conv1.weight"] = rn(W, 3, P, P, std=(3 * P * P) ** -0.5 * gain)
+    sd["visual.class_embedding"] = rn(W, std=scale)
+    sd["visual.positional_embedding"] = rn(L, W, std=scale)
+    sd["visual.ln_pre.weight"] = 1.0 + 0.1 * rn(W)
+    sd["visual.ln_pre.bias"] = 0.1 * rn(W)
+    _resblocks(sd, "visual.transformer", W, a["v_layers"], g, gain,
+               attn_std=W ** -0.5, proj_std=(W ** -0.5) * ((2 * a["v_layers"]) ** -0.5), fc_std=(2 * W) ** -0.5)
+    sd["visual.ln_post.weight"] = 1.0 + 0.1 * rn(W)
+    sd["visual.ln_post.bias"] = 0.1 * rn(W)
+    sd["visual.proj"] = rn(W, a["embed"], std=scale * gain)
+
+    T = a["t_width"]
+    sd["token_embedding.weight"] = rn(a["vocab"], T, std=0.02 * 10)
+    sd["positional_embedding"] = rn(a["ctx"], T, std=0.01 * 10)
+    _resblocks(sd, "transformer", T, a["t_layers"], g, gain,
+               attn_std=T ** -0.5, proj_std=(T ** -0.5) * ((2 * a["t_layers"]) ** -0.5), fc_std=(2 * T) ** -0.5)
+    sd["ln_final.weight"] = 1.0 + 0.1 * rn(T)
+    sd["ln_final.bias"] = 0.1 * rn(T)
+    sd["text_projection"] = rn(T, a["embed"], std=T ** -0.5 * gain)
+    sd["logit_scale"] = torch.tensor(math.log(1 / 0.07))
+    return sd
+
+
+def load_state_dict(path):
+    """Read a LOCAL checkpoint into an OpenAI-named f32 state-dict: a TorchScript archive such as
+    the upstream `ViT-B-32.pt` (torch.jit.load(...).state_dict()), a pickled state-dict, or a
+    safetensors file."""
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        sd = load_file(path)
+    else:
+        try:
+            sd = torch.jit.load(path, map_location="cpu").state_dict()
+        except RuntimeError:
+            sd = torch.load(path, map_location="cpu")
+            if hasattr(sd, "state_dict"):
+                sd = sd.state_dict()
+            if "state_dict" in sd:
+                sd = sd["state_dict"]
+    sd = {k: v.float() for k, v in sd.items() if torch.is_tensor(v)}
+    if "visual.conv1.weight" not in sd:
+        raise ValueError(f"{path}: no 'visual.conv1.weight' — expected OpenAI CLIP ViT key names")
+    return sd
+
+
+def infer_dims(sd):
+    """Model dimensions from tensor shapes, the way the upstream build_model does."""
+    W = sd["visual.conv1.weight"].shape[0]
+    P = sd["visual.conv1.weight"].shape[-1]
+    Lv = sd["visual.positional_embedding"].shape[0]
+    grid = round((Lv - 1) ** 0.5)
+    v_layers = len({k.split(".")[3] for k in sd if k.startswith("visual.transformer.resblocks.")})
+    T = sd["ln_final.weight"].shape[0]
+    t_layers = len({k.split(".")[2] for k in sd if k.startswith("transformer.resblocks.")})
+    return dict(v_width=W, v_layers=v_layers, patch=P, res=P * grid, v_tokens=Lv,
+                t_width=T, t_layers=t_layers, ctx=sd["positional_embedding"].shape[0],
+                vocab=sd["token_embedding.weight"].shape[0], embed=sd["text_projection"].shape[1])
+
+
+class _Blob:
+    """256-byte aligned bump layout of tensors into one byte buffer."""
+
+    def __init__(self):
+        self.items = []
+        self.size = 0
+
+    def put(self, t, dtype):
+        self.size = (self.size + 255) // 256 * 256
+        off = self.size
+        t = t.detach().to("cpu").contiguous().to(dtype).contiguous()
+        self.items.append((off, t))
+        self.size += t.numel() * t.element_size()
+        return off
+
+    def materialise(self, device):
+        total = (self.size + 255) // 256 * 256
+        buf = torch.zeros(total, dtype=torch.uint8)
+        for off, t in self.items:
+            raw = t.view(torch.uint8).reshape(-1) if t.dtype != torch.uint8 else t.reshape(-1)
+            buf[off:off + raw.numel()] = raw
+        return buf.to(device), total
+
+
+def _pack_layers(tw, blob, sd, prefix, width, layers):
+    bf, f32 = torch.bfloat16, torch.float32
+    first = None
+    stride = None
+    names = [("lo_ln1_w", "ln_1.weight", f32), ("lo_ln1_b", "ln_1.bias", f32),
+             ("lo_qkv_w", "attn.in_proj_weight", bf), ("lo_qkv_b", "attn.in_proj_bias", f32),
+             ("lo_out_w", "attn.out_proj.weight", bf), ("lo_out_b", "attn.out_proj.bias", f32),
+             ("lo_ln2_w", "ln_2.weight", f32), ("lo_ln2_b", "ln_2.bias", f32),
+             ("lo_fc_w", "mlp.c_fc.weight", bf), ("lo_fc_b", "mlp.c_fc.bias", f32),
+             ("lo_proj_w", "mlp.c_proj.weight", bf), ("lo_proj_b", "mlp.c_proj.bias", f32)]
+    for i in range(layers):
+        base = None
+        for field, key, dt in names:
+            off = blob.put(sd[f"{prefix}.resblocks.{i}.{key}"], dt)
+            if base is None:
+                base = off
+            if i == 0:
+                setattr(tw, field, off - base)
+            else:
+                assert off - base == getattr(tw, field), "layers must have identical layouts"
+        if i == 0:
+            first = base
+        elif i == 1:
+            stride = base - first
+        if i >= 1:
+            assert base - first == stride * i
+    tw.off_layers = first
+    tw.layer_stride = stride if stride is not None else 0
+
+
+def pack_vision(sd, device):
+    """OpenAI-named state-dict -> (Tower descriptor, uint8 device blob) for the vision tower."""
+    d = infer_dims(sd)
+    W, P = d["v_width"], d["patch"]
+    if W % 64 or (4 * W) % 128:
+        raise ValueError(f"vision width {W}: must be a multiple of 64")
+    tw = _lib.Tower()
+    tw.abi_version, tw.kind = _lib.ABI_VERSION, 0
+    tw.width, tw.layers, tw.heads, tw.mlp = W, d["v_layers"], W // 64, 4 * W
+    tw.embed, tw.tokens, tw.patch, tw.res = d["embed"], d["v_tokens"], P, d["res"]
+    k = 3 * P * P
+    tw.patch_k = (k + 63) // 64 * 64
+    blob = _Blob()
+    conv = sd["visual.conv1.weight"].reshape(W, k)
+    if tw.patch_k != k:
+        conv = torch.cat([conv, torch.zeros(W, tw.patch_k - k)], dim=1)
+    bf, f32 = torch.bfloat16, torch.float32
+    tw.off_patch_w = blob.put(conv, bf)
+    tw.off_cls = blob.put(sd["visual.class_embedding"], f32)
+    tw.off_pos = blob.put(sd["visual.positional_embedding"], f32)
+    tw.off_ln_pre_w = blob.put(sd["visual.ln_pre.weight"], f32)
+    tw.off_ln_pre_b = blob.put(sd["visual.ln_pre.bias"], f32)
+    _pack_layers(tw, blob, sd, "visual.transformer", W, d["v_layers"])
+    tw.off_ln_post_w = blob.put(sd["visual.ln_post.weight"], f32)
+    tw.off_ln_post_b = blob.put(sd["visual.ln_post.bias"], f32)
+    tw.off_out_proj = blob.put(sd["visual.proj"].t(), bf)          # [E][W]
+    buf, total = blob.materialise(device)
+    tw.blob_bytes = total
+    return tw, buf
+
+
+def pack_text(sd, device):
+    """OpenAI-named state-dict -> (Tower descriptor, uint8 device blob) for the text tower."""
+    d = infer_dims(sd)
+    T = d["t_width"]
+    tw = _lib.Tower()
+    tw.abi_version, tw.kind = _lib.ABI_VERSION, 1
+    tw.width, tw.layers, tw.heads, tw.mlp = T, d["t_layers"], T // 64, 4 * T
+    tw.embed, tw.tokens, tw.vocab = d["embed"], d["ctx"], d["vocab"]
+    blob = _Blob()
+    bf, f32 = torch.bfloat16, torch.float32
+    tw.off_tok_emb = blob.put(sd["token_embedding.weight"], f32)
+    tw.off_pos = blob.put(sd["positional_embedding"], f32)
+    _pack_layers(tw, blob, sd, "transformer", T, d["t_layers"])
+    tw.off_ln_post_w = blob.put(sd["ln_final.weight"], f32)
+    tw.off_ln_post_b = blob.put(sd["ln_final.bias"], f32)
+    tw.off_out_proj = blob.put(sd["text_projection"].t(), bf)      # [E][T]
+    buf, total = blob.materialise(device)
+    tw.blob_bytes = total
+    return tw, buf
+
+
+def bf16_round_state_dict(sd):
+    """The state-dict as the HIP path sees it: GEMM weights rounded to bf16 (then back to f32).
+    Parity tests feed THIS to the fp32 oracle so that the comparison isolates activation
+    rounding and accumulation order from the (deliberate) bf16 storage of the weights."""
+    out = {}
+    for k, v in sd.items():
+        gemm = (k.endswith(("in_proj_weight", "out_proj.weight", "c_fc.weight", "c_proj.weight"))
+                or k in ("visual.conv1.weight", "visual.proj", "text_projection"))
+        out[k] = v.to(torch.bfloat16).float() if gemm else v.clone()
+    return out
