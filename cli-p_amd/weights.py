@@ -48,7 +48,7 @@ def _resblocks(sd, prefix, width, layers, g, gain, attn_std, proj_std, fc_std):
         sd[f"{p}.mlp.c_proj.bias"] = 0.02 * rn(width)
 
 
-def random_state_dict(arch="ViT-B/32", seed=0, gain=3.0):
+def random_state_dict(arch="ViT-B/32", seed=0, gain=1.5):
     """Seeded random weights with OpenAI CLIP state-dict names and shapes. Standard deviations
     follow the published CLIP initialisation (width^-0.5 families) times `gain` on the matrices,
     plus non-trivial LayerNorm parameters and biases so that no term of the forward is vacuous.
