@@ -17,3 +17,5 @@ from .index import (IndexFlatIP, ShardedFlatIP, METRIC_INNER_PRODUCT, read_index
 __all__ = ["_lib", "ClipmiError", "IndexFlatIP", "ShardedFlatIP", "METRIC_INNER_PRODUCT",
            "read_index", "write_index", "shard_bounds", "merge_lists_host"]
 from . import weights  # noqa: E402
+from . import model  # noqa: E402
+from .model import CLIP, load, make_transform, available_models  # noqa: E402

@@ -1,0 +1,169 @@
+// encode.hip — clipmi_encode_image / clipmi_encode_text: the two towers as kernel sequences on
+// one stream. Replaces model.encode_image (reference build-index.py:49-50) and
+// model.encode_text + normalize (query-index.py:108, 13-17). Op order follows SURVEY.md §2.1.
+//
+// Activation layout in HBM (all row-major, token row t = b*L + l):
+//   x    f32  [B*L][W]     residual stream (f32 so that 12-24 residual adds do not round to bf16)
+//   h    bf16 [B*L][W]     LayerNorm output / attention output (GEMM A operands)
+//   big  bf16 [B*L][4W]    qkv ([..][3W]) and, later in the layer, the MLP hidden ([..][4W])
+//   patches bf16 [B*np][patch_k] (vision), pooled bf16 [B][W]
+#include "vit_kernels.hpp"
+
+namespace clipmi {
+namespace {
+
+struct Ws {
+    unsigned short* patches;
+    float* x;
+    unsigned short* h;
+    unsigned short* big;
+    unsigned short* pooled;
+    int* rowidx;
+};
+
+size_t carve(const clipmi_tower* t, int B, void* base, size_t cap, Ws* out) {
+    Arena ar(base ? base : reinterpret_cast<void*>(256), cap);
+    const size_t rows = (size_t)B * t->tokens;
+    const int W = t->width;
+    Ws w{};
+    if (t->kind == 0) w.patches = ar.take<unsigned short>((size_t)B * (t->tokens - 1) * t->patch_k);
+    w.x = ar.take<float>(rows * W);
+    w.h = ar.take<unsigned short>(rows * W);
+    w.big = ar.take<unsigned short>(rows * 4 * W);
+    w.pooled = ar.take<unsigned short>((size_t)B * W);
+    w.rowidx = ar.take<int>((size_t)B);
+    if (out) *out = w;
+    return ar.off + 256;
+}
+
+int check_tower(const clipmi_tower* t, int kind, const char* who) {
+    if (!t) return set_err(CLIPMI_EINVAL, "%s: NULL tower", who);
+    if (t->abi_version != CLIPMI_ABI_VERSION)
+        return set_err(CLIPMI_EINVAL, "%s: tower ABI %d != %d", who, t->abi_version, CLIPMI_ABI_VERSION);
+    if (t->kind != kind) return set_err(CLIPMI_EINVAL, "%s: tower kind %d", who, t->kind);
+    if (t->width % 128 != 0 || t->heads * 64 != t->width || t->mlp != 4 * t->width || t->embed % 128 != 0 ||
+        t->width > 1024 || t->layers < 1)
+        return set_err(CLIPMI_EUNSUPPORTED,
+                       "%s: width=%d heads=%d mlp=%d embed=%d (need width %% 128 == 0 <= 1024, head dim 64, embed %% 128 == 0)",
+                       who, t->width, t->heads, t->mlp, t->embed);
+    if (t->tokens > 80)
+        return set_err(CLIPMI_EUNSUPPORTED, "%s: %d tokens (fused attention covers <= 80)", who, t->tokens);
+    return 0;
+}
+
+template <typename T>
+const T* at(const void* blob, uint64_t off) {
+    return reinterpret_cast<const T*>(static_cast<const char*>(blob) + off);
+}
+
+// the 12 (or 24) residual attention blocks shared by both towers
+int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int causal, hipStream_t st) {
+    const int W = t->width, L = t->tokens, M = B * L;
+    for (int l = 0; l < t->layers; ++l) {
+        const uint64_t lb = t->off_layers + (uint64_t)l * t->layer_stride;
+        LnArgs ln{w.x, at<float>(blob, lb + t->lo_ln1_w), at<float>(blob, lb + t->lo_ln1_b), w.h, nullptr, 1, M, W, 1};
+        if (int rc = launch_layernorm(ln, st)) return rc;
+        GemmArgs g{};
+        g.A = w.h; g.W = at<unsigned short>(blob, lb + t->lo_qkv_w); g.bias = at<float>(blob, lb + t->lo_qkv_b);
+        g.out = w.big; g.M = M; g.N = 3 * W; g.K = W;
+        if (int rc = launch_gemm(g, EPI_BIAS_BF16, st)) return rc;
+        if (int rc = launch_attention(w.big, w.h, B, L, t->heads, causal, 1, st)) return rc;
+        g.A = w.h; g.W = at<unsigned short>(blob, lb + t->lo_out_w); g.bias = at<float>(blob, lb + t->lo_out_b);
+        g.out = w.x; g.N = W; g.K = W;
+        if (int rc = launch_gemm(g, EPI_BIAS_RESID_F32, st)) return rc;
+        ln.w = at<float>(blob, lb + t->lo_ln2_w); ln.b = at<float>(blob, lb + t->lo_ln2_b);
+        if (int rc = launch_layernorm(ln, st)) return rc;
+        g.A = w.h; g.W = at<unsigned short>(blob, lb + t->lo_fc_w); g.bias = at<float>(blob, lb + t->lo_fc_b);
+        g.out = w.big; g.N = 4 * W; g.K = W;
+        if (int rc = launch_gemm(g, EPI_BIAS_QGELU_BF16, st)) return rc;
+        g.A = w.big; g.W = at<unsigned short>(blob, lb + t->lo_proj_w); g.bias = at<float>(blob, lb + t->lo_proj_b);
+        g.out = w.x; g.N = W; g.K = 4 * W;
+        if (int rc = launch_gemm(g, EPI_BIAS_RESID_F32, st)) return rc;
+    }
+    return 0;
+}
+
+// pooled rows -> final LayerNorm -> projection [E][W] -> f32 [B][E] (-> optional L2 normalise)
+int run_head(const clipmi_tower* t, const void* blob, const Ws& w, int B, const int* rowidx, long long row_step,
+             float* out, int normalize, hipStream_t st) {
+    LnArgs ln{w.x, at<float>(blob, t->off_ln_post_w), at<float>(blob, t->off_ln_post_b), w.pooled, rowidx, row_step,
+              B, t->width, 1};
+    if (int rc = launch_layernorm(ln, st)) return rc;
+    GemmArgs g{};
+    g.A = w.pooled; g.W = at<unsigned short>(blob, t->off_out_proj); g.bias = nullptr; g.out = out;
+    g.M = B; g.N = t->embed; g.K = t->width;
+    if (int rc = launch_gemm(g, EPI_F32, st)) return rc;
+    if (normalize) return clipmi_l2_normalize_rows(out, B, t->embed, st);
+    return 0;
+}
+
+}  // namespace
+}  // namespace clipmi
+
+using namespace clipmi;
+
+extern "C" size_t clipmi_encode_image_workspace_bytes(const clipmi_tower* t, int B) {
+    if (check_tower(t, 0, "encode_image")) return 0;
+    if (B < 1) { set_err(CLIPMI_EINVAL, "encode_image: B=%d", B); return 0; }
+    return carve(t, B, nullptr, ~(size_t)0, nullptr);
+}
+
+extern "C" int clipmi_encode_image(const clipmi_tower* t, const void* blob_dev, const void* pixels_dev, int pix_dtype,
+                                   int B, float* out_dev, int normalize, void* ws_dev, size_t ws_bytes, void* stream) {
+    if (int rc = check_tower(t, 0, "encode_image")) return rc;
+    if (!blob_dev || !pixels_dev || !out_dev || !ws_dev) return set_err(CLIPMI_EINVAL, "encode_image: NULL pointer");
+    if (B < 1) return set_err(CLIPMI_EINVAL, "encode_image: B=%d", B);
+    if (pix_dtype != CLIPMI_F32 && pix_dtype != CLIPMI_BF16 && pix_dtype != CLIPMI_U8)
+        return set_err(CLIPMI_EINVAL, "encode_image: pix_dtype %d", pix_dtype);
+    const int grid = t->res / t->patch, np = grid * grid;
+    if (np + 1 != t->tokens || t->patch_k % 64 != 0 || t->patch_k < 3 * t->patch * t->patch)
+        return set_err(CLIPMI_EINVAL, "encode_image: inconsistent tower (res %d patch %d tokens %d patch_k %d)", t->res,
+                       t->patch, t->tokens, t->patch_k);
+    const size_t need = clipmi_encode_image_workspace_bytes(t, B);
+    if (ws_bytes < need) return set_err(CLIPMI_EWORKSPACE, "encode_image: workspace %zu < %zu", ws_bytes, need);
+    Ws w;
+    carve(t, B, ws_dev, ws_bytes, &w);
+    hipStream_t st = as_stream(stream);
+    const int W = t->width, L = t->tokens;
+
+    PatchArgs pa{pixels_dev, w.patches, pix_dtype, B, t->res, t->patch, grid, np, t->patch_k};
+    if (int rc = launch_patchify(pa, st)) return rc;
+    GemmArgs g{};
+    g.A = w.patches; g.W = at<unsigned short>(blob_dev, t->off_patch_w); g.bias = nullptr; g.out = w.x;
+    g.M = B * np; g.N = W; g.K = t->patch_k; g.pos = at<float>(blob_dev, t->off_pos); g.np = np; g.L = L;
+    if (int rc = launch_gemm(g, EPI_PATCH_F32, st)) return rc;
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((unsigned)(((long long)B * W + 255) / 256)), dim3(256), 0, st, w.x,
+                       at<float>(blob_dev, t->off_cls), at<float>(blob_dev, t->off_pos), B, L, W);
+    CLIPMI_CHECK_LAUNCH("cls_rows_kernel");
+    LnArgs ln{w.x, at<float>(blob_dev, t->off_ln_pre_w), at<float>(blob_dev, t->off_ln_pre_b), w.x, nullptr, 1, B * L, W, 0};
+    if (int rc = launch_layernorm(ln, st)) return rc;       // ln_pre, in place (each wave owns its row)
+    if (int rc = run_layers(t, blob_dev, w, B, 0, st)) return rc;
+    return run_head(t, blob_dev, w, B, nullptr, L, out_dev, normalize, st);
+}
+
+extern "C" size_t clipmi_encode_text_workspace_bytes(const clipmi_tower* t, int Q) {
+    if (check_tower(t, 1, "encode_text")) return 0;
+    if (Q < 1) { set_err(CLIPMI_EINVAL, "encode_text: Q=%d", Q); return 0; }
+    return carve(t, Q, nullptr, ~(size_t)0, nullptr);
+}
+
+extern "C" int clipmi_encode_text(const clipmi_tower* t, const void* blob_dev, const int32_t* ids_dev, int Q,
+                                  float* out_dev, int normalize, void* ws_dev, size_t ws_bytes, void* stream) {
+    if (int rc = check_tower(t, 1, "encode_text")) return rc;
+    if (!blob_dev || !ids_dev || !out_dev || !ws_dev) return set_err(CLIPMI_EINVAL, "encode_text: NULL pointer");
+    if (Q < 1) return set_err(CLIPMI_EINVAL, "encode_text: Q=%d", Q);
+    const size_t need = clipmi_encode_text_workspace_bytes(t, Q);
+    if (ws_bytes < need) return set_err(CLIPMI_EWORKSPACE, "encode_text: workspace %zu < %zu", ws_bytes, need);
+    Ws w;
+    carve(t, Q, ws_dev, ws_bytes, &w);
+    hipStream_t st = as_stream(stream);
+    const int W = t->width, L = t->tokens;
+    const long long n4 = (long long)Q * L * (W / 4);
+    hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.x, ids_dev,
+                       at<float>(blob_dev, t->off_tok_emb), at<float>(blob_dev, t->off_pos), Q, L, W, t->vocab);
+    CLIPMI_CHECK_LAUNCH("text_embed_kernel");
+    hipLaunchKernelGGL(eot_rows_kernel, dim3((Q + 63) / 64), dim3(64), 0, st, ids_dev, w.rowidx, Q, L);
+    CLIPMI_CHECK_LAUNCH("eot_rows_kernel");
+    if (int rc = run_layers(t, blob_dev, w, Q, 1, st)) return rc;
+    return run_head(t, blob_dev, w, Q, w.rowidx, 1, out_dev, normalize, st);
+}

@@ -1,0 +1,182 @@
+// gemm.hpp — bf16 "NT" GEMM on v_mfma_f32_16x16x32_bf16 with fused epilogues (gfx950).
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k]      A: activations bf16 [M][K], W: weights bf16 [N][K]
+//
+// Both operands are K-contiguous (PyTorch Linear layout), so both LDS tiles are [rows][64] bf16
+// and every MFMA fragment is one 16-byte ds_read_b128. These are the GEMMs behind
+// model.encode_image / encode_text (reference build-index.py:49, query-index.py:108): patch
+// embedding, attention in/out projections, MLP c_fc / c_proj, final projection.
+//
+// Structure (v1): 128x128x64 block tile, 256 threads = 2x2 waves of 64x64, tiles staged by
+// LDS-DMA (global_load_lds, 16 B/lane) into two buffers, ONE barrier per K-tile (prefetch of
+// tile t+1 is in flight while tile t is multiplied). The 128-byte LDS rows are XOR-swizzled in
+// 16-byte chunks (chunk ^= row & 7) — applied on the SOURCE address of the DMA and on the read
+// address, never on the (lane-linear) DMA destination — which makes every ds_read_b128 lane
+// group conflict-free.
+//
+// The MFMA is issued as D = Wfrag x Afrag, i.e. the accumulator tile is C^T: its column (lane&15)
+// is the output ROW m and its 4 registers are 4 CONSECUTIVE output columns n, so the epilogue
+// loads bias / residual and stores results as 8- or 16-byte vectors.
+#pragma once
+#include "common.hpp"
+
+namespace clipmi {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    f32x2 v = {a, b};
+    bf16x2 r = __builtin_convertvector(v, bf16x2);     // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+    return __builtin_bit_cast(unsigned, r);
+}
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+__device__ __forceinline__ float quick_gelu(float x) {
+    // x * sigmoid(1.702 x)   (OpenAI CLIP QuickGELU)
+    return x / (1.0f + __expf(-1.702f * x));
+}
+
+enum Epilogue {
+    EPI_BIAS_BF16 = 0,        // out bf16 [M][N] = acc + bias
+    EPI_BIAS_QGELU_BF16 = 1,  // out bf16 = quick_gelu(acc + bias)
+    EPI_BIAS_RESID_F32 = 2,   // out f32 [M][N] += acc + bias        (residual stream, in place)
+    EPI_F32 = 3,              // out f32 = acc (+ bias if given)
+    EPI_PATCH_F32 = 4         // out f32 [b*L + 1 + p][n] = acc + pos[1 + p][n],  m = b*np + p
+};
+
+struct GemmArgs {
+    const unsigned short* A;   // bf16 [M][K]
+    const unsigned short* W;   // bf16 [N][K]
+    const float* bias;         // [N] or nullptr
+    void* out;
+    int M, N, K;
+    // EPI_PATCH_F32 only
+    const float* pos;          // [L][N]
+    int np, L;
+};
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 64;
+constexpr int GEMM_TILE_BYTES = GEMM_BM * GEMM_BK * 2;          // 16 KiB per operand tile
+constexpr int GEMM_LDS_BYTES = 4 * GEMM_TILE_BYTES;             // A,B x 2 buffers = 64 KiB
+
+template <int EPI>
+__global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;       // 2x2 waves, each 64 (m) x 64 (n)
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int ntn = g.N / GEMM_BN;
+    const int bm = blockIdx.x / ntn, bn = blockIdx.x - bm * ntn;    // n fastest: neighbours share the A panel
+    const int m0 = bm * GEMM_BM, n0 = bn * GEMM_BN;
+    const int K = g.K;
+
+    // --- LDS-DMA staging: each wave-instruction moves 8 rows x 128 B. Wave w owns rows
+    // [32w, 32w+32) of both tiles: 4 instructions per operand per K-tile.
+    const int srow = lane >> 3;          // row within the 8-row piece
+    const int spos = lane & 7;           // 16-byte chunk position in the LDS row
+    const unsigned short* a_src[4];
+    const unsigned short* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + srow;
+        const int chunk = spos ^ (row & 7);                 // swizzle on the SOURCE (rule: DMA dest is lane-linear)
+        int am = m0 + row;
+        am = am < g.M ? am : g.M - 1;                        // M tail: duplicate the last row, masked in the epilogue
+        a_src[i] = g.A + (size_t)am * K + chunk * 8;
+        w_src[i] = g.W + (size_t)(n0 + row) * K + chunk * 8;
+    }
+    auto stage = [&](int kt, int buf) {
+        char* abase = smem + buf * (2 * GEMM_TILE_BYTES) + wave * 32 * 128;
+        char* bbase = abase + GEMM_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * GEMM_BK),
+                                             (__attribute__((address_space(3))) void*)(abase + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + kt * GEMM_BK),
+                                             (__attribute__((address_space(3))) void*)(bbase + i * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row (16*t + fr) of the wave's 64-row slice, logical chunk 4*ks + fg
+    const int sw = fr & 7;
+    const int a_off = (wm * 64 + fr) * 128;
+    const int b_off = GEMM_TILE_BYTES + (wn * 64 + fr) * 128;
+    const int c0 = ((0 + fg) ^ sw) * 16, c1 = ((4 + fg) ^ sw) * 16;
+
+    const int nk = K / GEMM_BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt have landed
+        __syncthreads();                                      // ... everyone's have; tile kt-1 is fully consumed
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char* base = smem + (kt & 1) * (2 * GEMM_TILE_BYTES);
+        bf16x8 af[4][2], wf[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            af[t][0] = *reinterpret_cast<const bf16x8*>(base + a_off + t * 2048 + c0);
+            af[t][1] = *reinterpret_cast<const bf16x8*>(base + a_off + t * 2048 + c1);
+            wf[t][0] = *reinterpret_cast<const bf16x8*>(base + b_off + t * 2048 + c0);
+            wf[t][1] = *reinterpret_cast<const bf16x8*>(base + b_off + t * 2048 + c1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], af[mt][ks], acc[mt][nt], 0, 0, 0);
+    }
+
+    // --- epilogue: lane holds, per (mt, nt): row m = ..+fr, columns n = ..+4*fg+{0,1,2,3}
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wm * 64 + mt * 16 + fr;
+        if (m >= g.M) continue;
+        size_t orow = (size_t)m;
+        const float* posrow = nullptr;
+        if (EPI == EPI_PATCH_F32) {
+            const int b = m / g.np, p = m - b * g.np;
+            orow = (size_t)b * g.L + 1 + p;
+            posrow = g.pos + (size_t)(1 + p) * g.N;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wn * 64 + nt * 16 + 4 * fg;
+            f32x4 v = acc[mt][nt];
+            if (g.bias) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
+                v += b;
+            }
+            if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16) {
+                if (EPI == EPI_BIAS_QGELU_BF16) {
+                    v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
+                }
+                uint2 o = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                *reinterpret_cast<uint2*>(static_cast<unsigned short*>(g.out) + orow * g.N + n) = o;
+            } else {
+                float* dst = static_cast<float*>(g.out) + orow * g.N + n;
+                if (EPI == EPI_BIAS_RESID_F32) v += *reinterpret_cast<const f32x4*>(dst);
+                if (EPI == EPI_PATCH_F32) v += *reinterpret_cast<const f32x4*>(posrow + n);
+                *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
+    }
+}
+
+// host-side launcher (defined in gemm.hip)
+int launch_gemm(const GemmArgs& g, int epi, hipStream_t st);
+
+}  // namespace clipmi

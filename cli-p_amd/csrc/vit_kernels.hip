@@ -1,0 +1,66 @@
+// vit_kernels.hip — launchers for the non-GEMM tower kernels and their debug entry points.
+#include "vit_kernels.hpp"
+
+namespace clipmi {
+
+int launch_layernorm(const LnArgs& a, hipStream_t st) {
+    if (a.M < 1) return 0;
+    if (a.W % 4 != 0 || a.W > 1024) return set_err(CLIPMI_EINVAL, "layernorm: W=%d (need W %% 4 == 0, W <= 1024)", a.W);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((a.M + 3) / 4), dim3(256), 0, st, a);
+    CLIPMI_CHECK_LAUNCH("layernorm_kernel");
+    return 0;
+}
+
+template <int NT, bool CAUSAL, bool TR>
+static int launch_attn_t(const unsigned short* qkv, unsigned short* out, int B, int L, int heads, hipStream_t st) {
+    constexpr int KS = (NT + 1) / 2;
+    const size_t lds = 4 * KS * 32 * 128;
+    const long long items = (long long)B * heads;
+    hipLaunchKernelGGL((attention_kernel<NT, CAUSAL, TR>), dim3((unsigned)((items + 3) / 4)), dim3(256), lds, st, qkv, out,
+                       B, L, heads);
+    CLIPMI_CHECK_LAUNCH("attention_kernel");
+    return 0;
+}
+
+int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int L, int heads, int causal, int tr,
+                     hipStream_t st) {
+    if (B < 1) return 0;
+    if (L < 1 || L > 80) return set_err(CLIPMI_EUNSUPPORTED, "attention: L=%d (fused short-sequence kernel covers L <= 80)", L);
+    const int nt = (L + 15) / 16;
+#define ATT(NT_)                                                                                         \
+    if (nt <= NT_) {                                                                                     \
+        if (causal) return tr ? launch_attn_t<NT_, true, true>(qkv, out, B, L, heads, st)                \
+                              : launch_attn_t<NT_, true, false>(qkv, out, B, L, heads, st);              \
+        return tr ? launch_attn_t<NT_, false, true>(qkv, out, B, L, heads, st)                           \
+                  : launch_attn_t<NT_, false, false>(qkv, out, B, L, heads, st);                         \
+    }
+    ATT(1) ATT(2) ATT(4) ATT(5)
+#undef ATT
+    return set_err(CLIPMI_EUNSUPPORTED, "attention: L=%d", L);
+}
+
+int launch_patchify(const PatchArgs& a, hipStream_t st) {
+    const long long total = (long long)a.B * a.np * (a.patch_k / 8);
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    CLIPMI_CHECK_LAUNCH("patchify_kernel");
+    return 0;
+}
+
+}  // namespace clipmi
+
+using namespace clipmi;
+
+extern "C" int clipmi_dbg_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, void* out_dev, int M,
+                                    int W, int out_bf16, void* stream) {
+    if (!x_dev || !w_dev || !b_dev || !out_dev) return set_err(CLIPMI_EINVAL, "dbg_layernorm: NULL pointer");
+    LnArgs a{x_dev, w_dev, b_dev, out_dev, nullptr, 1, M, W, out_bf16};
+    return launch_layernorm(a, as_stream(stream));
+}
+
+// `causal` bit 0 = causal mask; bit 1 = use the 2-byte LDS reads instead of ds_read_b64_tr_b16
+extern "C" int clipmi_dbg_attention(const void* qkv_dev, void* out_dev, int B, int L, int heads, int causal,
+                                    void* stream) {
+    if (!qkv_dev || !out_dev) return set_err(CLIPMI_EINVAL, "dbg_attention: NULL pointer");
+    return launch_attention(static_cast<const unsigned short*>(qkv_dev), static_cast<unsigned short*>(out_dev), B, L,
+                            heads, causal & 1, (causal & 2) ? 0 : 1, as_stream(stream));
+}

@@ -1,0 +1,316 @@
+// vit_kernels.hpp — the non-GEMM kernels of the CLIP towers (gfx950): patch extraction with the
+// fused pixel normalisation, CLS/positional rows, LayerNorm, fused small-sequence attention,
+// token embedding and EOT pooling. Reference call sites: model.encode_image (build-index.py:49),
+// model.encode_text (query-index.py:108); op list in SURVEY.md §2.1.
+#pragma once
+#include "gemm.hpp"
+
+namespace clipmi {
+
+// ---------------------------------------------------------------------------------------------
+// patches: pixels [B][3][R][R] (f32 / bf16 normalised, or u8 raw) -> bf16 [B*np][patch_k],
+// column k = c*P*P + py*P + px (conv1.weight flattened), zero beyond 3*P*P. One thread = 8 px.
+// u8 input fuses CLIP's transform tail (x/255 - mean)/std.
+// ---------------------------------------------------------------------------------------------
+struct PatchArgs {
+    const void* pix;
+    unsigned short* out;
+    int dtype, B, R, P, grid, np, patch_k;
+};
+
+static __global__ void __launch_bounds__(256) patchify_kernel(PatchArgs a) {
+    const long long total = (long long)a.B * a.np * (a.patch_k / 8);
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int kc = a.patch_k / 8;
+    const int k8 = (int)(i % kc);
+    const long long bp = i / kc;
+    const int p = (int)(bp % a.np);
+    const int b = (int)(bp / a.np);
+    const int PP = a.P * a.P;
+    const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
+    const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k8 * 8 + j;
+        float x = 0.f;
+        if (k < 3 * PP) {
+            const int c = k / PP, rem = k - c * PP;
+            const int py = rem / a.P, px = rem - py * a.P;
+            const int y = (p / a.grid) * a.P + py, xx = (p % a.grid) * a.P + px;
+            const size_t src = (((size_t)b * 3 + c) * a.R + y) * a.R + xx;
+            if (a.dtype == CLIPMI_F32) x = static_cast<const float*>(a.pix)[src];
+            else if (a.dtype == CLIPMI_BF16) x = bf16_to_f32(static_cast<const unsigned short*>(a.pix)[src]);
+            else x = ((float)static_cast<const unsigned char*>(a.pix)[src] / 255.0f - mean[c]) / stdv[c];
+        }
+        v[j] = x;
+    }
+    uint4 o = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    *reinterpret_cast<uint4*>(a.out + ((size_t)bp * a.patch_k + k8 * 8)) = o;
+}
+
+// x[b*L + 0][:] = class_embedding + positional_embedding[0]
+static __global__ void __launch_bounds__(256) cls_rows_kernel(float* x, const float* cls, const float* pos, int B, int L, int W) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * W) return;
+    const int b = (int)(i / W), c = (int)(i - (long long)b * W);
+    x[(size_t)b * L * W + c] = cls[c] + pos[c];
+}
+
+// x[q*L + t][:] = token_embedding[ids[q][t]] + positional_embedding[t]; one thread = 4 floats
+static __global__ void __launch_bounds__(256) text_embed_kernel(float* x, const int* ids, const float* tok, const float* pos,
+                                                         int Q, int L, int W, int vocab) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int wc = W / 4;
+    if (i >= (long long)Q * L * wc) return;
+    const int c4 = (int)(i % wc);
+    const long long row = i / wc;
+    const int t = (int)(row % L);
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const f32x4 e = *reinterpret_cast<const f32x4*>(tok + (size_t)id * W + c4 * 4);
+    const f32x4 p = *reinterpret_cast<const f32x4*>(pos + (size_t)t * W + c4 * 4);
+    *reinterpret_cast<f32x4*>(x + (size_t)row * W + c4 * 4) = e + p;
+}
+
+// rowidx[q] = q*L + (first argmax of ids[q][:])  — the EOT row of each prompt
+static __global__ void eot_rows_kernel(const int* ids, int* rowidx, int Q, int L) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    int best = ids[(size_t)q * L], bi = 0;
+    for (int t = 1; t < L; ++t) {
+        const int v = ids[(size_t)q * L + t];
+        if (v > best) { best = v; bi = t; }
+    }
+    rowidx[q] = q * L + bi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm(eps 1e-5) over rows of f32 x: one wave per row, values held in registers,
+// two-pass mean / variance as torch does. Source row r is x[rowidx ? rowidx[r] : r*row_step].
+// ---------------------------------------------------------------------------------------------
+struct LnArgs {
+    const float* x;
+    const float* w;
+    const float* b;
+    void* out;            // [M][W] bf16 or f32 (dense rows)
+    const int* rowidx;    // optional gather
+    long long row_step;   // source row stride in ROWS when rowidx == nullptr (1 = dense, L = CLS rows)
+    int M, W, out_bf16;
+};
+
+static __global__ void __launch_bounds__(256) layernorm_kernel(LnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.M) return;
+    const long long src_row = a.rowidx ? (long long)a.rowidx[r] : (long long)r * a.row_step;
+    const float* p = a.x + src_row * a.W;
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 256 + lane * 4;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < a.W) v[i] = *reinterpret_cast<const f32x4*>(p + c);
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)a.W;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < a.W) {
+            const f32x4 d = v[i] - mean;
+            q += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)a.W + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < a.W) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(a.w + c);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(a.b + c);
+            const f32x4 y = (v[i] - mean) * rstd * g + bb;
+            if (a.out_bf16)
+                *reinterpret_cast<uint2*>(static_cast<unsigned short*>(a.out) + (size_t)r * a.W + c) =
+                    make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+            else
+                *reinterpret_cast<f32x4*>(static_cast<float*>(a.out) + (size_t)r * a.W + c) = y;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused attention for short sequences (L <= 16*NT; ViT-B/32: L = 50, text: L = 77), head dim 64.
+// One wave per (sequence, head). qkv bf16 [B*L][3W] (q | k | v, head h at columns 64h..64h+63
+// of each third) -> out bf16 [B*L][W].
+//
+// S^T = K Q^T is computed with the KEY on the accumulator rows and the QUERY on its column
+// (lane & 15): the softmax reduction over keys is then 4*NT in-lane values plus two xor-shuffles,
+// and the P^T accumulator registers ARE the B operand of O^T = V^T P^T with no data movement
+// (k-slot j of lane group g is key 16*(2s + (j>>2)) + 4g + (j&3), for both operands).
+// K and Q fragments come straight from global memory (16 B per lane); V goes through a per-wave
+// LDS tile and is read transposed with ds_read_b64_tr_b16 (TR = 1) or 2-byte reads (TR = 0).
+// Scores, softmax and normalisation are f32; P and the output are rounded to bf16.
+// ---------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int NT, bool CAUSAL, bool TR>
+__global__ void __launch_bounds__(256) attention_kernel(const unsigned short* __restrict__ qkv,
+                                                        unsigned short* __restrict__ out, int B, int L, int heads) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = (NT + 1) / 2;            // 32-key steps of the second product
+    constexpr int ROWS = KS * 32;               // V rows staged (>= 16*NT), zero-weight beyond L
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int W = heads * 64;
+    const long long item = (long long)blockIdx.x * 4 + wave;      // (b, h)
+    if (item >= (long long)B * heads) return;                       // wave-uniform; no block barriers below
+    const int b = (int)(item / heads), h = (int)(item - (long long)b * heads);
+    const unsigned short* base = qkv + (size_t)b * L * 3 * W + h * 64;
+    const size_t rs = (size_t)3 * W;                                // row stride (elements)
+    char* vt = smem + wave * (ROWS * 128);
+
+    // ---- stage V rows [0, ROWS) of this head: 8 rows x 128 B per wave-instruction
+#pragma unroll
+    for (int i = 0; i < ROWS / 8; ++i) {
+        int row = i * 8 + (lane >> 3);
+        const int srcrow = row < L ? row : L - 1;
+        const uint4 d = *reinterpret_cast<const uint4*>(base + (size_t)srcrow * rs + 2 * W + (lane & 7) * 8);
+        *reinterpret_cast<uint4*>(vt + row * 128 + (lane & 7) * 16) = d;
+    }
+
+    // ---- S^T tiles: acc[kt][qt], rows = keys 16kt + 4fg + r, column = query 16qt + fr
+    bf16x8 kf[NT][2], qf[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int row = t * 16 + fr;
+        row = row < L ? row : L - 1;
+        const unsigned short* pr = base + (size_t)row * rs + fg * 8;
+        qf[t][0] = *reinterpret_cast<const bf16x8*>(pr);
+        qf[t][1] = *reinterpret_cast<const bf16x8*>(pr + 32);
+        kf[t][0] = *reinterpret_cast<const bf16x8*>(pr + W);
+        kf[t][1] = *reinterpret_cast<const bf16x8*>(pr + W + 32);
+    }
+    f32x4 s[NT][NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], qf[qt][0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][1], qf[qt][1], a, 0, 0, 0);
+            s[kt][qt] = a;
+        }
+
+    // ---- softmax over keys for each query column (f32): scale 1/8, mask, max, exp, sum
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+        const int qi = qt * 16 + fr;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ki = kt * 16 + 4 * fg + r;
+                float x = s[kt][qt][r] * 0.125f;
+                if (ki >= L || (CAUSAL && ki > qi)) x = -INFINITY;
+                s[kt][qt][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[kt][qt][r] - mx);     // key 0 is never masked: mx is finite
+                s[kt][qt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) s[kt][qt] *= inv;
+    }
+
+    // ---- O^T = V^T P^T: acc o[dt][qt], rows = d 16dt + 4fg + r, column = query
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's V tile is in LDS
+    __builtin_amdgcn_wave_barrier();
+    f32x4 o[4][NT];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 pf[NT];
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            const f32x4 lo = s[2 * ks][qt];
+            f32x4 hi = {0.f, 0.f, 0.f, 0.f};
+            if (2 * ks + 1 < NT) hi = s[2 * ks + 1 < NT ? 2 * ks + 1 : 0][qt];
+            const uint4 u = make_uint4(pack_bf16x2(lo.x, lo.y), pack_bf16x2(lo.z, lo.w), pack_bf16x2(hi.x, hi.y),
+                                       pack_bf16x2(hi.z, hi.w));
+            pf[qt] = __builtin_bit_cast(bf16x8, u);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            bf16x8 vf;
+            if (TR) {
+                // 16-lane group fg reads the 4-key x 16-d block at keys 16*kt' + 4fg, d 16dt..16dt+15;
+                // lane i of the group supplies the address of key (i>>2), d 4*(i&3) and receives d = i
+                const int k0 = 32 * ks + 4 * fg + (fr >> 2);
+                const char* ad = vt + k0 * 128 + (dt * 16 + 4 * (fr & 3)) * 2;
+                const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad));
+                const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad + 16 * 128));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                const s16x8 t = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                vf = __builtin_bit_cast(bf16x8, t);
+            } else {
+                unsigned short e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int key = 16 * (2 * ks + (j >> 2)) + 4 * fg + (j & 3);
+                    e[j] = *reinterpret_cast<const unsigned short*>(vt + key * 128 + (dt * 16 + fr) * 2);
+                }
+                const uint4 u = make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16),
+                                           e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16));
+                vf = __builtin_bit_cast(bf16x8, u);
+            }
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt)
+                o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[dt][qt], 0, 0, 0);
+        }
+    }
+
+    // ---- store: lane holds 4 consecutive d for query 16qt + fr
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+        const int qi = qt * 16 + fr;
+        if (qi >= L) continue;
+        unsigned short* dst = out + ((size_t)b * L + qi) * W + h * 64 + 4 * fg;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const f32x4 v = o[dt][qt];
+            *reinterpret_cast<uint2*>(dst + dt * 16) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        }
+    }
+}
+
+// host launchers (vit_kernels.hip)
+int launch_layernorm(const LnArgs& a, hipStream_t st);
+int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int L, int heads, int causal, int tr,
+                     hipStream_t st);
+int launch_patchify(const PatchArgs& a, hipStream_t st);
+
+}  // namespace clipmi

@@ -1,0 +1,169 @@
+"""Host-side mirror of the `clip` calls the reference scripts make:
+
+    model, transform = clip.load("ViT-B/32", device=device, jit=False)   build-index.py:18, query-index.py:21
+    model.eval()                                                          build-index.py:20
+    transform(image).unsqueeze(0).to(device)                              build-index.py:48
+    model.encode_image(image)                                             build-index.py:49
+    clip.tokenize([in_text]).to(device)                                   query-index.py:107
+    model.encode_text(texts)                                              query-index.py:108
+
+Same names, argument meaning and error behaviour; the arithmetic runs in libclipmi.so
+(clipmi_encode_image / clipmi_encode_text). Differences a caller can see: weights must come from
+a LOCAL file (no download); batches are first-class (the reference feeds B = 1).
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, weights
+
+_DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.uint8: _lib.U8}
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+class _Visual:
+    def __init__(self, res):
+        self.input_resolution = res
+
+
+class CLIP:
+    """Both towers resident in HBM as packed blobs; encode_* enqueue the HIP kernel sequences on
+    torch's current stream and return device tensors (f32 [B, E])."""
+
+    def __init__(self, state_dict, device="cuda:0"):
+        self.device = torch.device(device)
+        self.dims = weights.infer_dims(state_dict)
+        self.vision, self._vblob = weights.pack_vision(state_dict, self.device)
+        self.text, self._tblob = weights.pack_text(state_dict, self.device)
+        self.visual = _Visual(self.dims["res"])
+        self.context_length = self.dims["ctx"]
+        self.embed_dim = self.dims["embed"]
+        self._ws = None
+        self.max_batch = 1024        # images per kernel sequence; larger inputs are chunked
+
+    def eval(self):
+        return self
+
+    def _workspace(self, need):
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _require_gpu(self, what):
+        if self.device.type != "cuda":
+            raise _lib.ClipmiError(f"{what} needs the HIP path (device {self.device} is not a GPU); no CPU fallback")
+
+    def encode_image(self, image, normalize=False):
+        """image: [B,3,R,R] f32/bf16 (output of `transform`, already normalised) or uint8 raw RGB
+        (normalisation fused on the device). Returns f32 [B,E]; `normalize=True` also applies
+        build-index.py:50 (x / x.norm(dim=-1, keepdim=True)) in the same stream."""
+        self._require_gpu("encode_image")
+        L = _lib.lib()
+        if not isinstance(image, torch.Tensor):
+            image = torch.as_tensor(image)
+        R = self.dims["res"]
+        if image.dim() != 4 or image.shape[1] != 3 or image.shape[2] != R or image.shape[3] != R:
+            raise ValueError(f"encode_image: expected [B,3,{R},{R}], got {tuple(image.shape)}")
+        if image.dtype not in _DTYPES:
+            image = image.float()
+        image = image.to(self.device).contiguous()
+        B = image.shape[0]
+        out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=self.device)
+        for lo in range(0, B, self.max_batch):
+            hi = min(B, lo + self.max_batch)
+            need = L.clipmi_encode_image_workspace_bytes(self.vision, hi - lo)
+            if need == 0:
+                raise _lib.ClipmiError("encode_image: " + _lib.last_error())
+            ws = self._workspace(need)
+            rc = L.clipmi_encode_image(self.vision, self._vblob.data_ptr(), image[lo:hi].data_ptr(),
+                                       _DTYPES[image.dtype], hi - lo, out[lo:hi].data_ptr(), int(bool(normalize)),
+                                       ws.data_ptr(), ws.numel(), _lib.stream_ptr(self.device))
+            _lib.check(rc, "clipmi_encode_image")
+        return out
+
+    def encode_text(self, text, normalize=False):
+        """text: int [Q, ctx] token ids (clip.tokenize output). Returns f32 [Q,E]."""
+        self._require_gpu("encode_text")
+        L = _lib.lib()
+        if not isinstance(text, torch.Tensor):
+            text = torch.as_tensor(text)
+        if text.dim() != 2 or text.shape[1] != self.context_length:
+            raise ValueError(f"encode_text: expected [Q,{self.context_length}], got {tuple(text.shape)}")
+        ids = text.to(device=self.device, dtype=torch.int32).contiguous()
+        Q = ids.shape[0]
+        out = torch.empty((Q, self.embed_dim), dtype=torch.float32, device=self.device)
+        for lo in range(0, Q, self.max_batch):
+            hi = min(Q, lo + self.max_batch)
+            need = L.clipmi_encode_text_workspace_bytes(self.text, hi - lo)
+            if need == 0:
+                raise _lib.ClipmiError("encode_text: " + _lib.last_error())
+            ws = self._workspace(need)
+            rc = L.clipmi_encode_text(self.text, self._tblob.data_ptr(), ids[lo:hi].data_ptr(), hi - lo,
+                                      out[lo:hi].data_ptr(), int(bool(normalize)), ws.data_ptr(), ws.numel(),
+                                      _lib.stream_ptr(self.device))
+            _lib.check(rc, "clipmi_encode_text")
+        return out
+
+
+def make_transform(n_px):
+    """The upstream `_transform(n_px)`: Resize(n_px, bicubic) on the shorter side, CenterCrop(n_px),
+    RGB, ToTensor, Normalize(CLIP mean/std) — restated with Pillow + numpy (torchvision is not a
+    dependency). Returns f32 [3, n_px, n_px]."""
+    from PIL import Image
+
+    mean = np.asarray(CLIP_MEAN, np.float32).reshape(3, 1, 1)
+    std = np.asarray(CLIP_STD, np.float32).reshape(3, 1, 1)
+
+    def transform(img):
+        w, h = img.size
+        if not (w <= h and w == n_px) and not (h <= w and h == n_px):
+            if w <= h:
+                nw, nh = n_px, int(n_px * h / w)
+            else:
+                nh, nw = n_px, int(n_px * w / h)
+            img = img.resize((nw, nh), Image.BICUBIC)
+            w, h = nw, nh
+        left = int(round((w - n_px) / 2.0))
+        top = int(round((h - n_px) / 2.0))
+        img = img.crop((left, top, left + n_px, top + n_px)).convert("RGB")
+        a = np.asarray(img, dtype=np.float32).transpose(2, 0, 1) / 255.0
+        return torch.from_numpy((a - mean) / std)
+
+    return transform
+
+
+def available_models():
+    return [k for k in weights.ARCHS if k != "toy"]
+
+
+def load(name, device="cuda" if torch.cuda.is_available() else "cpu", jit=False, seed=None):
+    """clip.load stand-in. `name` is a path to a LOCAL checkpoint with OpenAI key names
+    (TorchScript archive such as ViT-B-32.pt, pickled state-dict, or safetensors). An architecture
+    name ("ViT-B/32") is resolved through $CLIPMI_WEIGHTS_DIR/<name with / -> ->.pt; with
+    `seed` given (or CLIPMI_RANDOM_WEIGHTS=<seed>) seeded random weights of that architecture are
+    used instead — for synthetic benchmarks and tests only. Nothing is ever downloaded."""
+    if device == "cuda":
+        device = "cuda:0"
+    if os.path.exists(name):
+        sd = weights.load_state_dict(name)
+    elif name in weights.ARCHS:
+        env_seed = os.environ.get("CLIPMI_RANDOM_WEIGHTS")
+        wdir = os.environ.get("CLIPMI_WEIGHTS_DIR")
+        cand = os.path.join(wdir, name.replace("/", "-").replace("@", "-") + ".pt") if wdir else None
+        if seed is None and cand and os.path.exists(cand):
+            sd = weights.load_state_dict(cand)
+        elif seed is not None or env_seed is not None:
+            sd = weights.random_state_dict(name, seed=int(seed if seed is not None else env_seed))
+        else:
+            raise RuntimeError(
+                f"Model {name}: no local weights. This build never downloads: pass a checkpoint path, set "
+                "CLIPMI_WEIGHTS_DIR to a directory holding e.g. ViT-B-32.pt, or set CLIPMI_RANDOM_WEIGHTS=<seed> "
+                "for synthetic weights.")
+    else:
+        raise RuntimeError(f"Model {name} not found; available models = {available_models()}")
+    model = CLIP(sd, device=device)
+    return model, make_transform(model.visual.input_resolution)

@@ -25,7 +25,7 @@ ARCHS = {
                            t_width=768, t_layers=12, ctx=77, vocab=49408, embed=768),
     # 2-layer toy used by kernel-level tests (SURVEY.md §8c fixture (i))
     "toy": dict(v_width=128, v_layers=2, patch=32, res=64,
-                t_width=128, t_layers=2, ctx=16, vocab=512, embed=64),
+                t_width=128, t_layers=2, ctx=16, vocab=512, embed=128),
 }
 
 

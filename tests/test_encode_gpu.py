@@ -1,0 +1,127 @@
+"""-m gpu parity of clipmi_encode_image / clipmi_encode_text (through the C ABI, via the
+cli-p_amd.model mirror) against oracle/clip_oracle.py on the same seeded weights and inputs, and
+against the committed golden vectors.
+
+Stated tolerance (floating point; BASELINE.json asks for one): the HIP path stores GEMM weights
+and GEMM-input activations in bf16 with f32 accumulation, f32 residual stream, f32
+LayerNorm/softmax. Its deviation from the fp32 oracle (fed the SAME bf16-rounded weights) must be
+within 3x the deviation that the oracle itself shows when ITS matrix-product inputs are rounded
+to bf16 (measured in the test, typically 1e-2..4e-2 absolute on outputs of magnitude ~5), and the
+row-wise cosine similarity to the oracle must be >= 0.9995 (>= 0.999 against the golden file,
+which used unrounded weights)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, GOLD)
+sys.path.insert(0, ROOT)
+import clip_case  # noqa: E402
+from oracle import clip_oracle  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos(a, b):
+    return torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=-1)
+
+
+def _tolerances(clipmi, sd, fn, x):
+    sdr = clipmi.weights.bf16_round_state_dict(sd)
+    ref = fn(sdr, x)
+    with clip_oracle.act_round(torch.bfloat16):
+        emu = fn(sdr, x)
+    return ref, (emu - ref).abs().max().item()
+
+
+@pytest.mark.parametrize("name", ["toy_seed0", "vitb32_seed0", "vitb32_outlier"])
+def test_encode_image_matches_oracle(clipmi, gpu, name):
+    sd = clip_case.state_dict(name)
+    images, _ = clip_case.inputs(name)
+    model = clipmi.CLIP(sd, device=gpu)
+    got = model.encode_image(images).cpu()
+    ref, noise = _tolerances(clipmi, sd, clip_oracle.encode_image, images)
+    err = (got - ref).abs().max().item()
+    cos = _cos(got, ref).min().item()
+    print(f"{name}: image err {err:.4g} (bf16-emulation noise {noise:.4g}), min cosine {cos:.6f}")
+    assert torch.isfinite(got).all()
+    assert err <= 3 * noise + 1e-3, f"err {err} vs measured bf16 noise {noise}"
+    assert cos >= 0.9995
+    gold = torch.from_numpy(np.load(os.path.join(GOLD, f"clip_{name}.npz"))["image_embeds"])
+    assert _cos(got, gold).min().item() >= 0.999
+    # fused normalise == build-index.py:50 on the unfused result
+    gotn = model.encode_image(images, normalize=True).cpu()
+    assert torch.allclose(gotn, got / got.norm(dim=-1, keepdim=True), atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["toy_seed0", "vitb32_seed0", "vitb32_outlier"])
+def test_encode_text_matches_oracle(clipmi, gpu, name):
+    sd = clip_case.state_dict(name)
+    _, ids = clip_case.inputs(name)
+    model = clipmi.CLIP(sd, device=gpu)
+    got = model.encode_text(ids).cpu()
+    ref, noise = _tolerances(clipmi, sd, clip_oracle.encode_text, ids)
+    err = (got - ref).abs().max().item()
+    cos = _cos(got, ref).min().item()
+    print(f"{name}: text err {err:.4g} (bf16-emulation noise {noise:.4g}), min cosine {cos:.6f}")
+    assert err <= 3 * noise + 1e-3 and cos >= 0.9995
+    gold = torch.from_numpy(np.load(os.path.join(GOLD, f"clip_{name}.npz"))["text_embeds"])
+    assert _cos(got, gold).min().item() >= 0.999
+
+
+def test_encode_image_batch_invariance_and_dtypes(clipmi, gpu):
+    """Rows do not depend on their batch neighbours or on the batch size (M-tail handling), and
+    uint8 input with the fused transform tail equals pre-normalised f32 input."""
+    sd = clip_case.state_dict("vitb32_seed0")
+    model = clipmi.CLIP(sd, device=gpu)
+    g = torch.Generator(device="cpu"); g.manual_seed(7)
+    u8 = torch.randint(0, 256, (131, 3, 224, 224), generator=g, dtype=torch.uint8)
+    mean = torch.tensor(clipmi.model.CLIP_MEAN).reshape(1, 3, 1, 1)
+    std = torch.tensor(clipmi.model.CLIP_STD).reshape(1, 3, 1, 1)
+    f32 = (u8.float() / 255.0 - mean) / std
+    a = model.encode_image(u8).cpu()
+    b = model.encode_image(f32).cpu()
+    assert _cos(a, b).min().item() >= 0.99999 and (a - b).abs().max().item() < 2e-2
+    one = model.encode_image(f32[5:6]).cpu()
+    three = model.encode_image(f32[4:7]).cpu()
+    assert torch.equal(one[0], b[5]) and torch.equal(three[1], b[5])
+    ref = clip_oracle.encode_image(clipmi.weights.bf16_round_state_dict(sd), f32[:2])
+    assert _cos(b[:2], ref).min().item() >= 0.9995
+
+
+def test_encode_text_rows_after_eot_are_ignored(clipmi, gpu):
+    sd = clip_case.state_dict("vitb32_seed0")
+    _, ids = clip_case.inputs("vitb32_seed0")
+    model = clipmi.CLIP(sd, device=gpu)
+    a = model.encode_text(ids).cpu()
+    ids2 = ids.clone(); ids2[0, 6:] = 11
+    b = model.encode_text(ids2).cpu()
+    assert torch.equal(a[0], b[0])
+    # Q = 1 (the reference's query shape) equals row 0 of the batch
+    assert torch.equal(model.encode_text(ids[:1]).cpu()[0], a[0])
+
+
+def test_end_to_end_index_and_query(clipmi, gpu, topk_oracle):
+    """cfg-1 in miniature: encode images, store normalised rows, image-similarity query
+    (query-index.py:86-99) and text query against the index; ids bit-exact vs the oracle top-k
+    over the SAME stored vectors."""
+    sd = clip_case.state_dict("vitb32_seed0")
+    model = clipmi.CLIP(sd, device=gpu)
+    g = torch.Generator(device="cpu"); g.manual_seed(3)
+    imgs = torch.randn(64, 3, 224, 224, generator=g)
+    feats = model.encode_image(imgs, normalize=True)
+    idx = clipmi.IndexFlatIP(512, device=gpu)
+    idx.add(feats)
+    stored = feats.cpu().numpy()
+    D, I = idx.search(stored[10:11], 11)
+    Ds, Is = topk_oracle.topk(stored, stored[10:11], 11)
+    assert np.array_equal(I, Is) and np.array_equal(D.view(np.uint32), Ds.view(np.uint32)) and I[0, 0] == 10
+    _, ids = clip_case.inputs("vitb32_seed0")
+    q = model.encode_text(ids[:1], normalize=True).cpu().numpy()
+    D, I = idx.search(q, 11)
+    Ds, Is = topk_oracle.topk(stored, q, 11)
+    assert np.array_equal(I, Is) and np.array_equal(D.view(np.uint32), Ds.view(np.uint32))

@@ -1,0 +1,135 @@
+"""-m gpu numerics of the individual HIP kernels behind encode_* (through the C ABI debug hooks)
+against plain torch fp32 references of the same op computed on the SAME bf16-rounded inputs, so
+the only differences are accumulation order and the kernel's own output rounding.
+Tolerances: f32 outputs 2e-4 relative to the output scale (f32 accumulation over K <= 3072);
+bf16 outputs one bf16 ulp (2^-8 relative) on top of that."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16)
+
+
+def _qgelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1, 128, 64), (200, 256, 128), (77, 512, 512),
+                                   (6400, 768, 768), (6401, 2304, 768), (1000, 768, 3072), (196, 768, 3072)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm_epilogues(clipmi, gpu, M, N, K, epi):
+    L = clipmi._lib.lib()
+    g = torch.Generator(device="cpu"); g.manual_seed(M * 7 + N + K + epi)
+    a = _bf16(torch.randn(M, K, generator=g)).to(gpu)
+    w = _bf16(torch.randn(N, K, generator=g) * K ** -0.5).to(gpu)
+    bias = torch.randn(N, generator=g).to(gpu)
+    ref = a.float() @ w.float().t() + bias
+    if epi in (0, 1):
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=gpu)
+    elif epi == 2:
+        res = torch.randn(M, N, generator=g).to(gpu)
+        out = res.clone()
+        ref = ref + res
+    else:
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device=gpu)
+    if epi == 1:
+        ref = _qgelu(ref)
+    rc = L.clipmi_dbg_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, epi, None)
+    clipmi._lib.check(rc, "gemm")
+    torch.cuda.synchronize()
+    got = out.float()
+    scale = ref.abs().max().item()
+    tol = 2e-4 * scale + (2.0 ** -8) * scale * (epi in (0, 1))
+    err = (got - ref).abs().max().item()
+    assert torch.isfinite(got).all() and err <= tol, f"M={M} N={N} K={K} epi={epi}: err {err} tol {tol}"
+
+
+def test_gemm_layout_asymmetric(clipmi, gpu):
+    """A = I-like selector with an ASYMMETRIC W catches a transposed or permuted C write."""
+    L = clipmi._lib.lib()
+    M, N, K = 128, 128, 128
+    a = torch.zeros(M, K); a[torch.arange(M), torch.arange(M) % K] = 1.0
+    w = (torch.arange(N).reshape(N, 1) * 3 + torch.arange(K).reshape(1, K) * 0.5).float() / 64.0
+    a, w = _bf16(a).to(gpu), _bf16(w).to(gpu)
+    out = torch.zeros(M, N, dtype=torch.float32, device=gpu)
+    clipmi._lib.check(L.clipmi_dbg_gemm_bf16(a.data_ptr(), w.data_ptr(), None, out.data_ptr(), M, N, K, 3, None), "gemm")
+    torch.cuda.synchronize()
+    assert torch.equal(out, a.float() @ w.float().t())
+
+
+def test_gemm_rejects_bad_shapes(clipmi, gpu):
+    L = clipmi._lib.lib()
+    x = torch.zeros(16, device=gpu)
+    assert L.clipmi_dbg_gemm_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 4, 100, 64, 0, None) == 1
+    assert "N % 128" in clipmi._lib.last_error()
+
+
+@pytest.mark.parametrize("M,W", [(1, 768), (7, 512), (1000, 768), (33, 1024), (5, 128)])
+@pytest.mark.parametrize("out_bf16", [0, 1])
+def test_layernorm(clipmi, gpu, M, W, out_bf16):
+    L = clipmi._lib.lib()
+    g = torch.Generator(device="cpu"); g.manual_seed(M + W)
+    x = (torch.randn(M, W, generator=g) * 3 + 1.5)
+    x[0, 3] = 80.0                                # an outlier channel
+    w = 1 + 0.1 * torch.randn(W, generator=g)
+    b = 0.1 * torch.randn(W, generator=g)
+    ref = torch.nn.functional.layer_norm(x, (W,), w, b, 1e-5)
+    xd, wd, bd = x.to(gpu), w.to(gpu), b.to(gpu)
+    out = torch.empty(M, W, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=gpu)
+    clipmi._lib.check(L.clipmi_dbg_layernorm(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), M, W, out_bf16, None), "ln")
+    torch.cuda.synchronize()
+    err = (out.float().cpu() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= (2e-5 + (2.0 ** -8) * out_bf16) * scale
+
+
+def _attn_ref(qkv, B, L, heads, causal):
+    W = heads * 64
+    x = qkv.float().reshape(B, L, 3, heads, 64)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if causal:
+        s = s + torch.full((L, L), float("-inf")).triu_(1)
+    o = torch.softmax(s, -1) @ v
+    return o.transpose(1, 2).reshape(B * L, W)
+
+
+@pytest.mark.parametrize("B,L,heads,causal", [(3, 50, 12, 0), (2, 77, 8, 1), (5, 5, 2, 0), (4, 16, 2, 1),
+                                              (1, 64, 12, 0), (2, 80, 8, 1), (7, 33, 3, 0), (257, 50, 12, 0)])
+@pytest.mark.parametrize("no_tr", [0, 1])
+def test_attention(clipmi, gpu, B, L, heads, causal, no_tr):
+    Lb = clipmi._lib.lib()
+    g = torch.Generator(device="cpu"); g.manual_seed(B * 100 + L)
+    W = heads * 64
+    qkv = _bf16(torch.randn(B * L, 3 * W, generator=g) * 1.5)
+    ref = _attn_ref(qkv, B, L, heads, causal)
+    qd = qkv.to(gpu)
+    out = torch.full((B * L, W), float("nan"), dtype=torch.bfloat16, device=gpu)
+    clipmi._lib.check(Lb.clipmi_dbg_attention(qd.data_ptr(), out.data_ptr(), B, L, heads, causal | (no_tr << 1), None), "attn")
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    # P is rounded to bf16 before the second product and the output to bf16: 2 ulps of the scale
+    err = (got - ref).abs().max().item()
+    assert err <= 3 * (2.0 ** -8) * ref.abs().max().item(), f"err {err} scale {ref.abs().max().item()}"
+
+
+def test_attention_spiked_softmax(clipmi, gpu):
+    """One key dominates a query by a large margin (exp underflow of the others) — exercises the
+    max-subtraction; result must be that key's V row."""
+    Lb = clipmi._lib.lib()
+    B, L, heads = 1, 50, 1
+    qkv = torch.zeros(B * L, 192)
+    qkv[:, 128:] = torch.randn(L, 64)
+    qkv[7, :64] = 30.0          # query 7
+    qkv[21, 64:128] = 30.0      # key 21 matches it: score 30*30*64/8 = 7200
+    qkv = _bf16(qkv)
+    out = torch.empty(B * L, 64, dtype=torch.bfloat16, device=gpu)
+    qd = qkv.to(gpu)
+    clipmi._lib.check(Lb.clipmi_dbg_attention(qd.data_ptr(), out.data_ptr(), B, L, heads, 0, None), "attn")
+    torch.cuda.synchronize()
+    assert torch.equal(out[7].cpu(), qkv[21, 128:])
