@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path of ps-auxw/CLI-P on MI355X: ViT-B/32 encode_image throughput and exact
+flat inner-product top-50 search, on synthetic data, one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one batch: encode a batch of B synthetic 224x224 uint8
+images on every rank (weak: per-GPU work fixed), then — timed in its own bracket — one search
+batch of Q queries for the best K = 50 + 1 (query-index.py:111: k + offset + 1) over the 10M x 512
+f32 matrix split contiguously over the ranks (strong: total rows fixed), with ONE all-gather of the
+per-rank partial lists and the K-way merge. Rank 0 prints ONE JSON line.
+
+`value` is images/s (BASELINE.json's first metric); the second metric (queries/s) and its own
+roofline and CPU baseline are in the "search" object of the same line.
+"""
+import argparse
+import ctypes as C
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import clipmi  # noqa: E402
+
+FLOP_PER_IMAGE = 8_817_623_040          # ViT-B/32, L = 50, 2 FLOP per MAC
+PEAK_BF16_TFLOPS = 2500.0               # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0                   # MI355X HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
+    ap.add_argument("--rows", type=int, default=10_000_000, help="total rows of the flat index")
+    ap.add_argument("--queries", type=int, default=16, help="queries per search batch")
+    ap.add_argument("--k", type=int, default=50, help="results per query (K = k + 1 is searched)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def bracket(dist, world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def timed(fn, steps, warmup, dist, world):
+    for _ in range(warmup):
+        fn()
+    bracket(dist, world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    bracket(dist, world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def event_avg_ms(fn, reps):
+    """Average duration of `fn`'s launches with HIP events on torch's current stream — the stream
+    the library launches on (cli-p_amd/_lib.stream_ptr)."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json,
+    written by tools/pmc_traffic.py from FETCH_SIZE/WRITE_SIZE with the gfx950 corrections)."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if os.path.isdir(pdir):
+        for f in sorted(os.listdir(pdir)):
+            if f.endswith("_pmc_traffic.json"):
+                try:
+                    d = json.load(open(os.path.join(pdir, f)))
+                    if key in d:
+                        best = d[key]
+                except Exception:
+                    pass
+    return best
+
+
+def cpu_baseline_encode(sd):
+    """Reference semantics on the host cores: JPEG decode + transform + fp32
+    encode at B = 1 per image (build-index.py:47-50) through oracle/clip_oracle.py ("port")."""
+    from PIL import Image
+    from oracle import clip_oracle
+    rng = np.random.default_rng(0)
+    n = 48
+    blobs = []
+    for _ in range(n):
+        buf = io.BytesIO()
+        Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)).save(buf, format="JPEG", quality=95)
+        blobs.append(buf.getvalue())
+    tf = clipmi.make_transform(224)
+    clip_oracle.encode_image(sd, tf(Image.open(io.BytesIO(blobs[0]))).unsqueeze(0))
+    t0 = time.perf_counter()
+    for b in blobs:
+        x = tf(Image.open(io.BytesIO(b))).unsqueeze(0)
+        f = clip_oracle.encode_image(sd, x)
+        f = f / f.norm(dim=-1, keepdim=True)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} synthetic 224x224 JPEGs (quality 95): Pillow decode + transform + oracle fp32 "
+                      f"encode at B=1 per image (reference semantics), torch {torch.__version__} CPU"}
+
+
+def cpu_baseline_search(rows_total, Q, K):
+    """faiss IndexFlatIP stand-in on the host cores: numpy f32 `db @ q.T` + top-K, on a bounded
+    row sample, scaled linearly to the full row count."""
+    n = min(rows_total, 1_000_000)
+    rng = np.random.default_rng(1)
+    db = rng.standard_normal((n, 512), dtype=np.float32)
+    q = rng.standard_normal((Q, 512), dtype=np.float32)
+
+    def once():
+        s = db @ q.T
+        idx = np.argpartition(-s, K, axis=0)[:K]
+        return np.take_along_axis(s, idx, axis=0)
+    once()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    dt = (time.perf_counter() - t0) / reps
+    scale = rows_total / n
+    return {"value": Q / (dt * scale), "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"numpy f32 matmul + argpartition top-{K} over {n} x 512 rows, Q={Q}, time scaled x{scale:g} "
+                      f"to {rows_total} rows"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    L = clipmi._lib.lib()
+
+    # ---------------- encode: synthetic uint8 images resident in HBM, random-init ViT-B/32 -------
+    sd = clipmi.weights.random_state_dict("ViT-B/32", seed=0)
+    model = clipmi.CLIP(sd, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    B = a.batch
+    images = torch.randint(0, 256, (B, 3, 224, 224), generator=g, device=dev, dtype=torch.uint8)
+    enc_out = [None]
+
+    def enc_step():
+        enc_out[0] = model.encode_image(images, normalize=True)
+    dt_enc = timed(enc_step, a.steps, a.warmup, dist, world)
+    img_per_s = world * B * a.steps / dt_enc
+    assert torch.isfinite(enc_out[0]).all()
+
+    # dominant encode kernel, timed alone with HIP events: the MLP c_fc GEMM (+bias+QuickGELU)
+    M, N, Kd = B * 50, 3072, 768
+    ga = torch.randn(M, Kd, generator=g, device=dev).to(torch.bfloat16)
+    gw = (torch.randn(N, Kd, generator=g, device=dev) * Kd ** -0.5).to(torch.bfloat16)
+    gb = torch.randn(N, generator=g, device=dev)
+    go = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+
+    def gemm_once():
+        clipmi._lib.check(L.clipmi_dbg_gemm_bf16(ga.data_ptr(), gw.data_ptr(), gb.data_ptr(), go.data_ptr(), M, N, Kd,
+                                                 1, clipmi._lib.stream_ptr(dev)), "gemm")
+    gemm_ms = event_avg_ms(gemm_once, 20)
+    gemm_tflops = 2.0 * M * N * Kd / (gemm_ms * 1e-3) / 1e12
+    del ga, gw, gb, go
+
+    # ---------------- search: 10M x 512 f32 split over the ranks, Q queries, K = k + 1 -----------
+    K = a.k + 1
+    Q = a.queries
+    lo, hi = clipmi.shard_bounds(a.rows, world, rank)
+    n_local = hi - lo
+    gd = torch.Generator(device=dev)
+    gd.manual_seed(1)            # same stream of rows on every rank count: row r is rank-independent only at N=1;
+    db = torch.empty((n_local, 512), dtype=torch.float32, device=dev)   # the bench needs shape, not identity
+    chunk = 1 << 20
+    for s in range(0, n_local, chunk):
+        e = min(n_local, s + chunk)
+        blk = torch.randn((e - s, 512), generator=gd, device=dev)
+        db[s:e] = blk / blk.norm(dim=1, keepdim=True)
+    idx = clipmi.IndexFlatIP(512, device=dev)
+    idx.add(db)
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(2)
+    q = torch.randn((Q, 512), generator=gq, device=dev)
+    q = q / q.norm(dim=1, keepdim=True)
+    searcher = clipmi.ShardedFlatIP(idx, a.rows) if world > 1 else idx
+    res = [None]
+
+    def search_step():
+        res[0] = searcher.search_device(q, K)
+    dt_s = timed(search_step, a.steps, a.warmup, dist, world)
+    qps = Q * a.steps / dt_s
+    assert (res[0][1][:, 0] >= 0).all()
+
+    # main scan kernel alone, HIP events inside the library on the launch stream
+    ws_need = L.clipmi_topk_ip_workspace_bytes(n_local, 512, min(Q, 16), K)
+    ws = torch.empty(ws_need, dtype=torch.uint8, device=dev)
+    os_ = torch.empty((16, K), dtype=torch.float32, device=dev)
+    oi_ = torch.empty((16, K), dtype=torch.int64, device=dev)
+    scan_ms = C.c_float(0)
+    clipmi._lib.check(L.clipmi_dbg_topk_scan_ms(db.data_ptr(), n_local, 512, q.data_ptr(), min(Q, 16), K, os_.data_ptr(),
+                                                oi_.data_ptr(), ws.data_ptr(), ws.numel(), clipmi._lib.stream_ptr(dev),
+                                                10, C.byref(scan_ms)), "scan_ms")
+    scan_gbs = n_local * 512 * 4 / (scan_ms.value * 1e-3) / 1e9
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    out = {
+        "metric": "images/sec ViT-B/32 encode", "value": img_per_s, "unit": "images/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_enc / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"ViT-B/32 bf16 encode of synthetic 224x224 uint8 images (random-init weights, "
+                               f"L=50, 12 layers), {B} images per GPU per step, fused normalise, inputs resident "
+                               f"in HBM; then exact flat-IP top-{K} (k={a.k}+1, query-index.py:111) over "
+                               f"{a.rows} x 512 f32 split over {world} GPU(s), Q={Q} per batch",
+                   "images_per_gpu_per_step": B, "index_rows_total": a.rows, "queries_per_batch": Q, "K": K},
+        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel<1> (MLP c_fc + bias + QuickGELU, "
+                                                f"M={M} N={N} K={Kd})",
+                     "achieved": gemm_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": gemm_tflops / PEAK_BF16_TFLOPS, "traffic": pmc_traffic("gemm_c_fc_bytes_per_launch"),
+                     "kernel_ms": gemm_ms,
+                     "whole_step_tflops_per_gpu": FLOP_PER_IMAGE * B * a.steps / dt_enc / 1e12,
+                     "whole_step_frac": FLOP_PER_IMAGE * B * a.steps / dt_enc / 1e12 / PEAK_BF16_TFLOPS},
+        "search": {"metric": f"queries/sec top-{a.k} over {a.rows}x512 flat IP (exact, f32)", "value": qps,
+                   "unit": "queries/s", "ms_per_step": dt_s / a.steps * 1e3, "scaling": "strong",
+                   "dtype": "f32", "queries_per_batch": Q, "rows_per_gpu": n_local,
+                   "roofline": {"bound": "hbm", "kernel": "scan_topk_f32_kernel<512,false>",
+                                "achieved": scan_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": scan_gbs / PEAK_HBM_GBS, "traffic": pmc_traffic("scan_bytes_per_launch"),
+                                "kernel_ms": scan_ms.value,
+                                "whole_call_gbs_per_gpu": n_local * 2048 * ((Q + 15) // 16) * a.steps / dt_s / 1e9}},
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_encode(sd)
+        out["search"]["cpu_baseline"] = cpu_baseline_search(a.rows, Q, K)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

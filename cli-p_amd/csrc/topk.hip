@@ -75,7 +75,9 @@ struct ScanArgs {
     long long cap;
 };
 
-template <int E>
+// PREPASS only changes the kernel's NAME (profilers average per name; the threshold pre-pass over
+// a few thousand rows must not dilute the main scan's average duration).
+template <int E, bool PREPASS>
 __global__ void __launch_bounds__(256) scan_topk_f32_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = E / 16;      // float4 per lane per 16-row tile
@@ -439,18 +441,20 @@ bool make_plan(long long N, int E, int Q, int K, Plan& p) {
     return true;
 }
 
-template <int E>
-int launch_scan(const ScanArgs& a, int grid, int waves, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL(scan_topk_f32_kernel<E>, dim3(grid), dim3(waves * 64), lds, st, a);
-    CLIPMI_CHECK_LAUNCH("scan_topk_f32_kernel");
-    return 0;
-}
-
 int opt_in_lds(const void* fn, size_t bytes) {
     if (bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return set_err(CLIPMI_EHIP, "hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
     }
+    return 0;
+}
+
+template <int E, bool PREPASS>
+int launch_scan(const ScanArgs& a, int grid, int waves, size_t lds, hipStream_t st) {
+    const void* fn = (const void*)scan_topk_f32_kernel<E, PREPASS>;
+    if (int rc = opt_in_lds(fn, lds)) return rc;
+    hipLaunchKernelGGL((scan_topk_f32_kernel<E, PREPASS>), dim3(grid), dim3(waves * 64), lds, st, a);
+    CLIPMI_CHECK_LAUNCH("scan_topk_f32_kernel");
     return 0;
 }
 
@@ -469,9 +473,9 @@ extern "C" size_t clipmi_topk_ip_workspace_bytes(int64_t N, int E, int Q, int K)
     return align_up((size_t)p.QA * p.cap * sizeof(uint2), 256) + 256 /*gcnt*/ + 256 /*thr*/ + 256;
 }
 
-extern "C" int clipmi_topk_ip(const void* db_dev, int db_dtype, int64_t N, int E, const float* q_dev, int Q, int K,
-                              int64_t id_base, float* out_score_dev, int64_t* out_id_dev, void* ws_dev,
-                              size_t ws_bytes, void* stream) {
+static int topk_ip_impl(const void* db_dev, int db_dtype, int64_t N, int E, const float* q_dev, int Q, int K,
+                        int64_t id_base, float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes,
+                        void* stream, hipEvent_t* scan_ev) {
     if (db_dtype != CLIPMI_F32) return set_err(CLIPMI_EUNSUPPORTED, "topk_ip: db_dtype %d (only CLIPMI_F32)", db_dtype);
     if (!q_dev || !out_score_dev || !out_id_dev) return set_err(CLIPMI_EINVAL, "topk_ip: NULL pointer");
     if (N >= (1ll << 32) - 1) return set_err(CLIPMI_EINVAL, "topk_ip: N=%lld exceeds 2^32-2 rows per shard", (long long)N);
@@ -494,8 +498,6 @@ extern "C" int clipmi_topk_ip(const void* db_dev, int db_dtype, int64_t N, int E
     unsigned* gcnt = ar.take<unsigned>(16);
     float* thr0 = ar.take<float>(16);
 
-    const void* scan_fn = E == 512 ? (const void*)scan_topk_f32_kernel<512> : (const void*)scan_topk_f32_kernel<768>;
-    if (int rc = opt_in_lds(scan_fn, p.lds_scan)) return rc;
     if (int rc = opt_in_lds((const void*)select_topk_kernel, p.lds_sel)) return rc;
 
     for (int q0 = 0; q0 < Q; q0 += p.QA) {
@@ -516,8 +518,8 @@ extern "C" int clipmi_topk_ip(const void* db_dev, int db_dtype, int64_t N, int E
             // K-th best of all rows; the main pass then only buffers scores >= that bound
             a.nrows = p.sample_rows;
             if (hipMemsetAsync(gcnt, 0, 64, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
-            int rc = E == 512 ? launch_scan<512>(a, p.grid_sample, p.waves, p.lds_scan, st)
-                              : launch_scan<768>(a, p.grid_sample, p.waves, p.lds_scan, st);
+            int rc = E == 512 ? launch_scan<512, true>(a, p.grid_sample, p.waves, p.lds_scan, st)
+                              : launch_scan<768, true>(a, p.grid_sample, p.waves, p.lds_scan, st);
             if (rc) return rc;
             hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, cand, gcnt, p.cap, K,
                                (long long)0, (float*)nullptr, (long long*)nullptr, thr0);
@@ -526,15 +528,50 @@ extern "C" int clipmi_topk_ip(const void* db_dev, int db_dtype, int64_t N, int E
         }
         a.nrows = N;
         if (hipMemsetAsync(gcnt, 0, 64, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
-        int rc = E == 512 ? launch_scan<512>(a, p.grid, p.waves, p.lds_scan, st)
-                          : launch_scan<768>(a, p.grid, p.waves, p.lds_scan, st);
+        if (scan_ev) (void)hipEventRecord(scan_ev[0], st);
+        int rc = E == 512 ? launch_scan<512, false>(a, p.grid, p.waves, p.lds_scan, st)
+                          : launch_scan<768, false>(a, p.grid, p.waves, p.lds_scan, st);
         if (rc) return rc;
+        if (scan_ev) (void)hipEventRecord(scan_ev[1], st);
         hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, cand, gcnt, p.cap, K,
                            (long long)id_base, out_score_dev + (size_t)q0 * K, (long long*)out_id_dev + (size_t)q0 * K,
                            (float*)nullptr);
         CLIPMI_CHECK_LAUNCH("select_topk_kernel");
     }
     return 0;
+}
+
+extern "C" int clipmi_topk_ip(const void* db_dev, int db_dtype, int64_t N, int E, const float* q_dev, int Q, int K,
+                              int64_t id_base, float* out_score_dev, int64_t* out_id_dev, void* ws_dev,
+                              size_t ws_bytes, void* stream) {
+    return topk_ip_impl(db_dev, db_dtype, N, E, q_dev, Q, K, id_base, out_score_dev, out_id_dev, ws_dev, ws_bytes,
+                        stream, nullptr);
+}
+
+// Measurement hook (bench.py roofline): the same call sequence as clipmi_topk_ip, `reps` times,
+// with HIP events recorded on `stream` around the MAIN scan kernel only; synchronises, and
+// returns the average scan-kernel duration in milliseconds through *scan_ms. Q <= 16.
+extern "C" int clipmi_dbg_topk_scan_ms(const void* db_dev, int64_t N, int E, const float* q_dev, int Q, int K,
+                                       float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes,
+                                       void* stream, int reps, float* scan_ms) {
+    if (!scan_ms || reps < 1 || Q > 16) return set_err(CLIPMI_EINVAL, "dbg_topk_scan_ms: bad arguments");
+    hipEvent_t ev[2];
+    if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess)
+        return set_err(CLIPMI_EHIP, "hipEventCreate");
+    double total = 0.0;
+    int rc = 0;
+    for (int i = 0; i < reps && rc == 0; ++i) {
+        rc = topk_ip_impl(db_dev, CLIPMI_F32, N, E, q_dev, Q, K, 0, out_score_dev, out_id_dev, ws_dev, ws_bytes, stream, ev);
+        if (rc) break;
+        if (hipEventSynchronize(ev[1]) != hipSuccess) { rc = set_err(CLIPMI_EHIP, "hipEventSynchronize"); break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+        total += ms;
+    }
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    if (rc == 0) *scan_ms = (float)(total / reps);
+    return rc;
 }
 
 extern "C" size_t clipmi_merge_topk_workspace_bytes(int R, int Q, int K) {

@@ -168,6 +168,12 @@ int clipmi_dbg_layernorm(const float* x_dev, const float* w_dev, const float* b_
 int clipmi_dbg_attention(const void* qkv_dev, void* out_dev, int B, int L, int heads,
                          int causal, void* stream);
 
+/* clipmi_topk_ip's launch sequence `reps` times with HIP events around the MAIN scan kernel on
+ * `stream`; synchronises; *scan_ms = average duration of that kernel (bench.py roofline). Q <= 16 */
+int clipmi_dbg_topk_scan_ms(const void* db_dev, int64_t N, int E, const float* q_dev, int Q, int K,
+                            float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes,
+                            void* stream, int reps, float* scan_ms);
+
 #ifdef __cplusplus
 }
 #endif
