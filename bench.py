@@ -69,20 +69,6 @@ def timed(fn, steps, warmup, dist, world):
     return dt
 
 
-def event_avg_ms(fn, reps):
-    """Average duration of `fn`'s launches with HIP events on torch's current stream — the stream
-    the library launches on (cli-p_amd/_lib.stream_ptr)."""
-    fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
-
-
 def pmc_traffic(key):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json,
     written by tools/pmc_traffic.py from FETCH_SIZE/WRITE_SIZE with the gfx950 corrections)."""
@@ -181,19 +167,20 @@ def main():
     img_per_s = world * B * a.steps / dt_enc
     assert torch.isfinite(enc_out[0]).all()
 
-    # dominant encode kernel, timed alone with HIP events: the MLP c_fc GEMM (+bias+QuickGELU)
+    # dominant encode kernel (MLP c_fc GEMM + bias + QuickGELU, 12 launches per step), timed IN SITU:
+    # HIP events recorded by the library around each of its launches on the launch stream
     M, N, Kd = B * 50, 3072, 768
-    ga = torch.randn(M, Kd, generator=g, device=dev).to(torch.bfloat16)
-    gw = (torch.randn(N, Kd, generator=g, device=dev) * Kd ** -0.5).to(torch.bfloat16)
-    gb = torch.randn(N, generator=g, device=dev)
-    go = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-
-    def gemm_once():
-        clipmi._lib.check(L.clipmi_dbg_gemm_bf16(ga.data_ptr(), gw.data_ptr(), gb.data_ptr(), go.data_ptr(), M, N, Kd,
-                                                 1, clipmi._lib.stream_ptr(dev)), "gemm")
-    gemm_ms = event_avg_ms(gemm_once, 20)
+    need = L.clipmi_encode_image_workspace_bytes(model.vision, B)
+    ews = torch.empty(need, dtype=torch.uint8, device=dev)
+    eout = torch.empty((B, 512), dtype=torch.float32, device=dev)
+    kms, nl = C.c_float(0), C.c_int(0)
+    clipmi._lib.check(L.clipmi_dbg_encode_image_probe_ms(model.vision, model._vblob.data_ptr(), images.data_ptr(),
+                                                         clipmi._lib.U8, B, eout.data_ptr(), ews.data_ptr(), ews.numel(),
+                                                         clipmi._lib.stream_ptr(dev), 1, 3, C.byref(kms), C.byref(nl)),
+                      "encode_image_probe")
+    gemm_ms = kms.value
     gemm_tflops = 2.0 * M * N * Kd / (gemm_ms * 1e-3) / 1e12
-    del ga, gw, gb, go
+    del ews, eout
 
     # ---------------- search: 10M x 512 f32 split over the ranks, Q queries, K = k + 1 -----------
     K = a.k + 1
@@ -253,7 +240,7 @@ def main():
                                                 f"M={M} N={N} K={Kd})",
                      "achieved": gemm_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": gemm_tflops / PEAK_BF16_TFLOPS, "traffic": pmc_traffic("gemm_c_fc_bytes_per_launch"),
-                     "kernel_ms": gemm_ms,
+                     "kernel_ms": gemm_ms, "launches_timed": nl.value,
                      "whole_step_tflops_per_gpu": FLOP_PER_IMAGE * B * a.steps / dt_enc / 1e12,
                      "whole_step_frac": FLOP_PER_IMAGE * B * a.steps / dt_enc / 1e12 / PEAK_BF16_TFLOPS},
         "search": {"metric": f"queries/sec top-{a.k} over {a.rows}x512 flat IP (exact, f32)", "value": qps,

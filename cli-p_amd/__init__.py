@@ -11,7 +11,7 @@ or through the `clipmi` shim module at the repo root.
 """
 from . import _lib
 from ._lib import ClipmiError
-from .index import (IndexFlatIP, ShardedFlatIP, METRIC_INNER_PRODUCT, read_index, write_index,
+from .index import (IndexFlatIP, IndexIVFFlat, ShardedFlatIP, METRIC_INNER_PRODUCT, read_index, write_index,
                     shard_bounds, merge_lists_host)
 
 __all__ = ["_lib", "ClipmiError", "IndexFlatIP", "ShardedFlatIP", "METRIC_INNER_PRODUCT",

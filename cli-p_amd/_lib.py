@@ -20,6 +20,7 @@ SYMBOLS = [
     "clipmi_merge_topk_workspace_bytes", "clipmi_merge_topk",
     "clipmi_l2_normalize_rows", "clipmi_last_error", "clipmi_abi_version",
     "clipmi_dbg_gemm_bf16", "clipmi_dbg_layernorm", "clipmi_dbg_attention", "clipmi_dbg_topk_scan_ms",
+    "clipmi_dbg_encode_image_probe_ms",
 ]
 
 
@@ -84,6 +85,9 @@ def lib():
     L.clipmi_dbg_attention.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.clipmi_dbg_topk_scan_ms.restype = i32
     L.clipmi_dbg_topk_scan_ms.argtypes = [vp, i64, i32, vp, i32, i32, vp, vp, vp, sz, vp, i32, C.POINTER(C.c_float)]
+    L.clipmi_dbg_encode_image_probe_ms.restype = i32
+    L.clipmi_dbg_encode_image_probe_ms.argtypes = [TP, vp, vp, i32, i32, vp, vp, sz, vp, i32, i32,
+                                                   C.POINTER(C.c_float), C.POINTER(C.c_int)]
     if L.clipmi_abi_version() != ABI_VERSION:
         raise ClipmiError(f"libclipmi.so ABI {L.clipmi_abi_version()} != binding {ABI_VERSION}: rebuild")
     _lib = L

@@ -167,3 +167,34 @@ extern "C" int clipmi_encode_text(const clipmi_tower* t, const void* blob_dev, c
     if (int rc = run_layers(t, blob_dev, w, Q, 1, st)) return rc;
     return run_head(t, blob_dev, w, Q, w.rowidx, 1, out_dev, normalize, st);
 }
+
+// Measurement hook (bench.py roofline): clipmi_encode_image `reps` times with HIP events around
+// every launch of the GEMM with epilogue `probe_epi` (1 = MLP c_fc + QuickGELU) on `stream`;
+// synchronises; *kernel_ms = average duration of those launches, *launches = how many were timed.
+extern "C" int clipmi_dbg_encode_image_probe_ms(const clipmi_tower* t, const void* blob_dev, const void* pixels_dev,
+                                                int pix_dtype, int B, float* out_dev, void* ws_dev, size_t ws_bytes,
+                                                void* stream, int probe_epi, int reps, float* kernel_ms, int* launches) {
+    if (!kernel_ms || reps < 1) return set_err(CLIPMI_EINVAL, "dbg_encode_image_probe_ms: bad arguments");
+    GemmProbe& p = gemm_probe();
+    for (int i = 0; i < 2 * GemmProbe::MAX; ++i)
+        if (hipEventCreate(&p.ev[i]) != hipSuccess) return set_err(CLIPMI_EHIP, "hipEventCreate");
+    double total = 0.0;
+    int count = 0, rc = 0;
+    for (int r = 0; r < reps && rc == 0; ++r) {
+        p.active = true; p.epi = probe_epi; p.n = 0;
+        rc = clipmi_encode_image(t, blob_dev, pixels_dev, pix_dtype, B, out_dev, 1, ws_dev, ws_bytes, stream);
+        p.active = false;
+        if (rc) break;
+        if (hipStreamSynchronize(as_stream(stream)) != hipSuccess) { rc = set_err(CLIPMI_EHIP, "hipStreamSynchronize"); break; }
+        for (int i = 0; i < p.n; ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]);
+            total += ms;
+            ++count;
+        }
+    }
+    for (int i = 0; i < 2 * GemmProbe::MAX; ++i) (void)hipEventDestroy(p.ev[i]);
+    if (rc == 0 && count == 0) rc = set_err(CLIPMI_EINVAL, "dbg_encode_image_probe_ms: no launch matched epi %d", probe_epi);
+    if (rc == 0) { *kernel_ms = (float)(total / count); if (launches) *launches = count; }
+    return rc;
+}

@@ -11,7 +11,25 @@ static int launch_epi(const GemmArgs& g, hipStream_t st) {
     return 0;
 }
 
+// Measurement probe (bench.py roofline): while active on this thread, every launch of the GEMM
+// with epilogue `epi` is bracketed by a pair of HIP events on its own stream.
+GemmProbe& gemm_probe() {
+    static thread_local GemmProbe p;
+    return p;
+}
+
+static int launch_gemm_inner(const GemmArgs& g, int epi, hipStream_t st);
+
 int launch_gemm(const GemmArgs& g, int epi, hipStream_t st) {
+    GemmProbe& p = gemm_probe();
+    const bool hit = p.active && p.epi == epi && p.n < GemmProbe::MAX;
+    if (hit) (void)hipEventRecord(p.ev[2 * p.n], st);
+    const int rc = launch_gemm_inner(g, epi, st);
+    if (hit) { (void)hipEventRecord(p.ev[2 * p.n + 1], st); ++p.n; }
+    return rc;
+}
+
+static int launch_gemm_inner(const GemmArgs& g, int epi, hipStream_t st) {
     if (g.M < 1 || g.N < 1 || g.K < 1 || g.N % GEMM_BN != 0 || g.K % GEMM_BK != 0)
         return set_err(CLIPMI_EINVAL, "gemm: M=%d N=%d K=%d (need N %% 128 == 0, K %% 64 == 0)", g.M, g.N, g.K);
     if (!g.A || !g.W || !g.out) return set_err(CLIPMI_EINVAL, "gemm: NULL pointer");

@@ -179,4 +179,12 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
 // host-side launcher (defined in gemm.hip)
 int launch_gemm(const GemmArgs& g, int epi, hipStream_t st);
 
+struct GemmProbe {
+    static constexpr int MAX = 64;
+    bool active = false;
+    int epi = -1, n = 0;
+    hipEvent_t ev[2 * MAX];
+};
+GemmProbe& gemm_probe();
+
 }  // namespace clipmi

@@ -129,6 +129,16 @@ class IndexFlatIP:
         return s.cpu().numpy(), i.cpu().numpy()
 
 
+def IndexIVFFlat(quantizer, d, nlist=100, metric=METRIC_INNER_PRODUCT):
+    """faiss.IndexIVFFlat(quantizer, 512, 100, faiss.METRIC_INNER_PRODUCT) (build-index.py:81) — returns
+    the EXACT flat index: the inverted lists exist to avoid a full scan, which this build performs
+    at HBM speed instead. `nlist` is accepted and ignored; only inner product is supported."""
+    if metric != METRIC_INNER_PRODUCT:
+        raise ValueError("IndexIVFFlat: only METRIC_INNER_PRODUCT is supported")
+    dev = getattr(quantizer, "device", "cuda:0")
+    return IndexFlatIP(d, device=dev)
+
+
 class ShardedFlatIP:
     """Rank-local shard + the one all-gather merge. One process per GPU.
 

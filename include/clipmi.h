@@ -174,6 +174,13 @@ int clipmi_dbg_topk_scan_ms(const void* db_dev, int64_t N, int E, const float* q
                             float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes,
                             void* stream, int reps, float* scan_ms);
 
+/* clipmi_encode_image `reps` times with HIP events around every launch of the GEMM whose
+ * epilogue is `probe_epi` (1 = MLP c_fc + QuickGELU), on `stream`; synchronises;
+ * *kernel_ms = average duration of the timed launches (bench.py roofline) */
+int clipmi_dbg_encode_image_probe_ms(const clipmi_tower* t, const void* blob_dev, const void* pixels_dev,
+                                     int pix_dtype, int B, float* out_dev, void* ws_dev, size_t ws_bytes,
+                                     void* stream, int probe_epi, int reps, float* kernel_ms, int* launches);
+
 #ifdef __cplusplus
 }
 #endif
