@@ -39,7 +39,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
+    # 435 images x 50 tokens = 85 row-tiles of 256: the four GEMM shapes of a layer then need 765 / 255 /
+    # 1020 / 255 tiles = whole rounds of the 256 CUs (tile quantisation is the first-order batch effect)
+    ap.add_argument("--batch", type=int, default=435, help="images per GPU per step")
     ap.add_argument("--rows", type=int, default=10_000_000, help="total rows of the flat index")
     ap.add_argument("--queries", type=int, default=16, help="queries per search batch")
     ap.add_argument("--k", type=int, default=50, help="results per query (K = k + 1 is searched)")
@@ -236,7 +238,7 @@ def main():
                                f"in HBM; then exact flat-IP top-{K} (k={a.k}+1, query-index.py:111) over "
                                f"{a.rows} x 512 f32 split over {world} GPU(s), Q={Q} per batch",
                    "images_per_gpu_per_step": B, "index_rows_total": a.rows, "queries_per_batch": Q, "K": K},
-        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel<1> (MLP c_fc + bias + QuickGELU, "
+        "roofline": {"bound": "mfma", "kernel": "gemm256_bf16_nt_kernel<1> (MLP c_fc + bias + QuickGELU, "
                                                 f"M={M} N={N} K={Kd})",
                      "achieved": gemm_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": gemm_tflops / PEAK_BF16_TFLOPS, "traffic": pmc_traffic("gemm_c_fc_bytes_per_launch"),

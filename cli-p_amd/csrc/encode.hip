@@ -66,19 +66,19 @@ int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int 
         GemmArgs g{};
         g.A = w.h; g.W = at<unsigned short>(blob, lb + t->lo_qkv_w); g.bias = at<float>(blob, lb + t->lo_qkv_b);
         g.out = w.big; g.M = M; g.N = 3 * W; g.K = W;
-        if (int rc = launch_gemm(g, EPI_BIAS_BF16, st)) return rc;
+        if (int rc = launch_gemm_algo(g, EPI_BIAS_BF16, 0, st)) return rc;
         if (int rc = launch_attention(w.big, w.h, B, L, t->heads, causal, 1, st)) return rc;
         g.A = w.h; g.W = at<unsigned short>(blob, lb + t->lo_out_w); g.bias = at<float>(blob, lb + t->lo_out_b);
         g.out = w.x; g.N = W; g.K = W;
-        if (int rc = launch_gemm(g, EPI_BIAS_RESID_F32, st)) return rc;
+        if (int rc = launch_gemm_algo(g, EPI_BIAS_RESID_F32, 0, st)) return rc;
         ln.w = at<float>(blob, lb + t->lo_ln2_w); ln.b = at<float>(blob, lb + t->lo_ln2_b);
         if (int rc = launch_layernorm(ln, st)) return rc;
         g.A = w.h; g.W = at<unsigned short>(blob, lb + t->lo_fc_w); g.bias = at<float>(blob, lb + t->lo_fc_b);
         g.out = w.big; g.N = 4 * W; g.K = W;
-        if (int rc = launch_gemm(g, EPI_BIAS_QGELU_BF16, st)) return rc;
+        if (int rc = launch_gemm_algo(g, EPI_BIAS_QGELU_BF16, 0, st)) return rc;
         g.A = w.big; g.W = at<unsigned short>(blob, lb + t->lo_proj_w); g.bias = at<float>(blob, lb + t->lo_proj_b);
         g.out = w.x; g.N = W; g.K = 4 * W;
-        if (int rc = launch_gemm(g, EPI_BIAS_RESID_F32, st)) return rc;
+        if (int rc = launch_gemm_algo(g, EPI_BIAS_RESID_F32, 0, st)) return rc;
     }
     return 0;
 }
@@ -92,7 +92,7 @@ int run_head(const clipmi_tower* t, const void* blob, const Ws& w, int B, const 
     GemmArgs g{};
     g.A = w.pooled; g.W = at<unsigned short>(blob, t->off_out_proj); g.bias = nullptr; g.out = out;
     g.M = B; g.N = t->embed; g.K = t->width;
-    if (int rc = launch_gemm(g, EPI_F32, st)) return rc;
+    if (int rc = launch_gemm_algo(g, EPI_F32, 0, st)) return rc;
     if (normalize) return clipmi_l2_normalize_rows(out, B, t->embed, st);
     return 0;
 }
@@ -131,7 +131,7 @@ extern "C" int clipmi_encode_image(const clipmi_tower* t, const void* blob_dev, 
     GemmArgs g{};
     g.A = w.patches; g.W = at<unsigned short>(blob_dev, t->off_patch_w); g.bias = nullptr; g.out = w.x;
     g.M = B * np; g.N = W; g.K = t->patch_k; g.pos = at<float>(blob_dev, t->off_pos); g.np = np; g.L = L;
-    if (int rc = launch_gemm(g, EPI_PATCH_F32, st)) return rc;
+    if (int rc = launch_gemm_algo(g, EPI_PATCH_F32, 0, st)) return rc;
     hipLaunchKernelGGL(cls_rows_kernel, dim3((unsigned)(((long long)B * W + 255) / 256)), dim3(256), 0, st, w.x,
                        at<float>(blob_dev, t->off_cls), at<float>(blob_dev, t->off_pos), B, L, W);
     CLIPMI_CHECK_LAUNCH("cls_rows_kernel");

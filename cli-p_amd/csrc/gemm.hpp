@@ -36,8 +36,10 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
 __device__ __forceinline__ float quick_gelu(float x) {
-    // x * sigmoid(1.702 x)   (OpenAI CLIP QuickGELU)
-    return x / (1.0f + __expf(-1.702f * x));
+    // x * sigmoid(1.702 x)   (OpenAI CLIP QuickGELU). v_exp_f32 + v_rcp_f32 (1 ulp): the
+    // result is rounded to bf16 right after, and an IEEE divide costs ~10 VALU ops per element in the
+    // epilogue of the largest GEMM.
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
 }
 
 enum Epilogue {
@@ -72,8 +74,16 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;       // 2x2 waves, each 64 (m) x 64 (n)
     const int fr = lane & 15, fg = lane >> 4;
 
+    // XCD-aware tile order: hardware deals workgroups round-robin over the 8 XCDs (b and b+8 share an
+    // L2), so give each XCD a CONTIGUOUS range of logical tiles; with n fastest, the n-tiles of one
+    // 128-row A panel then run on one XCD and the panel is fetched into one L2 instead of eight
+    // (r01 PMC: 341 MB read per c_fc launch vs 44 MB algorithmic before this remap). Bijective for
+    // any grid size; placement only affects speed.
     const int ntn = g.N / GEMM_BN;
-    const int bm = blockIdx.x / ntn, bn = blockIdx.x - bm * ntn;    // n fastest: neighbours share the A panel
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+    const int bm = tile / ntn, bn = tile - bm * ntn;                // n fastest: neighbours share the A panel
     const int m0 = bm * GEMM_BM, n0 = bn * GEMM_BN;
     const int K = g.K;
 
@@ -178,6 +188,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
 
 // host-side launcher (defined in gemm.hip)
 int launch_gemm(const GemmArgs& g, int epi, hipStream_t st);
+int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st);
 
 struct GemmProbe {
     static constexpr int MAX = 64;

@@ -1,0 +1,229 @@
+// gemm256.hpp — the large-shape bf16 NT GEMM: 256x256x64 block tile, 8 waves, LDS-DMA prefetch kept
+// in flight ACROSS barriers (counted s_waitcnt vmcnt, raw s_barrier), four phases per K-tile and two
+// wave groups running half a phase apart so that one group's MFMA cluster covers the other group's
+// LDS reads and DMA issue (the "8-phase" structure of cdna_hip_programming.md §5, re-derived here).
+//
+// Same contract and epilogues as gemm.hpp (C[m][n] = sum_k A[m][k] W[n][k]); requires N % 256 == 0,
+// K % 64 == 0, K >= 128.
+//
+// LDS (128 KiB, one array): 2 K-tile buffers x [A-lo | A-hi | B-lo | B-hi], each half-tile = 128 rows x
+// 64 bf16 (128-B rows, 16-B chunks XOR-swizzled with row & 7: on the DMA SOURCE address and on the
+// read address; the DMA destination is lane-linear).
+//
+// Wave (wm, wn), wm in {0,1}, wn in {0..3}, owns output rows {wm*64..+63} of BOTH A halves and columns
+// {wn*32..+31} of BOTH B halves, so the four phases of a K-tile touch the half-tiles in the order
+//   P0: A-lo x B-lo   P1: A-lo x B-hi   P2: A-hi x B-hi   P3: A-hi x B-lo
+// and each phase needs at most ONE half-tile that was not needed before. Phase p of K-tile t issues
+// the DMA of half-tile [A-lo, B-lo, B-hi, A-hi][p] of K-tile t+1 into the other buffer: every half-tile
+// has >= 3 phases between its issue and its first read (3 half-tiles = 6 DMA instructions per wave in
+// flight).
+//
+// Ordering argument (slots = intervals between consecutive workgroup barriers; group 1 = waves with
+// wm == 1 runs ONE slot behind group 0):
+//   RAW  a half-tile is read only after (i) every wave has executed the counted vmcnt that retires ITS
+//        two DMA instructions of that half-tile, placed at the end of the load slot of the phase
+//        BEFORE the first read, and (ii) a barrier that follows the later group's wait. The reader's
+//        load slot begins after exactly that barrier.
+//   WAR  a buffer is re-filled for K-tile t+1 from slot 8t on; its last reads (K-tile t-1) complete by
+//        slot 8t-2 (lgkmcnt(0) at the head of every MFMA slot).
+#pragma once
+#include "gemm.hpp"
+
+namespace clipmi {
+
+constexpr int G256_HALF = 128 * 128;            // bytes per half-tile (128 rows x 128 B)
+constexpr int G256_BUF = 4 * G256_HALF;         // 64 KiB per K-tile buffer
+constexpr int G256_LDS = 2 * G256_BUF;          // 128 KiB
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(512, 2) gemm256_bf16_nt_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int ntn = g.N >> 8;
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+    const int bm = tile / ntn, bn = tile - bm * ntn;
+    const int m0 = bm << 8, n0 = bn << 8;
+    const int K = g.K;
+
+    // ---- DMA source pointers: half-tile rows [16*wave, 16*wave+16), two 8-row pieces per wave
+    const int srow = lane >> 3, spos = lane & 7;
+    const unsigned short* src[4][2];            // [A-lo, A-hi, B-lo, B-hi][piece]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 16 + i * 8 + srow;
+        const int chunk = (spos ^ (row & 7)) * 8;
+        int ma = m0 + row, mb = m0 + 128 + row;
+        ma = ma < g.M ? ma : g.M - 1;
+        mb = mb < g.M ? mb : g.M - 1;
+        src[0][i] = g.A + (size_t)ma * K + chunk;
+        src[1][i] = g.A + (size_t)mb * K + chunk;
+        src[2][i] = g.W + (size_t)(n0 + row) * K + chunk;
+        src[3][i] = g.W + (size_t)(n0 + 128 + row) * K + chunk;
+    }
+    const int dma_off = wave * 16 * 128;
+    // issue half-tile H (0..3 as in `src`) of K-tile kt into buffer `buf`
+#define G256_ISSUE(H, kt, buf)                                                                                        \
+    do {                                                                                                              \
+        char* d_ = smem + (buf) * G256_BUF + (H) * G256_HALF + dma_off;                                               \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[H][0] + (kt) * 64),      \
+                                         (__attribute__((address_space(3))) void*)(d_), 16, 0, 0);                    \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[H][1] + (kt) * 64),      \
+                                         (__attribute__((address_space(3))) void*)(d_ + 1024), 16, 0, 0);             \
+    } while (0)
+
+    // ---- fragment read offsets
+    const int sw = fr & 7;
+    const int c0 = ((0 + fg) ^ sw) * 16, c1 = ((4 + fg) ^ sw) * 16;
+    const int offA = (wm * 64 + fr) * 128;                       // + half*16384 + mt*2048
+    const int offB = 2 * G256_HALF + (wn * 32 + fr) * 128;       // + half*16384 + nt*2048
+
+    f32x4 acc[2][4][2][2];     // [A half][mt][B half][nt]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 af[4][2];           // current A half: [mt][ks]
+    bf16x8 bl[2][2], bh[2][2]; // B-lo / B-hi: [nt][ks]
+
+#define G256_READ_A(base, half)                                                                      \
+    _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                               \
+        af[t_][0] = *reinterpret_cast<const bf16x8*>((base) + (half) * G256_HALF + offA + t_ * 2048 + c0); \
+        af[t_][1] = *reinterpret_cast<const bf16x8*>((base) + (half) * G256_HALF + offA + t_ * 2048 + c1); \
+    }
+#define G256_READ_B(dst, base, half)                                                                 \
+    _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {                                               \
+        dst[t_][0] = *reinterpret_cast<const bf16x8*>((base) + (half) * G256_HALF + offB + t_ * 2048 + c0); \
+        dst[t_][1] = *reinterpret_cast<const bf16x8*>((base) + (half) * G256_HALF + offB + t_ * 2048 + c1); \
+    }
+    // MFMA slot: 16 MFMAs of quadrant (A half a, B half b); D = Wfrag x Afrag (C^T tile, see gemm.hpp)
+#define G256_MFMA(a, bfr, b)                                                                         \
+    do {                                                                                             \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        __builtin_amdgcn_s_setprio(1);                                                               \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                          \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
+                _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                     \
+                    acc[a][i_][b][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j_][ks_], af[i_][ks_], acc[a][i_][b][j_], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        __builtin_amdgcn_s_barrier();                                                                \
+    } while (0)
+
+    const int nk = K >> 6;
+    // ---- prologue: K-tile 0 into buffer 0, in the order of first use
+    G256_ISSUE(0, 0, 0);
+    G256_ISSUE(2, 0, 0);
+    G256_ISSUE(3, 0, 0);
+    G256_ISSUE(1, 0, 0);
+    wait_vmcnt<4>();                         // A-lo(0), B-lo(0) landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one slot behind
+
+    for (int t = 0; t < nk - 1; ++t) {
+        const char* cur = smem + (t & 1) * G256_BUF;
+        const int nb = (t + 1) & 1;
+        // P0: A-lo x B-lo
+        G256_READ_B(bl, cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        G256_READ_A(cur, 0);
+        G256_ISSUE(0, t + 1, nb);
+        wait_vmcnt<4>();                     // retires B-hi(t)
+        __builtin_amdgcn_s_barrier();
+        G256_MFMA(0, bl, 0);
+        // P1: A-lo x B-hi
+        G256_READ_B(bh, cur, 1);
+        G256_ISSUE(2, t + 1, nb);
+        wait_vmcnt<4>();                     // retires A-hi(t)
+        __builtin_amdgcn_s_barrier();
+        G256_MFMA(0, bh, 1);
+        // P2: A-hi x B-hi
+        G256_READ_A(cur, 1);
+        G256_ISSUE(3, t + 1, nb);
+        __builtin_amdgcn_s_barrier();
+        G256_MFMA(1, bh, 1);
+        // P3: A-hi x B-lo (B-lo fragments still in registers)
+        G256_ISSUE(1, t + 1, nb);
+        wait_vmcnt<4>();                     // retires A-lo(t+1), B-lo(t+1)
+        __builtin_amdgcn_s_barrier();
+        G256_MFMA(1, bl, 0);
+    }
+    {   // last K-tile: nothing left to prefetch, the counts shrink
+        const char* cur = smem + ((nk - 1) & 1) * G256_BUF;
+        G256_READ_B(bl, cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        G256_READ_A(cur, 0);
+        wait_vmcnt<2>();                     // retires B-hi(last)
+        __builtin_amdgcn_s_barrier();
+        G256_MFMA(0, bl, 0);
+        G256_READ_B(bh, cur, 1);
+        wait_vmcnt<0>();                     // retires A-hi(last)
+        __builtin_amdgcn_s_barrier();
+        G256_MFMA(0, bh, 1);
+        G256_READ_A(cur, 1);
+        __builtin_amdgcn_s_barrier();
+        G256_MFMA(1, bh, 1);
+        __builtin_amdgcn_s_barrier();
+        G256_MFMA(1, bl, 0);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();     // balance the stagger: every wave has the same barrier count
+#undef G256_ISSUE
+#undef G256_READ_A
+#undef G256_READ_B
+#undef G256_MFMA
+
+    // ---- epilogue (same vector forms as gemm.hpp): lane holds row m, 4 consecutive columns n
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + a * 128 + wm * 64 + mt * 16 + fr;
+            if (m >= g.M) continue;
+            size_t orow = (size_t)m;
+            const float* posrow = nullptr;
+            if (EPI == EPI_PATCH_F32) {
+                const int b_ = m / g.np, p_ = m - b_ * g.np;
+                orow = (size_t)b_ * g.L + 1 + p_;
+                posrow = g.pos + (size_t)(1 + p_) * g.N;
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int n = n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg;
+                    f32x4 v = acc[a][mt][b][nt];
+                    if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+                    if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16) {
+                        if (EPI == EPI_BIAS_QGELU_BF16) {
+                            v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
+                        }
+                        *reinterpret_cast<uint2*>(static_cast<unsigned short*>(g.out) + orow * g.N + n) =
+                            make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                    } else {
+                        float* dst = static_cast<float*>(g.out) + orow * g.N + n;
+                        if (EPI == EPI_BIAS_RESID_F32) v += *reinterpret_cast<const f32x4*>(dst);
+                        if (EPI == EPI_PATCH_F32) v += *reinterpret_cast<const f32x4*>(posrow + n);
+                        *reinterpret_cast<f32x4*>(dst) = v;
+                    }
+                }
+        }
+}
+
+}  // namespace clipmi

@@ -15,6 +15,7 @@
 //     a beats b  <=>  a.score > b.score || (a.score == b.score && a.id < b.id); NaN never selected.
 #include "common.hpp"
 #include <float.h>
+#include <hip/hip_ext.h>
 
 namespace clipmi {
 namespace {
@@ -450,10 +451,13 @@ int opt_in_lds(const void* fn, size_t bytes) {
 }
 
 template <int E, bool PREPASS>
-int launch_scan(const ScanArgs& a, int grid, int waves, size_t lds, hipStream_t st) {
+int launch_scan(const ScanArgs& a, int grid, int waves, size_t lds, hipStream_t st, hipEvent_t* ev = nullptr) {
     const void* fn = (const void*)scan_topk_f32_kernel<E, PREPASS>;
     if (int rc = opt_in_lds(fn, lds)) return rc;
-    hipLaunchKernelGGL((scan_topk_f32_kernel<E, PREPASS>), dim3(grid), dim3(waves * 64), lds, st, a);
+    if (ev)   // measurement: the events take the dispatch's own begin/end timestamps
+        hipExtLaunchKernelGGL((scan_topk_f32_kernel<E, PREPASS>), dim3(grid), dim3(waves * 64), lds, st, ev[0], ev[1], 0, a);
+    else
+        hipLaunchKernelGGL((scan_topk_f32_kernel<E, PREPASS>), dim3(grid), dim3(waves * 64), lds, st, a);
     CLIPMI_CHECK_LAUNCH("scan_topk_f32_kernel");
     return 0;
 }
@@ -528,11 +532,9 @@ static int topk_ip_impl(const void* db_dev, int db_dtype, int64_t N, int E, cons
         }
         a.nrows = N;
         if (hipMemsetAsync(gcnt, 0, 64, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
-        if (scan_ev) (void)hipEventRecord(scan_ev[0], st);
-        int rc = E == 512 ? launch_scan<512, false>(a, p.grid, p.waves, p.lds_scan, st)
-                          : launch_scan<768, false>(a, p.grid, p.waves, p.lds_scan, st);
+        int rc = E == 512 ? launch_scan<512, false>(a, p.grid, p.waves, p.lds_scan, st, scan_ev)
+                          : launch_scan<768, false>(a, p.grid, p.waves, p.lds_scan, st, scan_ev);
         if (rc) return rc;
-        if (scan_ev) (void)hipEventRecord(scan_ev[1], st);
         hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, cand, gcnt, p.cap, K,
                            (long long)id_base, out_score_dev + (size_t)q0 * K, (long long*)out_id_dev + (size_t)q0 * K,
                            (float*)nullptr);

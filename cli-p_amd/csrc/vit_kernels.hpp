@@ -31,6 +31,41 @@ static __global__ void __launch_bounds__(256) patchify_kernel(PatchArgs a) {
     const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
     const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
     float v[8];
+    if ((a.P & 7) == 0 && (a.R & 7) == 0) {
+        // 8 consecutive pixels of one patch row: one aligned vector load (8 B for u8, 16 B for bf16,
+        // 2 x 16 B for f32) instead of 8 scalar ones
+        const int k = k8 * 8;
+        if (k < 3 * PP) {
+            const int c = k / PP, rem = k - c * PP;
+            const int py = rem / a.P, px = rem - py * a.P;
+            const int y = (p / a.grid) * a.P + py, xx = (p % a.grid) * a.P + px;
+            const size_t src = (((size_t)b * 3 + c) * a.R + y) * a.R + xx;
+            if (a.dtype == CLIPMI_F32) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.pix) + src);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.pix) + src + 4);
+                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            } else if (a.dtype == CLIPMI_BF16) {
+                const uint4 raw = *reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(a.pix) + src);
+                const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[2 * j] = __uint_as_float(w[j] << 16);
+                    v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+                }
+            } else {
+                const uint2 raw = *reinterpret_cast<const uint2*>(static_cast<const unsigned char*>(a.pix) + src);
+                const float m = mean[c], s = stdv[c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned byte = ((j < 4 ? raw.x : raw.y) >> (8 * (j & 3))) & 0xffu;
+                    v[j] = ((float)byte / 255.0f - m) / s;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = k8 * 8 + j;
@@ -45,6 +80,7 @@ static __global__ void __launch_bounds__(256) patchify_kernel(PatchArgs a) {
             else x = ((float)static_cast<const unsigned char*>(a.pix)[src] / 255.0f - mean[c]) / stdv[c];
         }
         v[j] = x;
+    }
     }
     uint4 o = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
     *reinterpret_cast<uint4*>(a.out + ((size_t)bp * a.patch_k + k8 * 8)) = o;

@@ -133,3 +133,56 @@ def test_attention_spiked_softmax(clipmi, gpu):
     clipmi._lib.check(Lb.clipmi_dbg_attention(qd.data_ptr(), out.data_ptr(), B, L, heads, 0, None), "attn")
     torch.cuda.synchronize()
     assert torch.equal(out[7].cpu(), qkv[21, 128:])
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1, 256, 128), (300, 512, 192), (1024, 768, 768),
+                                   (6400, 2304, 768), (6401, 768, 3072), (25600, 3072, 768), (12544, 768, 3072)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm256_epilogues(clipmi, gpu, M, N, K, epi):
+    """The 256x256 pipelined kernel (forced with bit 9 of `epi`), same references and tolerances.
+    Run twice: the counted-vmcnt / staggered-barrier pipeline must be deterministic."""
+    L = clipmi._lib.lib()
+    g = torch.Generator(device="cpu"); g.manual_seed(M * 7 + N + K + epi)
+    a = _bf16(torch.randn(M, K, generator=g)).to(gpu)
+    w = _bf16(torch.randn(N, K, generator=g) * K ** -0.5).to(gpu)
+    bias = torch.randn(N, generator=g).to(gpu)
+    ref = a.float() @ w.float().t() + bias
+    res = torch.randn(M, N, generator=g).to(gpu) if epi == 2 else None
+    if epi == 2:
+        ref = ref + res
+    if epi == 1:
+        ref = _qgelu(ref)
+    outs = []
+    for _ in range(2):
+        if epi in (0, 1):
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=gpu)
+        elif epi == 2:
+            out = res.clone()
+        else:
+            out = torch.full((M, N), float("nan"), dtype=torch.float32, device=gpu)
+        rc = L.clipmi_dbg_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, epi | (2 << 8), None)
+        clipmi._lib.check(rc, "gemm256")
+        torch.cuda.synchronize()
+        outs.append(out.float())
+    scale = ref.abs().max().item()
+    tol = 2e-4 * scale + (2.0 ** -8) * scale * (epi in (0, 1))
+    err = (outs[0] - ref).abs().max().item()
+    assert torch.isfinite(outs[0]).all() and err <= tol, f"M={M} N={N} K={K} epi={epi}: err {err} tol {tol}"
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_gemm256_layout_asymmetric_and_race_screen(clipmi, gpu):
+    """Exact-integer data (every product and sum exact in f32): any stale or early LDS read in the
+    DMA pipeline shows as a wrong integer. 30 launches on a shape with many K-tiles."""
+    L = clipmi._lib.lib()
+    M, N, K = 2048, 1024, 2048
+    g = torch.Generator(device="cpu"); g.manual_seed(5)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float()
+    ref = (a @ w.t()).to(gpu)
+    a, w = _bf16(a).to(gpu), _bf16(w).to(gpu)
+    for _ in range(30):
+        out = torch.zeros(M, N, dtype=torch.float32, device=gpu)
+        clipmi._lib.check(L.clipmi_dbg_gemm_bf16(a.data_ptr(), w.data_ptr(), None, out.data_ptr(), M, N, K, 3 | (2 << 8), None), "gemm256")
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
