@@ -150,38 +150,65 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], af[mt][ks], acc[mt][nt], 0, 0, 0);
     }
 
-    // --- epilogue: lane holds, per (mt, nt): row m = ..+fr, columns n = ..+4*fg+{0,1,2,3}
+    // --- epilogue: lane holds, per (mt, nt): row m = ..+fr, columns n = ..+4*fg+{0,1,2,3}.
+    // Bias loaded once per lane; the residual read-modify-write is software-pipelined (see gemm256.hpp).
+    f32x4 bz[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + 4 * fg;
+        bz[nt] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    constexpr bool RMW = (EPI == EPI_BIAS_RESID_F32) || (EPI == EPI_PATCH_F32);
+    auto row_of = [&](int mt, size_t& orow, const float*& addrow, bool& valid) {
+        const int m = m0 + wm * 64 + mt * 16 + fr;
+        valid = m < g.M;
+        const int mc = valid ? m : g.M - 1;
+        orow = (size_t)mc;
+        addrow = nullptr;
+        if (EPI == EPI_PATCH_F32) {
+            const int b_ = mc / g.np, p_ = mc - b_ * g.np;
+            orow = (size_t)b_ * g.L + 1 + p_;
+            addrow = g.pos + (size_t)(1 + p_) * g.N;
+        } else if (EPI == EPI_BIAS_RESID_F32) {
+            addrow = static_cast<const float*>(g.out) + orow * g.N;
+        }
+    };
+    f32x4 cur[4], nxt[4];
+    if (RMW) {
+        size_t orow; const float* addrow; bool valid;
+        row_of(0, orow, addrow, valid);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) cur[nt] = *reinterpret_cast<const f32x4*>(addrow + n0 + wn * 64 + nt * 16 + 4 * fg);
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + fr;
-        if (m >= g.M) continue;
-        size_t orow = (size_t)m;
-        const float* posrow = nullptr;
-        if (EPI == EPI_PATCH_F32) {
-            const int b = m / g.np, p = m - b * g.np;
-            orow = (size_t)b * g.L + 1 + p;
-            posrow = g.pos + (size_t)(1 + p) * g.N;
+        size_t orow; const float* addrow; bool valid;
+        row_of(mt, orow, addrow, valid);
+        if (RMW && mt + 1 < 4) {
+            size_t orow2; const float* addrow2; bool valid2;
+            row_of(mt + 1, orow2, addrow2, valid2);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) nxt[nt] = *reinterpret_cast<const f32x4*>(addrow2 + n0 + wn * 64 + nt * 16 + 4 * fg);
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n = n0 + wn * 64 + nt * 16 + 4 * fg;
-            f32x4 v = acc[mt][nt];
-            if (g.bias) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
-                v += b;
-            }
+            f32x4 v = acc[mt][nt] + bz[nt];
             if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16) {
                 if (EPI == EPI_BIAS_QGELU_BF16) {
                     v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
                 }
-                uint2 o = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-                *reinterpret_cast<uint2*>(static_cast<unsigned short*>(g.out) + orow * g.N + n) = o;
+                if (valid)
+                    *reinterpret_cast<uint2*>(static_cast<unsigned short*>(g.out) + orow * g.N + n) =
+                        make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
             } else {
-                float* dst = static_cast<float*>(g.out) + orow * g.N + n;
-                if (EPI == EPI_BIAS_RESID_F32) v += *reinterpret_cast<const f32x4*>(dst);
-                if (EPI == EPI_PATCH_F32) v += *reinterpret_cast<const f32x4*>(posrow + n);
-                *reinterpret_cast<f32x4*>(dst) = v;
+                if (RMW) v += cur[nt];
+                if (valid) *reinterpret_cast<f32x4*>(static_cast<float*>(g.out) + orow * g.N + n) = v;
             }
+        }
+        if (RMW) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cur[nt] = nxt[nt];
         }
     }
 }

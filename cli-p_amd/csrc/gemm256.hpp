@@ -189,41 +189,81 @@ __global__ void __launch_bounds__(512, 2) gemm256_bf16_nt_kernel(GemmArgs g) {
 #undef G256_READ_B
 #undef G256_MFMA
 
-    // ---- epilogue (same vector forms as gemm.hpp): lane holds row m, 4 consecutive columns n
+    // ---- epilogue: lane holds row m and 4 consecutive columns n per (A half, mt, B half, nt).
+    // Bias is loaded ONCE per lane (4 column groups); the f32 read-modify-write of the residual
+    // stream is software-pipelined (loads of row group i+1 are issued before the stores of group i):
+    // vmcnt retires in order, so a load issued behind a store waits for that store too.
+    f32x4 bz[2][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int m = m0 + a * 128 + wm * 64 + mt * 16 + fr;
-            if (m >= g.M) continue;
-            size_t orow = (size_t)m;
-            const float* posrow = nullptr;
-            if (EPI == EPI_PATCH_F32) {
-                const int b_ = m / g.np, p_ = m - b_ * g.np;
-                orow = (size_t)b_ * g.L + 1 + p_;
-                posrow = g.pos + (size_t)(1 + p_) * g.N;
-            }
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg;
+            bz[b][nt] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    constexpr bool RMW = (EPI == EPI_BIAS_RESID_F32) || (EPI == EPI_PATCH_F32);
+    auto row_of = [&](int idx, size_t& orow, const float*& addrow, bool& valid) {
+        const int m = m0 + (idx >> 2) * 128 + wm * 64 + (idx & 3) * 16 + fr;
+        valid = m < g.M;
+        const int mc = valid ? m : g.M - 1;
+        orow = (size_t)mc;
+        addrow = nullptr;
+        if (EPI == EPI_PATCH_F32) {
+            const int b_ = mc / g.np, p_ = mc - b_ * g.np;
+            orow = (size_t)b_ * g.L + 1 + p_;
+            addrow = g.pos + (size_t)(1 + p_) * g.N;
+        } else if (EPI == EPI_BIAS_RESID_F32) {
+            addrow = static_cast<const float*>(g.out) + orow * g.N;
+        }
+    };
+    f32x4 cur[2][2], nxt[2][2];
+    if (RMW) {
+        size_t orow; const float* addrow; bool valid;
+        row_of(0, orow, addrow, valid);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                cur[b][nt] = *reinterpret_cast<const f32x4*>(addrow + n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg);
+    }
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {
+        size_t orow; const float* addrow; bool valid;
+        row_of(idx, orow, addrow, valid);
+        if (RMW && idx + 1 < 8) {
+            size_t orow2; const float* addrow2; bool valid2;
+            row_of(idx + 1, orow2, addrow2, valid2);
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int n = n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg;
-                    f32x4 v = acc[a][mt][b][nt];
-                    if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
-                    if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16) {
-                        if (EPI == EPI_BIAS_QGELU_BF16) {
-                            v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
-                        }
+                for (int nt = 0; nt < 2; ++nt)
+                    nxt[b][nt] = *reinterpret_cast<const f32x4*>(addrow2 + n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int n = n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg;
+                f32x4 v = acc[idx >> 2][idx & 3][b][nt] + bz[b][nt];
+                if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16) {
+                    if (EPI == EPI_BIAS_QGELU_BF16) {
+                        v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
+                    }
+                    if (valid)
                         *reinterpret_cast<uint2*>(static_cast<unsigned short*>(g.out) + orow * g.N + n) =
                             make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-                    } else {
-                        float* dst = static_cast<float*>(g.out) + orow * g.N + n;
-                        if (EPI == EPI_BIAS_RESID_F32) v += *reinterpret_cast<const f32x4*>(dst);
-                        if (EPI == EPI_PATCH_F32) v += *reinterpret_cast<const f32x4*>(posrow + n);
-                        *reinterpret_cast<f32x4*>(dst) = v;
-                    }
+                } else {
+                    if (RMW) v += cur[b][nt];
+                    if (valid) *reinterpret_cast<f32x4*>(static_cast<float*>(g.out) + orow * g.N + n) = v;
                 }
+            }
+        if (RMW) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) cur[b][nt] = nxt[b][nt];
         }
+    }
 }
 
 }  // namespace clipmi
