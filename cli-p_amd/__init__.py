@@ -19,3 +19,5 @@ __all__ = ["_lib", "ClipmiError", "IndexFlatIP", "ShardedFlatIP", "METRIC_INNER_
 from . import weights  # noqa: E402
 from . import model  # noqa: E402
 from .model import CLIP, load, make_transform, available_models  # noqa: E402
+from . import tokenizer, store, pipeline  # noqa: E402
+from .tokenizer import tokenize  # noqa: E402

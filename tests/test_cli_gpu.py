@@ -1,0 +1,110 @@
+"""-m gpu end-to-end checks of the drop-in surface: the build/query scripts on a small synthetic
+photo directory, and the N>1 search path (RCCL process group, clipmi_merge_topk) with one rank."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, unit_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def _load_script(name):
+    spec = importlib.util.spec_from_file_location(name.replace("-", "_"), os.path.join(ROOT, name))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_build_then_query_scripts(clipmi, gpu, tmp_path, monkeypatch, topk_oracle, capsys):
+    from PIL import Image
+    d = tmp_path / "lib"
+    d.mkdir()
+    rng = np.random.default_rng(0)
+    for i in range(37):
+        Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)).save(str(d / f"img_{i:05d}.jpg"), quality=95)
+    (d / "broken.png").write_bytes(b"nope")
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("CLIPMI_RANDOM_WEIGHTS", "0")
+    monkeypatch.setenv("CLIPMI_BATCH", "16")
+    monkeypatch.delenv("CLIPMI_WEIGHTS", raising=False)
+    bi = _load_script("build-index.py")
+    bi.main([str(d) + "/"])
+    out = capsys.readouterr().out
+    assert out.count(".") >= 37 and "#" in out and "Preparing index for 37 entries..." in out and out.rstrip().endswith("Done!")
+    # vectors in the store are the normalised HIP embeddings of the decoded pixels
+    db = clipmi.store.VectorStore("vectors.lmdb", dim=512)
+    model, transform = clipmi.load("ViT-B/32", device=gpu, seed=0)
+    key = str(d) + "/img_00003.jpg"
+    ref = model.encode_image(transform(Image.open(key)).unsqueeze(0), normalize=True).cpu().numpy()
+    got = db.get_vector(key)
+    assert np.abs(got - ref).max() < 2e-3 and abs(np.linalg.norm(got) - 1) < 1e-5
+    # query side: image-similarity query through the REPL, checked against the oracle over the stored rows
+    qi = _load_script("query-index.py")
+    index = clipmi.read_index("images.index", device=gpu)
+    mat, _ = db.assemble()
+    script = iter(["c 10", "i 5", "q"])
+    lines = []
+    qi.repl(model, index, db, inp=lambda p: next(script), out=lambda s: lines.append(s))
+    res = [l for l in lines if l.count(" ") == 2 and l.split()[1].isdigit() and "/img_" in l]
+    D, I = topk_oracle.topk(mat, mat[5:6], 11)
+    assert I[0][0] == 5 and [int(l.split()[1]) for l in res] == list(I[0][1:])
+    db.close()
+
+
+def _nccl_worker(tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import clipmi
+    from conftest import TopkOracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29600 + os.getpid() % 1000)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        rng = np.random.default_rng(5)
+        db = unit_rows(rng, 20000, 512)
+        q = unit_rows(rng, 3, 512)
+        idx = clipmi.IndexFlatIP(512, device="cuda:0")
+        idx.add(db)
+        sh = clipmi.ShardedFlatIP(idx, 20000)
+        D, I = sh.search(q, 51)
+        Ds, Is = TopkOracle().topk(db, q, 51)
+        ok = np.array_equal(I, Is) and np.array_equal(D.view(np.uint32), Ds.view(np.uint32))
+        open(os.path.join(tmp, "ok"), "w").write("1" if ok else "0")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_search_rccl_single_rank(tmp_path):
+    """The RCCL all-gather + device merge path with world_size 1 (one GPU per box here; world 2 runs
+    on gloo in tests/test_host_logic.py). Own process: a process group outlives nothing else."""
+    code = f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}); " \
+           f"import test_cli_gpu as t; t._nccl_worker({str(tmp_path)!r})"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (tmp_path / "ok").read_text() == "1"
+
+
+def test_bench_contract_under_torchrun_one_rank(tmp_path):
+    """bench.py launched the way the driver launches N>1 (torch.distributed.run), with one rank and a
+    small index: one JSON line with the contract's keys."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
+           "--warmup", "1", "--rows", "200000", "--batch", "64", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "search"):
+        assert k in d
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["search"]["value"] > 0
+    assert d["roofline"]["bound"] == "mfma" and d["search"]["roofline"]["bound"] == "hbm"

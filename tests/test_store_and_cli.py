@@ -1,0 +1,175 @@
+"""CPU tests of the storage schema, the host transform and the CLI glue (no GPU: the model and the
+search are stubbed; what is under test is keys, ordering, resume semantics, REPL arithmetic)."""
+import importlib.util
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, unit_rows
+
+
+def _load_script(name):
+    spec = importlib.util.spec_from_file_location(name.replace("-", "_"), os.path.join(ROOT, name))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_packed_store_schema_and_resume(clipmi, tmp_path):
+    p = str(tmp_path / "vectors.lmdb")
+    db = clipmi.store.VectorStore(p, dim=512, backend="packed")
+    rng = np.random.default_rng(0)
+    v = unit_rows(rng, 5, 512)
+    keys = ["/d/b.jpg", "/d/a.jpg", "/d/Z.png", "/d/c.jpeg", "/d/\xe9.jpg"]
+    db.put_vectors(keys[:3], v[:3])
+    db.put_vectors(keys[3:], v[3:])
+    db.mark_skipped(["/d/bad.jpg"])
+    assert db.count() == 5 and db.has_vector("/d/a.jpg") and not db.has_vector("/d/bad.jpg")
+    assert db.is_skipped("/d/bad.jpg") and not db.is_skipped("/d/a.jpg")
+    # value bytes are exactly what build-index.py:51 stores
+    assert db.b.get("fn_db", b"/d/a.jpg") == v[1].astype("float32").tobytes()
+    got = db.get_vector("/d/a.jpg")
+    assert got.shape == (1, 512) and np.array_equal(got[0], v[1])
+    db.close()
+    # torn tail from an interrupted write is ignored; everything committed before it survives
+    with open(os.path.join(p, "fn_db.log"), "ab") as f:
+        f.write(b"\x05\x00\x00\x00\x00\x08\x00\x00abc")
+    db = clipmi.store.VectorStore(p, dim=512, backend="packed")
+    assert db.count() == 5
+    mat, paths = db.assemble()
+    order = sorted(k.encode() for k in keys)             # LMDB key order = bytewise
+    assert paths == order
+    for i, k in enumerate(order):
+        assert np.array_equal(mat[i], v[keys.index(k.decode())])
+        assert db.idx_get(i) == k
+    assert db.idx_get(99) is None
+    db.close()
+
+
+def test_packed_store_refuses_real_lmdb_dir(clipmi, tmp_path):
+    d = tmp_path / "vectors.lmdb"
+    d.mkdir()
+    (d / "data.mdb").write_bytes(b"x")
+    with pytest.raises(RuntimeError, match="lmdb"):
+        clipmi.store.VectorStore(str(d), backend="packed")
+
+
+def test_transform_matches_clip_preprocessing(clipmi):
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    tf = clipmi.make_transform(224)
+    a = rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)
+    t = tf(Image.fromarray(a))
+    mean = np.asarray(clipmi.model.CLIP_MEAN, np.float32).reshape(3, 1, 1)
+    std = np.asarray(clipmi.model.CLIP_STD, np.float32).reshape(3, 1, 1)
+    assert t.shape == (3, 224, 224) and t.dtype == torch.float32
+    assert np.array_equal(t.numpy(), (a.transpose(2, 0, 1).astype(np.float32) / 255.0 - mean) / std)
+    # shorter side -> 224 with Pillow bicubic, then centre crop; grey and RGBA inputs become RGB
+    big = Image.fromarray(rng.integers(0, 256, (300, 500, 3), dtype=np.uint8))
+    ref = big.resize((int(224 * 500 / 300), 224), Image.BICUBIC)
+    left = int(round((ref.size[0] - 224) / 2.0))
+    ref = np.asarray(ref.crop((left, 0, left + 224, 224)), np.float32).transpose(2, 0, 1) / 255.0
+    assert np.array_equal(tf(big).numpy(), (ref - mean) / std)
+    assert tf(Image.fromarray(a[:, :, 0])).shape == (3, 224, 224)
+
+
+def test_pipeline_uint8_equals_transform_pixels(clipmi, tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(2)
+    p = str(tmp_path / "x.png")
+    Image.fromarray(rng.integers(0, 256, (240, 260, 3), dtype=np.uint8)).save(p)
+    u8 = clipmi.pipeline.load_uint8(p, 224)
+    mean = np.asarray(clipmi.model.CLIP_MEAN, np.float32).reshape(3, 1, 1)
+    std = np.asarray(clipmi.model.CLIP_STD, np.float32).reshape(3, 1, 1)
+    assert np.array_equal(clipmi.make_transform(224)(Image.open(p)).numpy(), (u8.astype(np.float32) / 255.0 - mean) / std)
+
+
+class _StubModel:
+    """encode_image/encode_text that are deterministic functions of the input (CPU, test only)."""
+    embed_dim, context_length = 512, 77
+
+    class visual:
+        input_resolution = 224
+
+    device = torch.device("cpu")
+
+    def encode_image(self, x, normalize=False):
+        g = torch.Generator().manual_seed(7)
+        proj = torch.randn(3 * 8 * 8, 512, generator=g)
+        f = torch.nn.functional.avg_pool2d(x.float(), 28).reshape(x.shape[0], -1) @ proj
+        return f / f.norm(dim=-1, keepdim=True) if normalize else f
+
+    def encode_text(self, ids):
+        g = torch.Generator().manual_seed(int(ids.sum()) % 1000)
+        return torch.randn(ids.shape[0], 512, generator=g)
+
+
+def test_build_index_glue_keys_skip_resume(clipmi, tmp_path, monkeypatch, capsys):
+    from PIL import Image
+    bi = _load_script("build-index.py")
+    d = tmp_path / "photos"
+    d.mkdir()
+    rng = np.random.default_rng(3)
+    for n in ("b.jpg", "a.JPG", "c.png", "notes.txt"):
+        if n.endswith("txt"):
+            (d / n).write_text("x")
+        else:
+            Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)).save(str(d / n))
+    (d / "broken.jpeg").write_bytes(b"not an image")
+    base = str(d) + "/"                                   # trailing slash: key = base + name
+    monkeypatch.chdir(tmp_path)
+    db = clipmi.store.VectorStore("vectors.lmdb", dim=512, backend="packed")
+    bi.encode_directories([base], _StubModel(), db, batch=2, workers=2)
+    out = capsys.readouterr().out
+    assert out.startswith(f"CLIPing {base}...") and out.count(".") >= 3 and out.count("#") == 1
+    assert db.count() == 3 and db.is_skipped(base + "broken.jpeg") and db.has_vector(base + "a.JPG")
+    assert bi.candidates(base, db) == []                  # resume: nothing left to do, failures not retried
+    bi.finalise(db, "cpu")
+    out = capsys.readouterr().out
+    assert "Preparing index for 3 entries..." in out and "Generating (3, 512) matrix..." in out and "Saving index..." in out
+    idx = clipmi.read_index("images.index", device="cpu")
+    assert idx.ntotal == 3
+    assert db.idx_get(0) == (base + "a.JPG").encode()     # bytewise key order: 'a.JPG' < 'b.jpg' < 'c.png'
+    row0 = idx.matrix().numpy()[0]
+    assert np.array_equal(row0, db.get_vector(base + "a.JPG")[0]) and abs(np.linalg.norm(row0) - 1) < 1e-5
+    db.close()
+
+
+def test_query_repl_paging_and_similarity(clipmi, tmp_path, monkeypatch, topk_oracle):
+    qi = _load_script("query-index.py")
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(4)
+    N = 300
+    vecs = unit_rows(rng, N, 512)
+    db = clipmi.store.VectorStore("vectors.lmdb", dim=512, backend="packed")
+    keys = [f"/p/{i:04d}.jpg" for i in range(N)]
+    db.put_vectors(keys, vecs)
+    mat, _ = db.assemble()
+
+    class Idx:
+        nprobe = 32
+        calls = []
+
+        def search(self, f, K):
+            self.calls.append(K)
+            return topk_oracle.topk(mat, f, K)
+
+    idx = Idx()
+    script = iter(["h", "p 50", "p 500", "c 5", "i 7", "", "r 640x480", "r junk", "a", "i 99999", "c 0", "q"])
+    lines = []
+    qi.repl(_StubModel(), idx, db, inp=lambda prompt: next(script), out=lambda s: lines.append(s))
+    assert idx.calls == [6]                               # K = k + offset + 1 with k = 5 (query-index.py:111);
+    #                                                       "more results" is ignored until a TEXT query was made
+    assert "Set to probe 50 subsets." in lines and "Invalid probe value." in lines and "Showing 5 results." in lines
+    assert "Similar to /p/0007.jpg:" in lines and "Not found." in lines and "Reset number of results to 50." in lines
+    assert "Set maximum resolution to 640x480." in lines and "Unset maximum resolution." in lines
+    res = [l for l in lines if l.count(" ") == 2 and l.split()[1].isdigit() and l.split()[2].startswith("/p/")]
+    assert len(res) == 5                                  # best hit (the image itself, j = 0) is dropped
+    D, I = topk_oracle.topk(mat, vecs[7:8], 6)
+    assert [int(l.split()[1]) for l in res] == list(I[0][1:]) and I[0][0] == 7
+    assert res[0] == f"{D[0][1]:.4f} {I[0][1]} /p/{I[0][1]:04d}.jpg"
+    db.close()
