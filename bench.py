@@ -39,9 +39,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    # 870 images x 50 tokens = 170 row-tiles of 256: the four GEMM shapes of a layer then need 1530 / 510 /
-    # 2040 / 510 tiles = whole rounds of the 256 CUs (tile quantisation is the first-order batch effect)
-    ap.add_argument("--batch", type=int, default=870, help="images per GPU per step")
+    # 435 images x 50 tokens = 85 row-tiles of 256: the four GEMM shapes of a layer then need 765 / 255 /
+    # 1020 / 255 tiles = whole rounds of the 256 CUs (tile quantisation is the first-order batch effect;
+    # 870 = 170 row-tiles is the next such size and measures the same within 1 %)
+    ap.add_argument("--batch", type=int, default=435, help="images per GPU per step")
     ap.add_argument("--rows", type=int, default=10_000_000, help="total rows of the flat index")
     ap.add_argument("--queries", type=int, default=16, help="queries per search batch")
     ap.add_argument("--k", type=int, default=50, help="results per query (K = k + 1 is searched)")

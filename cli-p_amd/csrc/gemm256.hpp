@@ -189,10 +189,13 @@ __global__ void __launch_bounds__(512, 2) gemm256_bf16_nt_kernel(GemmArgs g) {
 #undef G256_READ_B
 #undef G256_MFMA
 
-    // ---- epilogue: lane holds row m and 4 consecutive columns n per (A half, mt, B half, nt).
-    // Bias is loaded ONCE per lane (4 column groups); the f32 read-modify-write of the residual
-    // stream is software-pipelined (loads of row group i+1 are issued before the stores of group i):
-    // vmcnt retires in order, so a load issued behind a store waits for that store too.
+    // ---- epilogue, staged through LDS (the K-loop's buffers are dead after the last barrier above).
+    // Fragment-shaped stores (16 rows x 32 B per wave-instruction, 32 instructions per lane) made the
+    // tail store-ISSUE-bound: ~12 us per round of tiles, 29 us for the f32 read-modify-write (r01,
+    // tools/gemm_overhead.py). Instead every lane drops its values (bias / QuickGELU applied) into a
+    // row-major LDS image of the tile — 16-byte chunks XOR-swizzled with row & 15 so that the 16 rows
+    // of a fragment column do not share banks — and the tile leaves as whole rows, 16 B per lane,
+    // 512 B..1 KiB contiguous per wave-instruction; the residual / positional add happens on that pass.
     f32x4 bz[2][2];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -201,67 +204,71 @@ __global__ void __launch_bounds__(512, 2) gemm256_bf16_nt_kernel(GemmArgs g) {
             const int n = n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg;
             bz[b][nt] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    constexpr bool RMW = (EPI == EPI_BIAS_RESID_F32) || (EPI == EPI_PATCH_F32);
-    auto row_of = [&](int idx, size_t& orow, const float*& addrow, bool& valid) {
-        const int m = m0 + (idx >> 2) * 128 + wm * 64 + (idx & 3) * 16 + fr;
-        valid = m < g.M;
-        const int mc = valid ? m : g.M - 1;
-        orow = (size_t)mc;
-        addrow = nullptr;
-        if (EPI == EPI_PATCH_F32) {
-            const int b_ = mc / g.np, p_ = mc - b_ * g.np;
-            orow = (size_t)b_ * g.L + 1 + p_;
-            addrow = g.pos + (size_t)(1 + p_) * g.N;
-        } else if (EPI == EPI_BIAS_RESID_F32) {
-            addrow = static_cast<const float*>(g.out) + orow * g.N;
-        }
-    };
-    f32x4 cur[2][2], nxt[2][2];
-    if (RMW) {
-        size_t orow; const float* addrow; bool valid;
-        row_of(0, orow, addrow, valid);
+    __syncthreads();
+    if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16) {
+        // image: 256 rows x 512 B
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                cur[b][nt] = *reinterpret_cast<const f32x4*>(addrow + n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg);
-    }
-#pragma unroll
-    for (int idx = 0; idx < 8; ++idx) {
-        size_t orow; const float* addrow; bool valid;
-        row_of(idx, orow, addrow, valid);
-        if (RMW && idx + 1 < 8) {
-            size_t orow2; const float* addrow2; bool valid2;
-            row_of(idx + 1, orow2, addrow2, valid2);
+        for (int idx = 0; idx < 8; ++idx) {
+            const int row = (idx >> 2) * 128 + wm * 64 + (idx & 3) * 16 + fr;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    nxt[b][nt] = *reinterpret_cast<const f32x4*>(addrow2 + n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg);
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int n = n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg;
-                f32x4 v = acc[idx >> 2][idx & 3][b][nt] + bz[b][nt];
-                if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16) {
+                for (int nt = 0; nt < 2; ++nt) {
+                    f32x4 v = acc[idx >> 2][idx & 3][b][nt] + bz[b][nt];
                     if (EPI == EPI_BIAS_QGELU_BF16) {
                         v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
                     }
-                    if (valid)
-                        *reinterpret_cast<uint2*>(static_cast<unsigned short*>(g.out) + orow * g.N + n) =
-                            make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-                } else {
-                    if (RMW) v += cur[b][nt];
-                    if (valid) *reinterpret_cast<f32x4*>(static_cast<float*>(g.out) + orow * g.N + n) = v;
+                    const int colbyte = (b * 128 + wn * 32 + nt * 16 + 4 * fg) * 2;
+                    const int off = row * 512 + ((((colbyte >> 4) ^ (row & 15)) << 4) | (colbyte & 8));
+                    *reinterpret_cast<uint2*>(smem + off) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                }
+        }
+        __syncthreads();
+        unsigned short* outp = static_cast<unsigned short*>(g.out);
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int row = wave * 32 + i * 2 + (lane >> 5);
+            const int chunk = lane & 31;
+            const uint4 v = *reinterpret_cast<const uint4*>(smem + row * 512 + ((chunk ^ (row & 15)) << 4));
+            const int m = m0 + row;
+            if (m < g.M) *reinterpret_cast<uint4*>(outp + (size_t)m * g.N + n0 + chunk * 8) = v;
+        }
+    } else {
+        // two passes of 128 rows x 1 KiB (f32)
+        float* outp = static_cast<float*>(g.out);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            if (a) __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int row = wm * 64 + mt * 16 + fr;
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const f32x4 v = acc[a][mt][b][nt] + bz[b][nt];
+                        const int chunk = (b * 128 + wn * 32 + nt * 16 + 4 * fg) >> 2;
+                        *reinterpret_cast<f32x4*>(smem + row * 1024 + ((chunk ^ (row & 15)) << 4)) = v;
+                    }
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const int row = wave * 16 + i;
+                f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * 1024 + ((lane ^ (row & 15)) << 4));
+                const int m = m0 + a * 128 + row;
+                if (m < g.M) {
+                    size_t orow = (size_t)m;
+                    if (EPI == EPI_PATCH_F32) {
+                        const int b_ = m / g.np, p_ = m - b_ * g.np;
+                        orow = (size_t)b_ * g.L + 1 + p_;
+                        v += *reinterpret_cast<const f32x4*>(g.pos + (size_t)(1 + p_) * g.N + n0 + lane * 4);
+                    }
+                    float* dst = outp + orow * g.N + n0 + lane * 4;
+                    if (EPI == EPI_BIAS_RESID_F32) v += *reinterpret_cast<const f32x4*>(dst);
+                    *reinterpret_cast<f32x4*>(dst) = v;
                 }
             }
-        if (RMW) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) cur[b][nt] = nxt[b][nt];
         }
     }
 }
