@@ -46,8 +46,8 @@ int check_tower(const clipmi_tower* t, int kind, const char* who) {
         return set_err(CLIPMI_EUNSUPPORTED,
                        "%s: width=%d heads=%d mlp=%d embed=%d (need width %% 128 == 0 <= 1024, head dim 64, embed %% 128 == 0)",
                        who, t->width, t->heads, t->mlp, t->embed);
-    if (t->tokens > 80)
-        return set_err(CLIPMI_EUNSUPPORTED, "%s: %d tokens (fused attention covers <= 80)", who, t->tokens);
+    if (t->tokens > 80 && kind == 1)
+        return set_err(CLIPMI_EUNSUPPORTED, "%s: %d tokens (causal attention covers <= 80)", who, t->tokens);
     return 0;
 }
 

@@ -25,7 +25,16 @@ static int launch_attn_t(const unsigned short* qkv, unsigned short* out, int B, 
 int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int L, int heads, int causal, int tr,
                      hipStream_t st) {
     if (B < 1) return 0;
-    if (L < 1 || L > 80) return set_err(CLIPMI_EUNSUPPORTED, "attention: L=%d (fused short-sequence kernel covers L <= 80)", L);
+    if (L < 1) return set_err(CLIPMI_EINVAL, "attention: L=%d", L);
+    if (L > 80) {
+        if (causal) return set_err(CLIPMI_EUNSUPPORTED, "attention: causal mask with L=%d > 80", L);
+        const int qblocks = (L + 63) / 64;
+        const long long items = (long long)B * heads * qblocks;
+        hipLaunchKernelGGL(attention_flash_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 4 * 64 * 128, st, qkv, out,
+                           B, L, heads, qblocks);
+        CLIPMI_CHECK_LAUNCH("attention_flash_kernel");
+        return 0;
+    }
     const int nt = (L + 15) / 16;
 #define ATT(NT_)                                                                                         \
     if (nt <= NT_) {                                                                                     \

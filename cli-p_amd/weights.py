@@ -23,6 +23,10 @@ ARCHS = {
                      t_width=768, t_layers=12, ctx=77, vocab=49408, embed=768),
     "ViT-L/14@336px": dict(v_width=1024, v_layers=24, patch=14, res=336,
                            t_width=768, t_layers=12, ctx=77, vocab=49408, embed=768),
+    # toy with ViT-L/14@336's awkward geometry: 14-pixel patches (K = 588, zero-padded to 640) and
+    # 101 tokens (> 80: flash-style attention path)
+    "toy-l14": dict(v_width=128, v_layers=2, patch=14, res=140,
+                    t_width=128, t_layers=2, ctx=16, vocab=512, embed=128),
     # 2-layer toy used by kernel-level tests (SURVEY.md §8c fixture (i))
     "toy": dict(v_width=128, v_layers=2, patch=32, res=64,
                 t_width=128, t_layers=2, ctx=16, vocab=512, embed=128),

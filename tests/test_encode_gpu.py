@@ -73,6 +73,43 @@ def test_encode_text_matches_oracle(clipmi, gpu, name):
     assert _cos(got, gold).min().item() >= 0.999
 
 
+def test_encode_image_l14_geometry(clipmi, gpu):
+    """ViT-L/14@336's geometry in miniature: 14-pixel patches (patch K 588 -> 640), 101 tokens
+    (flash attention), checked against the oracle with the same measured tolerance."""
+    sd = clipmi.weights.random_state_dict("toy-l14", seed=3)
+    g = torch.Generator(device="cpu"); g.manual_seed(9)
+    images = torch.randn(5, 3, 140, 140, generator=g)
+    model = clipmi.CLIP(sd, device=gpu)
+    assert model.vision.patch_k == 640 and model.vision.tokens == 101
+    got = model.encode_image(images).cpu()
+    ref, noise = _tolerances(clipmi, sd, clip_oracle.encode_image, images)
+    err = (got - ref).abs().max().item()
+    cos = _cos(got, ref).min().item()
+    print(f"toy-l14: image err {err:.4g} (bf16-emulation noise {noise:.4g}), min cosine {cos:.6f}")
+    assert err <= 3 * noise + 1e-3 and cos >= 0.9995
+
+
+def test_encode_image_vit_l14_336_full_size(clipmi, gpu):
+    """BASELINE.json configs[3]: ViT-L/14@336px (24 layers, width 1024, 577 tokens, 768-D) on seeded
+    weights, two images against the oracle."""
+    sd = clipmi.weights.random_state_dict("ViT-L/14@336px", seed=0)
+    g = torch.Generator(device="cpu"); g.manual_seed(10)
+    images = torch.randn(2, 3, 336, 336, generator=g)
+    model = clipmi.CLIP(sd, device=gpu)
+    assert model.vision.tokens == 577 and model.embed_dim == 768
+    got = model.encode_image(images).cpu()
+    ref, noise = _tolerances(clipmi, sd, clip_oracle.encode_image, images)
+    err = (got - ref).abs().max().item()
+    cos = _cos(got, ref).min().item()
+    print(f"ViT-L/14@336px: image err {err:.4g} (bf16-emulation noise {noise:.4g}), min cosine {cos:.6f}")
+    assert err <= 3 * noise + 1e-3 and cos >= 0.9995
+    # its 768-D vectors search through the same top-k path (E = 768)
+    idx = clipmi.IndexFlatIP(768, device=gpu)
+    idx.add(model.encode_image(images, normalize=True))
+    D, I = idx.search(model.encode_image(images[:1], normalize=True).cpu().numpy(), 2)
+    assert I[0, 0] == 0 and abs(D[0, 0] - 1.0) < 1e-3
+
+
 def test_encode_image_batch_invariance_and_dtypes(clipmi, gpu):
     """Rows do not depend on their batch neighbours or on the batch size (M-tail handling), and
     uint8 input with the fused transform tail equals pre-normalised f32 input."""

@@ -118,6 +118,25 @@ def test_attention(clipmi, gpu, B, L, heads, causal, no_tr):
     assert err <= 3 * (2.0 ** -8) * ref.abs().max().item(), f"err {err} scale {ref.abs().max().item()}"
 
 
+@pytest.mark.parametrize("B,L,heads", [(2, 197, 12), (1, 257, 16), (2, 577, 16), (3, 81, 2), (1, 128, 1), (1, 129, 3)])
+def test_attention_long_sequences(clipmi, gpu, B, L, heads):
+    """Flash-style kernel (L > 80): online softmax over 64-key blocks, no mask."""
+    Lb = clipmi._lib.lib()
+    g = torch.Generator(device="cpu"); g.manual_seed(B * 1000 + L)
+    W = heads * 64
+    qkv = _bf16(torch.randn(B * L, 3 * W, generator=g) * 1.5)
+    qkv[3, :64] *= 6.0                  # one sharp query row: the running max moves between blocks
+    ref = _attn_ref(qkv, B, L, heads, 0)
+    qd = qkv.to(gpu)
+    out = torch.full((B * L, W), float("nan"), dtype=torch.bfloat16, device=gpu)
+    clipmi._lib.check(Lb.clipmi_dbg_attention(qd.data_ptr(), out.data_ptr(), B, L, heads, 0, None), "attn")
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    assert err <= 3 * (2.0 ** -8) * ref.abs().max().item(), f"err {err} scale {ref.abs().max().item()}"
+
+
 def test_attention_spiked_softmax(clipmi, gpu):
     """One key dominates a query by a large margin (exp underflow of the others) — exercises the
     max-subtraction; result must be that key's V row."""
