@@ -191,8 +191,8 @@ def main():
     lo, hi = clipmi.shard_bounds(a.rows, world, rank)
     n_local = hi - lo
     gd = torch.Generator(device=dev)
-    gd.manual_seed(1)            # same stream of rows on every rank count: row r is rank-independent only at N=1;
-    db = torch.empty((n_local, 512), dtype=torch.float32, device=dev)   # the bench needs shape, not identity
+    gd.manual_seed(1000 + rank)  # every shard its own rows (no cross-shard duplicates)
+    db = torch.empty((n_local, 512), dtype=torch.float32, device=dev)
     chunk = 1 << 20
     for s in range(0, n_local, chunk):
         e = min(n_local, s + chunk)

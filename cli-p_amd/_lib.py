@@ -17,7 +17,7 @@ SYMBOLS = [
     "clipmi_encode_image_workspace_bytes", "clipmi_encode_image",
     "clipmi_encode_text_workspace_bytes", "clipmi_encode_text",
     "clipmi_topk_ip_workspace_bytes", "clipmi_topk_ip",
-    "clipmi_merge_topk_workspace_bytes", "clipmi_merge_topk",
+    "clipmi_merge_topk_workspace_bytes", "clipmi_merge_topk", "clipmi_merge_topk_packed",
     "clipmi_l2_normalize_rows", "clipmi_last_error", "clipmi_abi_version",
     "clipmi_dbg_gemm_bf16", "clipmi_dbg_layernorm", "clipmi_dbg_attention", "clipmi_dbg_topk_scan_ms",
     "clipmi_dbg_encode_image_probe_ms",
@@ -75,6 +75,8 @@ def lib():
     L.clipmi_merge_topk_workspace_bytes.argtypes = [i32, i32, i32]
     L.clipmi_merge_topk.restype = i32
     L.clipmi_merge_topk.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, sz, vp]
+    L.clipmi_merge_topk_packed.restype = i32
+    L.clipmi_merge_topk_packed.argtypes = [vp, sz, i32, i32, i32, vp, vp, vp]
     L.clipmi_l2_normalize_rows.restype = i32
     L.clipmi_l2_normalize_rows.argtypes = [vp, i64, i32, vp]
     L.clipmi_dbg_gemm_bf16.restype = i32

@@ -354,6 +354,7 @@ __global__ void fill_empty_kernel(float* out_s, long long* out_i, long long n) {
 // Cross-rank merge: R lists of K (score f32, id i64; id < 0 = empty) per query, rank counting
 // straight from LDS. One block per query.
 __global__ void __launch_bounds__(256) merge_lists_i64_kernel(const float* __restrict__ scores, const long long* __restrict__ ids,
+                                                              long long rstride_s, long long rstride_i,
                                                               int R, int Q, int K, float* out_s, long long* out_i) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -366,9 +367,9 @@ __global__ void __launch_bounds__(256) merge_lists_i64_kernel(const float* __res
     int myvalid = 0;
     for (int e = tid; e < n; e += blockDim.x) {
         const int r = e / K, k = e - r * K;
-        const size_t src = ((size_t)r * Q + q) * K + k;
-        const long long id = ids[src];
-        const float s = scores[src];
+        const size_t src = (size_t)q * K + k;
+        const long long id = ids[(size_t)r * rstride_i + src];
+        const float s = scores[(size_t)r * rstride_s + src];
         const bool ok = id >= 0 && s == s;
         sid[e] = ok ? id : -1;
         ss[e] = s;
@@ -581,17 +582,35 @@ extern "C" size_t clipmi_merge_topk_workspace_bytes(int R, int Q, int K) {
     return 256;   // the merge works out of LDS; a non-zero size keeps callers' allocation paths uniform
 }
 
-extern "C" int clipmi_merge_topk(const float* scores_dev, const int64_t* ids_dev, int R, int Q, int K,
-                                 float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes,
-                                 void* stream) {
-    (void)ws_dev; (void)ws_bytes;
+static int merge_impl(const float* scores_dev, const int64_t* ids_dev, long long rs_s, long long rs_i, int R, int Q,
+                      int K, float* out_score_dev, int64_t* out_id_dev, void* stream) {
     if (!scores_dev || !ids_dev || !out_score_dev || !out_id_dev) return set_err(CLIPMI_EINVAL, "merge_topk: NULL pointer");
     if (R < 1 || Q < 1 || K < 1) return set_err(CLIPMI_EINVAL, "merge_topk: R=%d Q=%d K=%d", R, Q, K);
     const size_t lds = (size_t)R * K * 12 + 16;
     if (lds > (size_t)LDS_LIMIT) return set_err(CLIPMI_EUNSUPPORTED, "merge_topk: R*K=%d too large for one LDS pass", R * K);
     if (int rc = opt_in_lds((const void*)merge_lists_i64_kernel, lds)) return rc;
     hipLaunchKernelGGL(merge_lists_i64_kernel, dim3(Q), dim3(256), lds, as_stream(stream), scores_dev,
-                       (const long long*)ids_dev, R, Q, K, out_score_dev, (long long*)out_id_dev);
+                       (const long long*)ids_dev, rs_s, rs_i, R, Q, K, out_score_dev, (long long*)out_id_dev);
     CLIPMI_CHECK_LAUNCH("merge_lists_i64_kernel");
     return 0;
+}
+
+extern "C" int clipmi_merge_topk(const float* scores_dev, const int64_t* ids_dev, int R, int Q, int K,
+                                 float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes,
+                                 void* stream) {
+    (void)ws_dev; (void)ws_bytes;
+    return merge_impl(scores_dev, ids_dev, (long long)Q * K, (long long)Q * K, R, Q, K, out_score_dev, out_id_dev, stream);
+}
+
+// Same merge over the buffer ONE all-gather produces when every rank contributes a packed record
+// [scores f32 Q*K | pad to 8 B | ids i64 Q*K]: rank r's record starts at gathered_dev + r*record_bytes.
+extern "C" int clipmi_merge_topk_packed(const void* gathered_dev, size_t record_bytes, int R, int Q, int K,
+                                        float* out_score_dev, int64_t* out_id_dev, void* stream) {
+    const size_t ids_off = align_up((size_t)Q * K * 4, 8);
+    if (!gathered_dev || record_bytes < ids_off + (size_t)Q * K * 8 || record_bytes % 8 != 0)
+        return set_err(CLIPMI_EINVAL, "merge_topk_packed: record_bytes %zu for Q=%d K=%d", record_bytes, Q, K);
+    const char* base = static_cast<const char*>(gathered_dev);
+    return merge_impl(reinterpret_cast<const float*>(base), reinterpret_cast<const int64_t*>(base + ids_off),
+                      (long long)(record_bytes / 4), (long long)(record_bytes / 8), R, Q, K, out_score_dev, out_id_dev,
+                      stream);
 }

@@ -98,8 +98,9 @@ class IndexFlatIP:
         return self._db
 
     # -- query side ---------------------------------------------------------------------------
-    def search_device(self, q, K):
-        """q: f32 [Q,d] device tensor -> (scores f32 [Q,K], ids i64 [Q,K]) device tensors. Async."""
+    def search_device(self, q, K, out=None):
+        """q: f32 [Q,d] device tensor -> (scores f32 [Q,K], ids i64 [Q,K]) device tensors. Async.
+        `out` = (scores, ids) views to write into (the packed all-gather record of ShardedFlatIP)."""
         L = _lib.lib()
         db = self.matrix()
         if self.device.type != "cuda":
@@ -112,8 +113,11 @@ class IndexFlatIP:
             raise _lib.ClipmiError("topk_ip: " + _lib.last_error())
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        out_s = torch.empty((Q, K), dtype=torch.float32, device=self.device)
-        out_i = torch.empty((Q, K), dtype=torch.int64, device=self.device)
+        if out is None:
+            out_s = torch.empty((Q, K), dtype=torch.float32, device=self.device)
+            out_i = torch.empty((Q, K), dtype=torch.int64, device=self.device)
+        else:
+            out_s, out_i = out
         rc = L.clipmi_topk_ip(db.data_ptr(), _lib.F32, N, self.d, q.data_ptr(), Q, K, self.id_base,
                               out_s.data_ptr(), out_i.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
                               _lib.stream_ptr(self.device))
@@ -162,37 +166,49 @@ class ShardedFlatIP:
         self._local_search = local_search
         self.nprobe = 1
 
+    def _record(self, Q, K, device):
+        """Per-rank packed record [scores f32 Q*K | pad | ids i64 Q*K] and the gather buffer, cached."""
+        key = (Q, K, str(device))
+        if getattr(self, "_rec_key", None) != key:
+            ids_off = (Q * K * 4 + 7) // 8 * 8
+            nbytes = ids_off + Q * K * 8
+            self._rec = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._gath = torch.empty(self.world * nbytes, dtype=torch.uint8, device=device)
+            self._rec_s = self._rec[:Q * K * 4].view(torch.float32).view(Q, K)
+            self._rec_i = self._rec[ids_off:].view(torch.int64).view(Q, K)
+            self._rec_key = key
+        return self._rec, self._gath, self._rec_s, self._rec_i
+
     def search_device(self, q, K):
         dist = self.dist
-        if self._local_search is not None:           # CPU/gloo test path: host merge
-            s, i = self._local_search(q, K, self.lo)
-            s = torch.as_tensor(s)
-            i = torch.as_tensor(i)
-        else:
-            s, i = self.local.search_device(q, K)
-        gs = [torch.empty_like(s) for _ in range(self.world)]
-        gi = [torch.empty_like(i) for _ in range(self.world)]
-        # one exchange step: scores and ids travel as one packed message per rank
-        packed = torch.cat([s.view(torch.int32).to(torch.int64).reshape(-1), i.reshape(-1)])
-        gathered = [torch.empty_like(packed) for _ in range(self.world)]
-        dist.all_gather(gathered, packed, group=self.group)
-        n = s.numel()
-        for r in range(self.world):
-            gs[r] = gathered[r][:n].to(torch.int32).view(torch.float32).reshape(s.shape)
-            gi[r] = gathered[r][n:].reshape(i.shape)
-        S = torch.stack(gs).contiguous()
-        I = torch.stack(gi).contiguous()
-        Q = s.shape[0]
-        if S.is_cuda:
+        Q = q.shape[0]
+        if self._local_search is None:
+            # GPU path: local top-K written straight into the packed record, ONE all-gather (RCCL),
+            # merge kernel on the gathered buffer — three enqueues, no host round trip
+            dev = self.local.device
+            rec, gath, rec_s, rec_i = self._record(Q, K, dev)
+            self.local.search_device(q, K, out=(rec_s, rec_i))
+            dist.all_gather_into_tensor(gath, rec, group=self.group)
             L = _lib.lib()
-            out_s = torch.empty((Q, K), dtype=torch.float32, device=S.device)
-            out_i = torch.empty((Q, K), dtype=torch.int64, device=S.device)
-            ws = torch.empty(256, dtype=torch.uint8, device=S.device)
-            rc = L.clipmi_merge_topk(S.data_ptr(), I.data_ptr(), self.world, Q, K, out_s.data_ptr(),
-                                     out_i.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(S.device))
-            _lib.check(rc, "clipmi_merge_topk")
+            out_s = torch.empty((Q, K), dtype=torch.float32, device=dev)
+            out_i = torch.empty((Q, K), dtype=torch.int64, device=dev)
+            rc = L.clipmi_merge_topk_packed(gath.data_ptr(), rec.numel(), self.world, Q, K, out_s.data_ptr(),
+                                            out_i.data_ptr(), _lib.stream_ptr(dev))
+            _lib.check(rc, "clipmi_merge_topk_packed")
             return out_s, out_i
-        ms, mi = merge_lists_host(S.numpy(), I.numpy(), K)
+        # CPU / gloo path (tests of the host logic): same record, host merge
+        s, i = self._local_search(q, K, self.lo)
+        s = torch.as_tensor(np.ascontiguousarray(s, dtype=np.float32))
+        i = torch.as_tensor(np.ascontiguousarray(i, dtype=np.int64))
+        rec, gath, rec_s, rec_i = self._record(Q, K, torch.device("cpu"))
+        rec_s.copy_(s)
+        rec_i.copy_(i)
+        dist.all_gather_into_tensor(gath, rec, group=self.group)
+        n = rec.numel()
+        ids_off = (Q * K * 4 + 7) // 8 * 8
+        S = np.stack([gath[r * n:r * n + Q * K * 4].view(torch.float32).view(Q, K).numpy() for r in range(self.world)])
+        I = np.stack([gath[r * n + ids_off:(r + 1) * n].view(torch.int64).view(Q, K).numpy() for r in range(self.world)])
+        ms, mi = merge_lists_host(S, I, K)
         return torch.from_numpy(ms), torch.from_numpy(mi)
 
     def search(self, x, K):

@@ -145,6 +145,12 @@ int clipmi_merge_topk(const float* scores_dev, const int64_t* ids_dev, int R, in
                       float* out_score_dev, int64_t* out_id_dev,
                       void* ws_dev, size_t ws_bytes, void* stream);
 
+/* The same merge over the buffer ONE all-gather yields when every rank contributes a packed record
+ * [scores f32 Q*K | pad to 8 B | ids int64 Q*K] of record_bytes (a multiple of 8): rank r's record is at
+ * gathered_dev + r * record_bytes. Lets the N>1 search path be: top-k -> one collective -> merge. */
+int clipmi_merge_topk_packed(const void* gathered_dev, size_t record_bytes, int R, int Q, int K,
+                             float* out_score_dev, int64_t* out_id_dev, void* stream);
+
 /* ---- a4/a10 stand-alone: rows of x[n][E] scaled to unit L2 norm in place (rows with
  * norm < 1e-9 are left unchanged, as query-index.py:13-17 does). */
 int clipmi_l2_normalize_rows(float* x_dev, int64_t n, int E, void* stream);
