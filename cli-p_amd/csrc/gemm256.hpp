@@ -50,10 +50,8 @@ __global__ void __launch_bounds__(512, 2) gemm256_bf16_nt_kernel(GemmArgs g) {
     const int fr = lane & 15, fg = lane >> 4;
 
     const int ntn = g.N >> 8;
-    const int nwg = gridDim.x;
-    const int xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-    const int bm = tile / ntn, bn = tile - bm * ntn;
+    int bm, bn;
+    gemm_tile_coords(blockIdx.x, gridDim.x, (g.M + 255) >> 8, ntn, 8, 4, bm, bn);
     const int m0 = bm << 8, n0 = bn << 8;
     const int K = g.K;
 
