@@ -102,16 +102,32 @@ def cpu_baseline_encode(sd):
         Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)).save(buf, format="JPEG", quality=95)
         blobs.append(buf.getvalue())
     tf = clipmi.make_transform(224)
-    clip_oracle.encode_image(sd, tf(Image.open(io.BytesIO(blobs[0]))).unsqueeze(0))
-    t0 = time.perf_counter()
-    for b in blobs:
-        x = tf(Image.open(io.BytesIO(b))).unsqueeze(0)
-        f = clip_oracle.encode_image(sd, x)
-        f = f / f.norm(dim=-1, keepdim=True)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+
+    def run(items):
+        t0 = time.perf_counter()
+        for b in items:
+            x = tf(Image.open(io.BytesIO(b))).unsqueeze(0)
+            f = clip_oracle.encode_image(sd, x)
+            f = f / f.norm(dim=-1, keepdim=True)
+        return time.perf_counter() - t0
+
+    # B = 1 matmuls do not scale to every host core: try torch's default thread count (what the
+    # reference would get) and a moderate one, keep the faster, and say which was used
+    default_threads = torch.get_num_threads()
+    best_threads, best_rate = default_threads, 0.0
+    for nt in sorted({default_threads, min(default_threads, 16), min(default_threads, 32)}):
+        torch.set_num_threads(nt)
+        run(blobs[:2])
+        rate = 6 / run(blobs[:6])
+        if rate > best_rate:
+            best_threads, best_rate = nt, rate
+    torch.set_num_threads(best_threads)
+    dt = run(blobs)
+    torch.set_num_threads(default_threads)
+    return {"value": n / dt, "unit": "images/s", "cores": best_threads, "kind": "port",
             "sample": f"{n} synthetic 224x224 JPEGs (quality 95): Pillow decode + transform + oracle fp32 "
-                      f"encode at B=1 per image (reference semantics), torch {torch.__version__} CPU"}
+                      f"encode at B=1 per image (reference semantics), torch {torch.__version__} CPU, "
+                      f"{best_threads} threads (fastest of default {default_threads} / 32 / 16)"}
 
 
 def cpu_baseline_search(rows_total, Q, K):

@@ -217,25 +217,53 @@ class ShardedFlatIP:
         return s.cpu().numpy(), i.cpu().numpy()
 
 
-def write_index(index, path):
-    """faiss.write_index stand-in (build-index.py:109). Own packed format, little-endian:
-    8-byte magic, u32 version, u32 d, u64 ntotal, then ntotal*d f32 rows. (A faiss-readable
-    IndexFlatIP writer is SURVEY.md §8f next-3.)"""
-    db = index.matrix().cpu().numpy()
+FAISS_FOURCC_FLAT_IP = b"IxFI"
+
+
+def write_index(index, path, format="clipmi"):
+    """faiss.write_index stand-in (build-index.py:109).
+    format="clipmi": own packed format, little-endian: 8-byte magic, u32 version, u32 d, u64 ntotal, then
+        ntotal*d f32 rows.
+    format="faiss": the serialisation of a faiss IndexFlatIP as published in faiss/impl/index_write.cpp
+        (fourcc "IxFI"; header d:i32, ntotal:i64, two i64 placeholders = 1<<20, is_trained:u8,
+        metric_type:i32 = 0; then u64 count of floats + the f32 rows), so that the ORIGINAL
+        query-index.py:29 (`faiss.read_index("images.index")`) can open an index built here
+        (SURVEY.md §8f next-3). faiss is not available offline: this layout is restated from the
+        upstream source, PARITY UNPINNED until checked against a real faiss build."""
+    db = np.ascontiguousarray(index.matrix().cpu().numpy(), dtype="<f4")
     with open(path, "wb") as f:
-        f.write(MAGIC + struct.pack("<IIQ", 1, index.d, db.shape[0]))
-        f.write(np.ascontiguousarray(db, dtype="<f4").tobytes())
+        if format == "faiss":
+            f.write(FAISS_FOURCC_FLAT_IP)
+            f.write(struct.pack("<iqqq", index.d, db.shape[0], 1 << 20, 1 << 20))
+            f.write(struct.pack("<Bi", 1, METRIC_INNER_PRODUCT))
+            f.write(struct.pack("<Q", db.size))
+        elif format == "clipmi":
+            f.write(MAGIC + struct.pack("<IIQ", 1, index.d, db.shape[0]))
+        else:
+            raise ValueError(f"write_index: unknown format {format!r}")
+        f.write(db.tobytes())
 
 
 def read_index(path, device="cuda:0"):
-    """faiss.read_index stand-in (query-index.py:29)."""
+    """faiss.read_index stand-in (query-index.py:29); reads both formats write_index produces."""
     with open(path, "rb") as f:
-        head = f.read(24)
-        if head[:8] != MAGIC:
-            raise ValueError(f"{path}: not a clipmi index file")
-        ver, d, n = struct.unpack("<IIQ", head[8:])
-        if ver != 1:
-            raise ValueError(f"{path}: unsupported version {ver}")
+        head = f.read(8)
+        if head[:4] == FAISS_FOURCC_FLAT_IP:
+            f.seek(4)
+            d, n, _, _ = struct.unpack("<iqqq", f.read(28))
+            trained, metric = struct.unpack("<Bi", f.read(5))
+            if metric != METRIC_INNER_PRODUCT:
+                raise ValueError(f"{path}: faiss flat index with metric {metric}; only inner product is supported")
+            (count,) = struct.unpack("<Q", f.read(8))
+            if count != n * d:
+                raise ValueError(f"{path}: vector count {count} != ntotal*d {n * d}")
+        elif head == MAGIC:
+            ver, d, n = struct.unpack("<IIQ", f.read(16))
+            if ver != 1:
+                raise ValueError(f"{path}: unsupported version {ver}")
+        else:
+            raise ValueError(f"{path}: not a clipmi or faiss IndexFlatIP file (an IVF index must be rebuilt: "
+                             "re-run build-index.py)")
         data = np.fromfile(f, dtype="<f4", count=n * d)
     if data.size != n * d:
         raise ValueError(f"{path}: truncated ({data.size} of {n * d} floats)")

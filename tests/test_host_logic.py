@@ -38,6 +38,28 @@ def test_index_file_roundtrip(clipmi, tmp_path):
         clipmi.read_index(p, device="cpu")
 
 
+def test_faiss_flat_ip_file_layout(clipmi, tmp_path):
+    """next-3: byte layout of the faiss IndexFlatIP serialisation (restated from upstream, unpinned)."""
+    import struct
+    rng = np.random.default_rng(1)
+    x = unit_rows(rng, 7, 512)
+    idx = clipmi.IndexFlatIP(512, device="cpu")
+    idx.add(x)
+    p = str(tmp_path / "images.index")
+    clipmi.write_index(idx, p, format="faiss")
+    raw = open(p, "rb").read()
+    assert raw[:4] == b"IxFI" and len(raw) == 4 + 4 + 8 + 8 + 8 + 1 + 4 + 8 + 7 * 512 * 4
+    d, n, d1, d2 = struct.unpack("<iqqq", raw[4:32])
+    assert (d, n, d1, d2) == (512, 7, 1 << 20, 1 << 20)
+    assert struct.unpack("<Bi", raw[32:37]) == (1, 0) and struct.unpack("<Q", raw[37:45]) == (7 * 512,)
+    assert raw[45:] == x.astype("<f4").tobytes()
+    back = clipmi.read_index(p, device="cpu")
+    assert back.ntotal == 7 and np.array_equal(back.matrix().numpy(), x)
+    open(p, "wb").write(b"IwFl" + raw[4:])
+    with pytest.raises(ValueError, match="rebuilt"):
+        clipmi.read_index(p, device="cpu")
+
+
 def _worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
