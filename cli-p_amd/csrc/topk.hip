@@ -23,7 +23,6 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SAMPLE_MIN_N = 65536;     // below this the pre-pass is not worth its launches
-constexpr int MAX_QA = 16;              // queries per pass = one MFMA tile of columns
 constexpr int LDS_LIMIT = 160 * 1024 - 512;
 
 __device__ __forceinline__ bool beats(float sa, unsigned ia, float sb, unsigned ib) {
@@ -66,19 +65,23 @@ struct ScanArgs {
     const float* db;        // [nrows][E]
     long long nrows;        // >= 1
     const float* q;         // first query of this group, [QA][E]
-    int QA;                 // active queries in this pass, 1..16
+    int QA;                 // active queries in this pass, 1..16*QG
     int K;
-    int C;                  // candidate capacity per (wave, query): multiple of 64, >= K + 64
+    int C;                  // candidate capacity per (wave, query): multiple of 16, >= K + 16
     int wave_bytes;         // LDS bytes per wave
     const float* thr_in;    // [QA] initial thresholds (valid lower bounds) or nullptr
     uint2* cand;            // [QA][cap] dense candidate lists (unsorted), cap >= NL * C
-    unsigned* gcnt;         // [16] entries used per query; zeroed on the stream before the launch
+    unsigned* gcnt;         // [32] entries used per query; zeroed on the stream before the launch
     long long cap;
 };
 
 // PREPASS only changes the kernel's NAME (profilers average per name; the threshold pre-pass over
 // a few thousand rows must not dilute the main scan's average duration).
-template <int E, bool PREPASS>
+// QG = 16-query column groups per pass (1 or 2): every DB fragment feeds QG independent MFMA
+// accumulator chains. The pass stays HBM-bound up to QG = 2 (f32 MFMA: 2 x 128 instructions of 32
+// cycles per 32 KiB tile per SIMD = 16 B/clk/CU against ~10 B/clk/CU of HBM), and two chains hide
+// the 40-cycle dependent-accumulator latency of a single one.
+template <int E, bool PREPASS, int QG>
 __global__ void __launch_bounds__(256) scan_topk_f32_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = E / 16;      // float4 per lane per 16-row tile
@@ -88,30 +91,37 @@ __global__ void __launch_bounds__(256) scan_topk_f32_kernel(ScanArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwaves = blockDim.x >> 6;
-    const int col = lane & 15;      // query column of this lane (B operand / accumulator column)
+    const int col = lane & 15;      // query column of this lane inside a group (B operand / accumulator column)
     const int g = lane >> 4;        // MFMA k index supplied by this lane; accumulator row group
 
-    // query image, one 1-KiB lane-linear piece per t: entry [t*64 + lane] = q[col][16t+4g .. +3]
+    // query image, one 1-KiB lane-linear piece per (group, t): entry [(qg*NT + t)*64 + lane] =
+    // q[16*qg + col][16t+4g .. +3]
     f32x4* qimg = reinterpret_cast<f32x4*>(smem);
-    for (int idx = tid; idx < NT * 64; idx += blockDim.x) {
-        const int t = idx >> 6, l = idx & 63, c_ = l & 15, g_ = l >> 4;
+    for (int idx = tid; idx < QG * NT * 64; idx += blockDim.x) {
+        const int l = idx & 63, t = (idx >> 6) % NT, qg = (idx >> 6) / NT;
+        const int c_ = qg * 16 + (l & 15), g_ = l >> 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (c_ < a.QA) v = *reinterpret_cast<const f32x4*>(a.q + (size_t)c_ * E + 16 * t + 4 * g_);
         qimg[idx] = v;
     }
-    char* wbase = smem + NT * 1024 + (size_t)wave * a.wave_bytes;
+    char* wbase = smem + QG * NT * 1024 + (size_t)wave * a.wave_bytes;
     uint2* buf = reinterpret_cast<uint2*>(wbase);            // [QA][C]
     uint2* scratch = buf + (size_t)a.QA * a.C;                // [C]
-    int* cnt = reinterpret_cast<int*>(scratch + a.C);         // [16]
-    float* thr = reinterpret_cast<float*>(cnt + 16);          // [16]
-    if (lane < 16) {
+    int* cnt = reinterpret_cast<int*>(scratch + a.C);         // [32]
+    float* thr = reinterpret_cast<float*>(cnt + 32);          // [32]
+    if (lane < 32) {
         cnt[lane] = 0;
         thr[lane] = (lane < a.QA) ? (a.thr_in ? a.thr_in[lane] : -INFINITY) : INFINITY;
     }
     __syncthreads();
 
-    const bool active = col < a.QA;
-    float tau = thr[col];
+    bool active[QG];
+    float tau[QG];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        active[qg] = qg * 16 + col < a.QA;
+        tau[qg] = thr[qg * 16 + col];
+    }
     const int C = a.C, K = a.K;
 
     const long long ntiles = (a.nrows + 15) >> 4;
@@ -136,26 +146,35 @@ __global__ void __launch_bounds__(256) scan_topk_f32_kernel(ScanArgs a) {
             rn = rn > last_row ? last_row : rn;
             const float* pn = a.db + rn * E + 4 * g;
 
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc[QG];
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) acc[qg] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int t = 8 * c + j;
-                    const f32x4 bq = qimg[t * 64 + lane];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t].x, bq.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t].y, bq.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t].z, bq.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t].w, bq.w, acc, 0, 0, 0);
+                    f32x4 bq[QG];
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg) bq[qg] = qimg[(qg * NT + t) * 64 + lane];
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg) acc[qg] = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t].x, bq[qg].x, acc[qg], 0, 0, 0);
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg) acc[qg] = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t].y, bq[qg].y, acc[qg], 0, 0, 0);
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg) acc[qg] = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t].z, bq[qg].z, acc[qg], 0, 0, 0);
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg) acc[qg] = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t].w, bq[qg].w, acc[qg], 0, 0, 0);
                 }
                 // this chunk's registers are free: refill them with the next tile (stays in
                 // flight across the candidate step below and the first chunks of the next pass).
                 // The sched_barriers pin the refill HERE: left alone, hipcc sinks all refills
                 // behind the tile's last MFMA and the wave then waits out the full HBM latency.
-                // The empty asm consumes the chunk's last MFMA result and clobbers memory, so no
+                // The empty asm consumes the chunk's last MFMA results and clobbers memory, so no
                 // refill load can be hoisted above an MFMA that still reads the old registers
                 // (which would cost a register copy behind a vmcnt(0) at the loop head).
-                asm volatile("" : "+a"(acc) : : "memory");
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg) asm volatile("" : "+a"(acc[qg]) : : "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -165,28 +184,42 @@ __global__ void __launch_bounds__(256) scan_topk_f32_kernel(ScanArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
 
-            // accumulator: column = query `col`, rows = tile*16 + 4g + r
+            // accumulator qg: column = query 16*qg + col, rows = tile*16 + 4g + r
             const long long row0 = tile * 16 + 4 * g;
-            bool p0 = active && (row0 + 0 <= last_row) && (acc.x >= tau);
-            bool p1 = active && (row0 + 1 <= last_row) && (acc.y >= tau);
-            bool p2 = active && (row0 + 2 <= last_row) && (acc.z >= tau);
-            bool p3 = active && (row0 + 3 <= last_row) && (acc.w >= tau);
-            if (__ballot(p0 | p1 | p2 | p3)) {
-                uint2* qb = buf + (size_t)col * C;
-                if (p0) { int pos = atomicAdd(&cnt[col], 1); qb[pos] = make_uint2(__float_as_uint(acc.x), (unsigned)(row0 + 0)); }
-                if (p1) { int pos = atomicAdd(&cnt[col], 1); qb[pos] = make_uint2(__float_as_uint(acc.y), (unsigned)(row0 + 1)); }
-                if (p2) { int pos = atomicAdd(&cnt[col], 1); qb[pos] = make_uint2(__float_as_uint(acc.z), (unsigned)(row0 + 2)); }
-                if (p3) { int pos = atomicAdd(&cnt[col], 1); qb[pos] = make_uint2(__float_as_uint(acc.w), (unsigned)(row0 + 3)); }
+            bool any = false;
+            bool pp[QG][4];
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pp[qg][r] = active[qg] && (row0 + r <= last_row) && (acc[qg][r] >= tau[qg]);
+                    any |= pp[qg][r];
+                }
+            if (__ballot(any)) {
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg) {
+                    const int qi = qg * 16 + col;
+                    uint2* qb = buf + (size_t)qi * C;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (pp[qg][r]) {
+                            const int pos = atomicAdd(&cnt[qi], 1);
+                            qb[pos] = make_uint2(__float_as_uint(acc[qg][r]), (unsigned)(row0 + r));
+                        }
+                }
                 wave_lds_sync();
-                const bool need = active && (g == 0) && (cnt[col] > C - 16);
-                unsigned long long mask = __ballot(need);
-                if (mask) {
-                    while (mask) {
-                        const int qq = __builtin_ctzll(mask);
-                        mask &= mask - 1;
-                        wave_compact(buf + (size_t)qq * C, scratch, &cnt[qq], &thr[qq], K, lane);
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg) {
+                    const bool need = active[qg] && (g == 0) && (cnt[qg * 16 + col] > C - 16);
+                    unsigned long long mask = __ballot(need);
+                    if (mask) {
+                        while (mask) {
+                            const int qq = qg * 16 + __builtin_ctzll(mask);
+                            mask &= mask - 1;
+                            wave_compact(buf + (size_t)qq * C, scratch, &cnt[qq], &thr[qq], K, lane);
+                        }
+                        tau[qg] = thr[qg * 16 + col];
                     }
-                    tau = thr[col];
                 }
             }
             if (!has_next) break;
@@ -195,12 +228,12 @@ __global__ void __launch_bounds__(256) scan_topk_f32_kernel(ScanArgs a) {
     }
 
     // publish the block's surviving candidates (unsorted, possibly more than K per wave): ONE
-    // returning atomic per (block, query), issued by 16 lanes at once — per-wave serial atomics
+    // returning atomic per (block, query), issued by up to 32 lanes at once — per-wave serial atomics
     // here cost ~200 us of same-address contention at the end of a 1M-row scan
     __syncthreads();
     unsigned* gbase = reinterpret_cast<unsigned*>(smem);            // query image is dead now
     auto wave_cnt = [&](int w) {
-        return reinterpret_cast<int*>(smem + NT * 1024 + (size_t)w * a.wave_bytes + (size_t)(a.QA + 1) * a.C * 8);
+        return reinterpret_cast<int*>(smem + QG * NT * 1024 + (size_t)w * a.wave_bytes + (size_t)(a.QA + 1) * a.C * 8);
     };
     if (wave == 0 && lane < a.QA) {
         unsigned total = 0;
@@ -400,7 +433,7 @@ __global__ void __launch_bounds__(256) merge_lists_i64_kernel(const float* __res
 }
 
 struct Plan {
-    int C, waves, QA, grid, grid_sample;
+    int C, waves, QA, QG, grid, grid_sample, wave_bytes;
     size_t lds_scan, lds_sel;
     long long NL, NL_sample, cap, sample_rows;
     bool sample;
@@ -409,25 +442,29 @@ struct Plan {
 // Shared by workspace sizing and launch so both always agree.
 bool make_plan(long long N, int E, int Q, int K, Plan& p) {
     if (N < 0 || Q < 1 || K < 1 || (E != 512 && E != 768)) return false;
-    p.C = (int)align_up((size_t)K + 64, 64);
-    const int qimg = (E / 16) * 1024;
-    const int qwant = Q < MAX_QA ? Q : MAX_QA;
+    p.C = (int)align_up((size_t)K + 16, 16);
     p.waves = 0;
-    for (int w = 4; w >= 1; w >>= 1) {
-        const long long per_wave = (LDS_LIMIT - qimg) / w - 128;
-        const long long fit = per_wave / ((long long)p.C * 8) - 1;     // queries that fit beside scratch
-        if (fit >= 1) { p.waves = w; p.QA = (int)(fit < qwant ? fit : qwant); break; }
-    }
+    // prefer 4 waves per block and as many queries per pass as LDS allows (32, else 16, else fewer)
+    for (int w = 4; w >= 1 && p.waves == 0; w >>= 1)
+        for (int qg = (Q > 16 ? 2 : 1); qg >= 1; --qg) {
+            const int qimg = qg * (E / 16) * 1024;
+            const long long per_wave = (LDS_LIMIT - qimg) / w - 256;
+            const long long fit = per_wave / ((long long)p.C * 8) - 1;     // queries that fit beside scratch
+            const int qwant = Q < 16 * qg ? Q : 16 * qg;
+            if (fit >= qwant || (qg == 1 && fit >= 1)) {
+                p.waves = w; p.QG = qg; p.QA = (int)(fit < qwant ? fit : qwant);
+                break;
+            }
+        }
     if (p.waves == 0) return false;
     p.lds_sel = 32 * 8 + (256 + 8 + 8) * 4 + (size_t)K * 8;
     if (p.lds_sel > (size_t)LDS_LIMIT) return false;
-    const int wave_bytes = (p.QA + 1) * p.C * 8 + 128;
-    p.lds_scan = (size_t)qimg + (size_t)p.waves * wave_bytes;
+    const int qimg = p.QG * (E / 16) * 1024;
+    p.wave_bytes = (p.QA + 1) * p.C * 8 + 256;
+    p.lds_scan = (size_t)qimg + (size_t)p.waves * p.wave_bytes;
     const long long ntiles = (N + 15) / 16;
-    int per_cu = (int)(LDS_BYTES / p.lds_scan);
-    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
     long long grid = (ntiles + p.waves - 1) / p.waves;
-    if (grid > (long long)NUM_CU * per_cu) grid = (long long)NUM_CU * per_cu;
+    if (grid > NUM_CU) grid = NUM_CU;            // one block per CU: the ring keeps ~100 KB in flight per CU
     if (grid < 1) grid = 1;
     p.grid = (int)grid;
     p.NL = grid * p.waves;
@@ -451,16 +488,24 @@ int opt_in_lds(const void* fn, size_t bytes) {
     return 0;
 }
 
-template <int E, bool PREPASS>
-int launch_scan(const ScanArgs& a, int grid, int waves, size_t lds, hipStream_t st, hipEvent_t* ev = nullptr) {
-    const void* fn = (const void*)scan_topk_f32_kernel<E, PREPASS>;
+template <int E, bool PREPASS, int QG>
+int launch_scan_t(const ScanArgs& a, int grid, int waves, size_t lds, hipStream_t st, hipEvent_t* ev) {
+    const void* fn = (const void*)scan_topk_f32_kernel<E, PREPASS, QG>;
     if (int rc = opt_in_lds(fn, lds)) return rc;
     if (ev)   // measurement: the events take the dispatch's own begin/end timestamps
-        hipExtLaunchKernelGGL((scan_topk_f32_kernel<E, PREPASS>), dim3(grid), dim3(waves * 64), lds, st, ev[0], ev[1], 0, a);
+        hipExtLaunchKernelGGL((scan_topk_f32_kernel<E, PREPASS, QG>), dim3(grid), dim3(waves * 64), lds, st, ev[0], ev[1], 0, a);
     else
-        hipLaunchKernelGGL((scan_topk_f32_kernel<E, PREPASS>), dim3(grid), dim3(waves * 64), lds, st, a);
+        hipLaunchKernelGGL((scan_topk_f32_kernel<E, PREPASS, QG>), dim3(grid), dim3(waves * 64), lds, st, a);
     CLIPMI_CHECK_LAUNCH("scan_topk_f32_kernel");
     return 0;
+}
+
+template <bool PREPASS>
+int launch_scan(int E, int QG, const ScanArgs& a, int grid, int waves, size_t lds, hipStream_t st, hipEvent_t* ev = nullptr) {
+    if (E == 512) return QG == 2 ? launch_scan_t<512, PREPASS, 2>(a, grid, waves, lds, st, ev)
+                                 : launch_scan_t<512, PREPASS, 1>(a, grid, waves, lds, st, ev);
+    return QG == 2 ? launch_scan_t<768, PREPASS, 2>(a, grid, waves, lds, st, ev)
+                   : launch_scan_t<768, PREPASS, 1>(a, grid, waves, lds, st, ev);
 }
 
 }  // namespace
@@ -471,7 +516,7 @@ using namespace clipmi;
 extern "C" size_t clipmi_topk_ip_workspace_bytes(int64_t N, int E, int Q, int K) {
     Plan p;
     if (!make_plan(N, E, Q, K, p)) {
-        set_err(CLIPMI_EINVAL, "topk_ip: unsupported N=%lld E=%d Q=%d K=%d (E in {512,768}, 1 <= K <= ~7000)",
+        set_err(CLIPMI_EINVAL, "topk_ip: unsupported N=%lld E=%d Q=%d K=%d (E in {512,768}, 1 <= K <= ~8000)",
                 (long long)N, E, Q, K);
         return 0;
     }
@@ -500,8 +545,8 @@ static int topk_ip_impl(const void* db_dev, int db_dtype, int64_t N, int E, cons
     if (ws_bytes < need_ws) return set_err(CLIPMI_EWORKSPACE, "topk_ip: workspace %zu < %zu", ws_bytes, need_ws);
     Arena ar(ws_dev, ws_bytes);
     uint2* cand = ar.take<uint2>((size_t)p.QA * p.cap);
-    unsigned* gcnt = ar.take<unsigned>(16);
-    float* thr0 = ar.take<float>(16);
+    unsigned* gcnt = ar.take<unsigned>(32);
+    float* thr0 = ar.take<float>(32);
 
     if (int rc = opt_in_lds((const void*)select_topk_kernel, p.lds_sel)) return rc;
 
@@ -513,7 +558,7 @@ static int topk_ip_impl(const void* db_dev, int db_dtype, int64_t N, int E, cons
         a.QA = qa;
         a.K = K;
         a.C = p.C;
-        a.wave_bytes = (p.QA + 1) * p.C * 8 + 128;
+        a.wave_bytes = p.wave_bytes;
         a.cand = cand;
         a.gcnt = gcnt;
         a.cap = p.cap;
@@ -522,9 +567,8 @@ static int topk_ip_impl(const void* db_dev, int db_dtype, int64_t N, int E, cons
             // pre-pass: exact K-th best score of the first S rows = a valid lower bound for the
             // K-th best of all rows; the main pass then only buffers scores >= that bound
             a.nrows = p.sample_rows;
-            if (hipMemsetAsync(gcnt, 0, 64, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
-            int rc = E == 512 ? launch_scan<512, true>(a, p.grid_sample, p.waves, p.lds_scan, st)
-                              : launch_scan<768, true>(a, p.grid_sample, p.waves, p.lds_scan, st);
+            if (hipMemsetAsync(gcnt, 0, 128, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
+            int rc = launch_scan<true>(E, p.QG, a, p.grid_sample, p.waves, p.lds_scan, st);
             if (rc) return rc;
             hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, cand, gcnt, p.cap, K,
                                (long long)0, (float*)nullptr, (long long*)nullptr, thr0);
@@ -532,9 +576,8 @@ static int topk_ip_impl(const void* db_dev, int db_dtype, int64_t N, int E, cons
             a.thr_in = thr0;
         }
         a.nrows = N;
-        if (hipMemsetAsync(gcnt, 0, 64, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
-        int rc = E == 512 ? launch_scan<512, false>(a, p.grid, p.waves, p.lds_scan, st, scan_ev)
-                          : launch_scan<768, false>(a, p.grid, p.waves, p.lds_scan, st, scan_ev);
+        if (hipMemsetAsync(gcnt, 0, 128, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
+        int rc = launch_scan<false>(E, p.QG, a, p.grid, p.waves, p.lds_scan, st, scan_ev);
         if (rc) return rc;
         hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, cand, gcnt, p.cap, K,
                            (long long)id_base, out_score_dev + (size_t)q0 * K, (long long*)out_id_dev + (size_t)q0 * K,
@@ -553,11 +596,11 @@ extern "C" int clipmi_topk_ip(const void* db_dev, int db_dtype, int64_t N, int E
 
 // Measurement hook (bench.py roofline): the same call sequence as clipmi_topk_ip, `reps` times,
 // with HIP events recorded on `stream` around the MAIN scan kernel only; synchronises, and
-// returns the average scan-kernel duration in milliseconds through *scan_ms. Q <= 16.
+// returns the average scan-kernel duration in milliseconds through *scan_ms. Q <= 32 (one pass).
 extern "C" int clipmi_dbg_topk_scan_ms(const void* db_dev, int64_t N, int E, const float* q_dev, int Q, int K,
                                        float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes,
                                        void* stream, int reps, float* scan_ms) {
-    if (!scan_ms || reps < 1 || Q > 16) return set_err(CLIPMI_EINVAL, "dbg_topk_scan_ms: bad arguments");
+    if (!scan_ms || reps < 1 || Q > 32) return set_err(CLIPMI_EINVAL, "dbg_topk_scan_ms: bad arguments");
     hipEvent_t ev[2];
     if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess)
         return set_err(CLIPMI_EHIP, "hipEventCreate");
