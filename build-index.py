@@ -9,7 +9,7 @@ still finalises the index). What differs: images are encoded in batches by hand-
 ("images.index" in cli-p_amd's packed format) instead of a trained IVF file.
 
 Weights: $CLIPMI_WEIGHTS (a local ViT-B-32.pt / state-dict), or CLIPMI_RANDOM_WEIGHTS=<seed> for a
-synthetic model. Knobs: CLIPMI_BATCH (default 256), CLIPMI_WORKERS (decode threads, default 8).
+synthetic model. Knobs: CLIPMI_BATCH (default 435 = whole rounds of GEMM tiles on 256 CUs), CLIPMI_WORKERS (decode threads, default 8).
 """
 import os
 import sys
@@ -65,7 +65,7 @@ def main(argv):
     model.eval()
     db = vstore.VectorStore("vectors.lmdb", dim=model.embed_dim)
     try:
-        encode_directories(argv, model, db, int(os.environ.get("CLIPMI_BATCH", "256")),
+        encode_directories(argv, model, db, int(os.environ.get("CLIPMI_BATCH", "435")),
                            int(os.environ.get("CLIPMI_WORKERS", "8")))
     except KeyboardInterrupt:
         print("Interrupted!")

@@ -28,10 +28,18 @@ int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int 
     if (L < 1) return set_err(CLIPMI_EINVAL, "attention: L=%d", L);
     if (L > 80) {
         if (causal) return set_err(CLIPMI_EUNSUPPORTED, "attention: causal mask with L=%d > 80", L);
+        // waves per workgroup (each wave = 64 queries): 4 share a staged K/V block, unless that
+        // leaves the last workgroup mostly idle (L = 577: 10 query blocks = 5 groups of 2, not 3 of 4)
         const int qblocks = (L + 63) / 64;
-        const long long items = (long long)B * heads * qblocks;
-        hipLaunchKernelGGL(attention_flash_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 4 * 64 * 128, st, qkv, out,
-                           B, L, heads, qblocks);
+        const int g4 = (qblocks + 3) / 4, g2 = (qblocks + 1) / 2;
+        const bool use2 = g2 * 2 * 10 < g4 * 4 * 9;          // 2-wave groups waste >10 % fewer wave slots
+        const long long groups = (long long)B * heads * (use2 ? g2 : g4);
+        if (use2)
+            hipLaunchKernelGGL(attention_flash_kernel<2>, dim3((unsigned)groups), dim3(128), 2 * 16384, st, qkv, out, B, L,
+                               heads, g2);
+        else
+            hipLaunchKernelGGL(attention_flash_kernel<4>, dim3((unsigned)groups), dim3(256), 2 * 16384, st, qkv, out, B, L,
+                               heads, g4);
         CLIPMI_CHECK_LAUNCH("attention_flash_kernel");
         return 0;
     }

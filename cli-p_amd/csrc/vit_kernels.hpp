@@ -345,30 +345,35 @@ __global__ void __launch_bounds__(256) attention_kernel(const unsigned short* __
 
 // ---------------------------------------------------------------------------------------------
 // Flash-style attention for long sequences (L > 80: ViT-B/16 L = 197, ViT-L/14 L = 257,
-// ViT-L/14@336 L = 577), head dim 64, no mask. One wave = 64 queries of one (sequence, head);
-// keys/values stream through in blocks of 64 with an online softmax (running max / sum per query,
-// f32). Same operand orientation as attention_kernel: S^T = K Q^T puts the key on the accumulator
-// rows, so a block's P^T registers are the B operand of O^T += V^T P^T as they stand, and the
-// per-query rescale exp(m_old - m_new) multiplies whole accumulator tiles of this lane's column.
+// ViT-L/14@336 L = 577), head dim 64, no mask. A workgroup of WPB waves owns one (sequence, head) and
+// WPB consecutive 64-query blocks (one per wave); keys/values stream through in 64-key blocks that the
+// workgroup stages ONCE into double-buffered LDS by LDS-DMA (issued before the block's math, one
+// barrier per block), so K and V are read from L2 once per workgroup
+// instead of once per query block. Online softmax in f32 with exp2 (scale and log2 e folded into one
+// FMA). Same operand orientation as attention_kernel: S^T = K Q^T puts the key on the accumulator rows,
+// so a block's P^T registers are the B operand of O^T += V^T P^T as they stand, and the per-query
+// rescale 2^(m_old - m_new) multiplies whole accumulator tiles of this lane's column.
+// K tile rows are 128 B with 16-byte chunks XOR-swizzled by row & 7 (conflict-free ds_read_b128 fragments);
+// the V tile is row-major for ds_read_b64_tr_b16.
 // ---------------------------------------------------------------------------------------------
-static __global__ void __launch_bounds__(256) attention_flash_kernel(const unsigned short* __restrict__ qkv,
-                                                              unsigned short* __restrict__ out, int B, int L, int heads,
-                                                              int qblocks) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+template <int WPB>
+__global__ void __launch_bounds__(WPB * 64, 2) attention_flash_kernel(const unsigned short* __restrict__ qkv,
+                                                                    unsigned short* __restrict__ out, int B, int L,
+                                                                    int heads, int qgroups) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 x [K 8 KiB | V 8 KiB]
     constexpr int NT = 4;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     const int W = heads * 64;
-    const long long item = (long long)blockIdx.x * 4 + wave;                // (b, h, query block)
-    if (item >= (long long)B * heads * qblocks) return;                      // wave-uniform; no block barriers below
-    const int qb = (int)(item % qblocks);
-    const long long bh = item / qblocks;
-    const int b = (int)(bh / heads), h = (int)(bh - (long long)b * heads);
+    const int qgi = blockIdx.x % qgroups;
+    const int bh = blockIdx.x / qgroups;
+    const int b = bh / heads, h = bh - b * heads;
     const unsigned short* base = qkv + (size_t)b * L * 3 * W + h * 64;
     const size_t rs = (size_t)3 * W;
-    char* vt = smem + wave * (64 * 128);
-    const int q0 = qb * 64;
+    const int q0 = (qgi * WPB + wave) * 64;
+    const bool wave_active = q0 < L;                  // idle waves still stage tiles and hit barriers
 
     bf16x8 qf[NT][2];
 #pragma unroll
@@ -388,97 +393,112 @@ static __global__ void __launch_bounds__(256) attention_flash_kernel(const unsig
 #pragma unroll
     for (int qt = 0; qt < NT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.f; }
 
-    for (int k0 = 0; k0 < L; k0 += 64) {
-        // the previous block's transposed V reads are complete (their MFMAs consumed them): restage
+    // staging by LDS-DMA (no VGPRs): a K/V block is 16 pieces of 1 KiB (8 rows x 128 B); pieces 0..7 are
+    // K (16-byte chunks XOR-swizzled with row & 7 — applied on the SOURCE address, the DMA destination is
+    // lane-linear), pieces 8..15 are V (plain rows). Wave w issues pieces [w*PPW, (w+1)*PPW).
+    constexpr int PPW = 16 / WPB;
+    auto issue_tiles = [&](int k0, int buf) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = i * 8 + (lane >> 3);
+        for (int i = 0; i < PPW; ++i) {
+            const int pc = wave * PPW + i;
+            const int isv = pc >> 3;
+            const int row = (pc & 7) * 8 + (lane >> 3);
+            const int ch = lane & 7;
+            const int srcch = isv ? ch : (ch ^ (row & 7));
             const int srcrow = k0 + row < L ? k0 + row : L - 1;
-            const uint4 d = *reinterpret_cast<const uint4*>(base + (size_t)srcrow * rs + 2 * W + (lane & 7) * 8);
-            *reinterpret_cast<uint4*>(vt + row * 128 + (lane & 7) * 16) = d;
+            const unsigned short* src = base + (size_t)srcrow * rs + (1 + isv) * W + srcch * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + buf * 16384 + pc * 1024), 16, 0, 0);
         }
-        bf16x8 kf[NT][2];
+    };
+    issue_tiles(0, 0);
+
+    const float c = 0.125f * 1.4426950408889634f;     // 1/sqrt(64) * log2(e)
+    const int nb = (L + 63) >> 6;
+    for (int j = 0; j < nb; ++j) {
+        const int k0 = j << 6;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of block j have landed
+        __syncthreads();                                      // ... everyone's have; block j-1 is fully consumed
+        if (j + 1 < nb) issue_tiles(k0 + 64, (j + 1) & 1);   // in flight under this block's math
+        const char* kb = smem + (j & 1) * 16384;
+        const char* vt = kb + 8192;
+        if (wave_active) {
+            f32x4 s[NT][NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            int row = k0 + t * 16 + fr;
-            row = row < L ? row : L - 1;
-            const unsigned short* pr = base + (size_t)row * rs + W + fg * 8;
-            kf[t][0] = *reinterpret_cast<const bf16x8*>(pr);
-            kf[t][1] = *reinterpret_cast<const bf16x8*>(pr + 32);
-        }
-        f32x4 s[NT][NT];
+            for (int kt = 0; kt < NT; ++kt) {
+                const int row = kt * 16 + fr;
+                const bf16x8 k0f = *reinterpret_cast<const bf16x8*>(kb + row * 128 + (((0 + fg) ^ (row & 7)) << 4));
+                const bf16x8 k1f = *reinterpret_cast<const bf16x8*>(kb + row * 128 + (((4 + fg) ^ (row & 7)) << 4));
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
+                for (int qt = 0; qt < NT; ++qt) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0f, qf[qt][0], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1f, qf[qt][1], a, 0, 0, 0);
+                    s[kt][qt] = a;
+                }
+            }
+            const bool tail = k0 + 64 > L;            // only the last block can hold masked keys
 #pragma unroll
             for (int qt = 0; qt < NT; ++qt) {
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], qf[qt][0], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][1], qf[qt][1], a, 0, 0, 0);
-                s[kt][qt] = a;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = s[kt][qt][r];
+                        if (tail && k0 + kt * 16 + 4 * fg + r >= L) x = -INFINITY;
+                        s[kt][qt][r] = x;
+                        mx = fmaxf(mx, x);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                mx *= c;                                            // running max kept in the exp2 domain
+                const float m_new = fmaxf(m_run[qt], mx);           // finite: every block holds >= 1 valid key
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);   // 0 on the first block
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][r], c, -m_new));
+                        s[kt][qt][r] = e;
+                        sum += e;
+                    }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                l_run[qt] = l_run[qt] * alpha + sum;
+                m_run[qt] = m_new;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;
             }
 #pragma unroll
-        for (int qt = 0; qt < NT; ++qt) {
-            float mx = -INFINITY;
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 pf[NT];
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ki = k0 + kt * 16 + 4 * fg + r;
-                    float x = s[kt][qt][r] * 0.125f;
-                    if (ki >= L) x = -INFINITY;
-                    s[kt][qt][r] = x;
-                    mx = fmaxf(mx, x);
+                for (int qt = 0; qt < NT; ++qt) {
+                    const f32x4 lo = s[2 * ks][qt], hi = s[2 * ks + 1][qt];
+                    const uint4 u = make_uint4(pack_bf16x2(lo.x, lo.y), pack_bf16x2(lo.z, lo.w), pack_bf16x2(hi.x, hi.y),
+                                               pack_bf16x2(hi.z, hi.w));
+                    pf[qt] = __builtin_bit_cast(bf16x8, u);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[qt], mx);          // finite: every block holds >= 1 valid key
-            const float alpha = __expf(m_run[qt] - m_new);     // 0 on the first block (m_run = -inf)
-            float sum = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt)
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int kk = 32 * ks + 4 * fg + (fr >> 2);
+                    const char* ad = vt + kk * 128 + (dt * 16 + 4 * (fr & 3)) * 2;
+                    const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad));
+                    const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad + 16 * 128));
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    const s16x8 t = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                    const bf16x8 vf = __builtin_bit_cast(bf16x8, t);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __expf(s[kt][qt][r] - m_new);
-                    s[kt][qt][r] = e;
-                    sum += e;
+                    for (int qt = 0; qt < NT; ++qt)
+                        o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[dt][qt], 0, 0, 0);
                 }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
-            l_run[qt] = l_run[qt] * alpha + sum;
-            m_run[qt] = m_new;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's V block is in LDS
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 pf[NT];
-#pragma unroll
-            for (int qt = 0; qt < NT; ++qt) {
-                const f32x4 lo = s[2 * ks][qt], hi = s[2 * ks + 1][qt];
-                const uint4 u = make_uint4(pack_bf16x2(lo.x, lo.y), pack_bf16x2(lo.z, lo.w), pack_bf16x2(hi.x, hi.y),
-                                           pack_bf16x2(hi.z, hi.w));
-                pf[qt] = __builtin_bit_cast(bf16x8, u);
-            }
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const int kk = 32 * ks + 4 * fg + (fr >> 2);
-                const char* ad = vt + kk * 128 + (dt * 16 + 4 * (fr & 3)) * 2;
-                const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad));
-                const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad + 16 * 128));
-                typedef short s16x8 __attribute__((ext_vector_type(8)));
-                const s16x8 t = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, t);
-#pragma unroll
-                for (int qt = 0; qt < NT; ++qt)
-                    o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[dt][qt], 0, 0, 0);
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // V reads done before the next block overwrites the tile
-        __builtin_amdgcn_wave_barrier();
     }
 
+    if (!wave_active) return;
 #pragma unroll
     for (int qt = 0; qt < NT; ++qt) {
         const int qi = q0 + qt * 16 + fr;
