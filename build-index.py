@@ -1,78 +1,9 @@
 #!/usr/bin/env python3
-"""build-index.py DIR/ [DIR/ ...] — drop-in for the reference's indexer, on MI355X.
-
-Same command line, console output and on-disk schema as ps-auxw/CLI-P's build-index.py (keys are
-`DIR + filename` with no separator inserted, build-index.py:31 — pass directories with a trailing
-slash; .jpg/.jpeg/.png only; already-indexed and previously-failed files are skipped; Ctrl-C
-still finalises the index). What differs: images are encoded in batches by hand-written HIP kernels
-(cli-p_amd), the store commits once per batch, and the index is an exact flat inner-product matrix
-("images.index" in cli-p_amd's packed format) instead of a trained IVF file.
-
-Weights: $CLIPMI_WEIGHTS (a local ViT-B-32.pt / state-dict), or CLIPMI_RANDOM_WEIGHTS=<seed> for a
-synthetic model. Knobs: CLIPMI_BATCH (default 435 = whole rounds of GEMM tiles on 256 CUs), CLIPMI_WORKERS (decode threads, default 8).
-"""
-import os
+"""build-index.py DIR/ [DIR/ ...] — drop-in for the reference's indexer on MI355X (see cli-p_amd/indexer.py)."""
 import sys
 
 import clipmi
-from clipmi import pipeline, store as vstore
-
-EXTS = (".jpg", ".jpeg", ".png")
-
-
-def candidates(base_path, db):
-    """Files of one directory that still need encoding, as store keys (base_path + name)."""
-    todo = []
-    for name in os.listdir(base_path):
-        if os.path.splitext(name)[1].lower() not in EXTS:
-            continue
-        key = base_path + name
-        if db.is_skipped(key) or db.has_vector(key):
-            continue
-        todo.append(key)
-    return todo
-
-
-def encode_directories(dirs, model, db, batch, workers):
-    for base_path in dirs:
-        print(f"CLIPing {base_path}...")
-        todo = candidates(base_path, db)
-        for ok, feats, bad in pipeline.encode_files(model, todo, batch=batch, workers=workers):
-            if ok:
-                db.put_vectors(ok, feats)
-            db.mark_skipped(bad)
-            print("." * len(ok) + "#" * len(bad), end="", flush=True)
-        print(flush=True)
-
-
-def finalise(db, device, out="images.index"):
-    n = db.count()
-    if n == 0:
-        return
-    print(f"Preparing index for {n} entries...")
-    print(f"Generating {(n, db.dim)} matrix...")
-    matrix, _ = db.assemble()
-    index = clipmi.IndexFlatIP(db.dim, device=device)
-    print("Adding to index...")
-    index.add(matrix)
-    print("Saving index...")
-    clipmi.write_index(index, out)
-
-
-def main(argv):
-    device = "cuda:0"
-    model, _ = clipmi.load(os.environ.get("CLIPMI_WEIGHTS", "ViT-B/32"), device=device, jit=False)
-    model.eval()
-    db = vstore.VectorStore("vectors.lmdb", dim=model.embed_dim)
-    try:
-        encode_directories(argv, model, db, int(os.environ.get("CLIPMI_BATCH", "435")),
-                           int(os.environ.get("CLIPMI_WORKERS", "8")))
-    except KeyboardInterrupt:
-        print("Interrupted!")
-    finalise(db, device)
-    print("Done!")
-    db.close()
-
+from clipmi.indexer import candidates, encode_directories, finalise, main  # noqa: F401
 
 if __name__ == "__main__":
     main(sys.argv[1:])

@@ -1,0 +1,166 @@
+"""Interactive prompt behind `query-index.py` — the query side of the drop-in CLI.
+
+Same prompt and commands as the reference's query-index.py (q, h, i ID, r WxH, a, c NUM, p NUM, empty
+line = more results; result lines "score id path"; the best hit is dropped and K = k + offset + 1,
+query-index.py:111,115-116). Text is encoded by the HIP text tower and searched EXACTLY over the flat
+matrix; `p NUM` is accepted and has no effect. Images are shown only if OpenCV is installed.
+
+Weights as for the indexer; the BPE merge table comes from $CLIPMI_BPE_PATH.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import store as vstore, tokenizer
+from .index import read_index
+from .model import load
+
+HELP = ("Enter a search query and you will receive a list of best matching\nimages. The first number is the "
+        "difference score, the second the\nimage ID followed by the filename.\n\nPress q to stop viewing image "
+        "and space for the next image.\n\nJust press enter for more results.\n\nCommands:\nq\tQuit\n"
+        "i ID\tFind images similar to ID\nr [RES]\tSet maximum resolution (e.g. 1280x720)\n"
+        "a\tToggle align window position\nc NUM\tSet default number of results to NUM\n"
+        "p NUM\tSet number of subsets to probe (1-100, 32 default)\nh\tShow this help")
+
+
+def normalize(v):
+    n = np.linalg.norm(v)
+    return v if n < 0.000000001 else v / n
+
+
+class Viewer:
+    """Optional OpenCV window (query-index.py:120-151); a no-op without cv2."""
+
+    def __init__(self):
+        try:
+            import cv2
+            self.cv2 = cv2
+        except ImportError:
+            self.cv2 = None
+        self.max_res = None
+        self.align = False
+
+    def show(self, path):
+        """Returns False when the user pressed q (stop showing this result list)."""
+        cv2 = self.cv2
+        if cv2 is None:
+            return True
+        img = cv2.imread(path, cv2.IMREAD_COLOR)
+        if img is None or img.shape[0] < 2:
+            return True
+        h, w = img.shape[:2]
+        if self.max_res is not None:
+            scale = min(1.0, self.max_res[0] / w, self.max_res[1] / h)
+            if scale < 1.0:
+                img = cv2.resize(img, (int(w * scale + 0.5), int(h * scale + 0.5)), interpolation=cv2.INTER_LANCZOS4)
+        cv2.imshow("Image", img)
+        if self.align:
+            cv2.moveWindow("Image", 0, 0)
+        while True:
+            key = cv2.waitKey(0) & 0xFF
+            if key == ord(" "):
+                return True
+            if key == ord("q"):
+                return False
+
+    def close(self):
+        if self.cv2 is not None:
+            self.cv2.destroyAllWindows()
+
+
+def repl(model, index, db, inp=input, out=print):
+    k, offset, last_j = 50, 0, 0
+    features, have_text = None, False
+    viewer = Viewer()
+    while True:
+        line = inp("[h,q,i,r,a,c,p] >>> ").strip()
+        if line == "q":
+            break
+        if line == "h":
+            out(HELP)
+            continue
+        if line.startswith("p "):
+            probe = int(line[2:])
+            if 0 < probe < 101:
+                index.nprobe = probe
+                out(f"Set to probe {probe} subsets.")
+            else:
+                out("Invalid probe value.")
+            continue
+        if line == "a":
+            viewer.align = not viewer.align
+            out("Aligning window position." if viewer.align else "Not aligning window position.")
+            continue
+        if line.startswith("r "):
+            try:
+                x, y = (int(t) for t in line[2:].split("x"))
+                if x > 0 and y > 0:
+                    viewer.max_res = (x, y)
+                    out(f"Set maximum resolution to {x}x{y}.")
+                    continue
+            except ValueError:
+                pass
+            viewer.max_res = None
+            out("Unset maximum resolution.")
+            continue
+        if line.startswith("c "):
+            k = int(line[2:])
+            if k < 1:
+                k = 50
+                out("Reset number of results to 50.")
+            else:
+                out(f"Showing {k} results.")
+            continue
+        if line.startswith("i "):
+            offset = last_j = 0
+            path = db.idx_get(int(line[2:]))
+            vec = db.get_vector(path) if path is not None else None
+            if vec is None:
+                out("Not found.")
+                continue
+            features = vec
+            out(f"Similar to {path.decode()}:")
+        elif line == "":
+            offset = last_j
+            if not have_text:
+                continue
+        else:
+            offset = last_j = 0
+            try:
+                tokens = tokenizer.tokenize([line], context_length=model.context_length)
+            except (RuntimeError, FileNotFoundError) as e:
+                out(str(e))
+                continue
+            have_text = True
+            features = normalize(model.encode_text(tokens).cpu().numpy().astype("float32"))
+
+        t0 = time.perf_counter()
+        D, I = index.search(features, k + offset + 1)
+        out(f"Search time: {time.perf_counter() - t0:.4f}s")
+        for j, i in enumerate(I[0]):
+            if j <= offset or i < 0:
+                continue
+            path = db.idx_get(i).decode()
+            out(f"{D[0][j]:.4f} {i} {path}")
+            last_j = j
+            if not viewer.show(path):
+                break
+        viewer.close()
+
+
+def main():
+    device = "cuda:0"
+    model, _ = load(os.environ.get("CLIPMI_WEIGHTS", "ViT-B/32"), device=device, jit=False)
+    model.eval()
+    db = vstore.VectorStore("vectors.lmdb", dim=model.embed_dim)
+    index = read_index("images.index", device=device)
+    index.nprobe = 32
+    try:
+        repl(model, index, db)
+    except (EOFError, KeyboardInterrupt):
+        print("Interrupted.")
+    db.close()
+    sys.exit(0)
+
