@@ -17,6 +17,7 @@ SYMBOLS = [
     "clipmi_encode_image_workspace_bytes", "clipmi_encode_image",
     "clipmi_encode_text_workspace_bytes", "clipmi_encode_text",
     "clipmi_topk_ip_workspace_bytes", "clipmi_topk_ip",
+    "clipmi_topk_ip_coarse_workspace_bytes", "clipmi_topk_ip_coarse", "clipmi_dbg_topk_coarse_scan_ms",
     "clipmi_merge_topk_workspace_bytes", "clipmi_merge_topk", "clipmi_merge_topk_packed",
     "clipmi_l2_normalize_rows", "clipmi_last_error", "clipmi_abi_version",
     "clipmi_dbg_gemm_bf16", "clipmi_dbg_layernorm", "clipmi_dbg_attention", "clipmi_dbg_topk_scan_ms",
@@ -71,6 +72,13 @@ def lib():
     L.clipmi_topk_ip_workspace_bytes.argtypes = [i64, i32, i32, i32]
     L.clipmi_topk_ip.restype = i32
     L.clipmi_topk_ip.argtypes = [vp, i32, i64, i32, vp, i32, i32, i64, vp, vp, vp, sz, vp]
+    L.clipmi_topk_ip_coarse_workspace_bytes.restype = sz
+    L.clipmi_topk_ip_coarse_workspace_bytes.argtypes = [i64, i32, i32, i32]
+    L.clipmi_topk_ip_coarse.restype = i32
+    L.clipmi_topk_ip_coarse.argtypes = [vp, vp, i64, i32, C.c_float, vp, i32, i32, i64, vp, vp, vp, sz, vp]
+    L.clipmi_dbg_topk_coarse_scan_ms.restype = i32
+    L.clipmi_dbg_topk_coarse_scan_ms.argtypes = [vp, vp, i64, i32, C.c_float, vp, i32, i32, vp, vp, vp, sz, vp, i32,
+                                                 C.POINTER(C.c_float)]
     L.clipmi_merge_topk_workspace_bytes.restype = sz
     L.clipmi_merge_topk_workspace_bytes.argtypes = [i32, i32, i32]
     L.clipmi_merge_topk.restype = i32

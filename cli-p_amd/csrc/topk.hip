@@ -73,6 +73,7 @@ struct ScanArgs {
     uint2* cand;            // [QA][cap] dense candidate lists (unsorted), cap >= NL * C
     unsigned* gcnt;         // [32] entries used per query; zeroed on the stream before the launch
     long long cap;
+    const unsigned* run_if; // optional device flag: the kernel exits at once when *run_if == 0
 };
 
 // PREPASS only changes the kernel's NAME (profilers average per name; the threshold pre-pass over
@@ -86,6 +87,7 @@ __global__ void __launch_bounds__(256) scan_topk_f32_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = E / 16;      // float4 per lane per 16-row tile
     constexpr int NCH = NT / 8;     // chunks of 8 float4
+    if (a.run_if && *a.run_if == 0) return;       // fallback launch that is not needed (uniform)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -270,8 +272,10 @@ constexpr int SEL_THREADS = 512;
 __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* __restrict__ cand,
                                                                  const unsigned* __restrict__ gcnt, long long cap,
                                                                  int K, long long id_base, float* out_s,
-                                                                 long long* out_i, float* thr_out) {
+                                                                 long long* out_i, float* thr_out,
+                                                                 const unsigned* run_if) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (run_if && *run_if == 0) return;
     unsigned long long* red = reinterpret_cast<unsigned long long*>(smem);   // [16] min, [16] max
     unsigned* hist = reinterpret_cast<unsigned*>(red + 32);                  // [256]
     unsigned* wsum = hist + 256;                                             // [8]
@@ -432,6 +436,256 @@ __global__ void __launch_bounds__(256) merge_lists_i64_kernel(const float* __res
     }
 }
 
+// =================================================================================================
+// Coarse-then-exact path (SURVEY.md §7 option (b)): a bf16 copy of the matrix is scanned with bf16
+// MFMA (half the HBM bytes, 64 queries per pass) keeping a PROVABLE SUPERSET of the exact top-K; the
+// survivors are re-scored in exact f32 with the same fmaf order as the exact kernel and selected by the
+// same radix select, so results stay bit-exact against the oracle.
+//
+// Superset argument. Let s(r) be the exact (fmaf-chain) score of row r and c(r) the bf16-MFMA score of
+// the bf16-rounded operands. bf16 RNE has relative error u = 2^-9 per operand, so the exact products
+// differ by at most (2u + u^2)|a_k b_k|; both accumulations (f32, 512 terms, any order) add at most
+// ~2 * 512 * 2^-24 * sum|a_k b_k|. With sum|a_k b_k| <= ||row|| ||q||:
+//        |c(r) - s(r)| <= 0.004 * ||row|| * ||q||  <=  margin_q := 0.0041 * R_max * ||q||
+// (R_max = largest row norm, kept with the bf16 copy). tau0_q = exact K-th best of the first S rows is
+// a lower bound of the final K-th best score; every row of the true top-K has s >= tau0_q, hence
+// c >= tau0_q - margin_q =: the coarse threshold. If a candidate list overflows its capacity a device
+// flag makes the (otherwise early-exiting) exact-scan fallback launches run and overwrite the result.
+// =================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
+    f32x2v v = {a, b};
+    bf16x2v r = __builtin_convertvector(v, bf16x2v);
+    return __builtin_bit_cast(unsigned, r);
+}
+
+// tauc[q] = thr0[q] - 0.0041 * rmax * ||q||   (one wave per query)
+__global__ void __launch_bounds__(256) coarse_thresholds_kernel(const float* __restrict__ thr0, const float* __restrict__ q,
+                                                                int E, float rmax, int QA, float* tauc) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= QA) return;
+    float ss = 0.f;
+    for (int k = lane; k < E; k += 64) { const float v = q[(size_t)qi * E + k]; ss = fmaf(v, v, ss); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) {
+        const float margin = 0.0041f * rmax * sqrtf(ss) * 1.001f;
+        const float t = thr0[qi];
+        tauc[qi] = (t == -INFINITY || !(margin == margin)) ? -INFINITY : t - margin;
+    }
+}
+
+struct CoarseArgs {
+    const unsigned short* dbh;   // bf16 [nrows][E]
+    long long nrows;
+    const float* q;              // f32 [QA][E]
+    int QA;                      // 1..16*QG
+    const float* tauc;           // [QA]
+    uint2* cand;                 // [QA][cap]: .y = row id (.x filled by the re-scoring pass)
+    unsigned* gcnt;              // [64]
+    long long cap;
+    unsigned* overflow;          // set to 1 when a list would exceed cap
+};
+
+constexpr int COARSE_LIST = 1536;       // per-wave (query, row) list entries in LDS
+constexpr int COARSE_FLUSH = 512;       // flush when more than this many are pending (a step adds <= 1024)
+
+template <int E, int QG>
+__global__ void __launch_bounds__(256) scan_coarse_bf16_kernel(CoarseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = E / 32;          // bf16 MFMA k-steps per 16-row tile
+    constexpr int SLOTS = 2 * KS;       // one step = two row tiles (32 rows): SLOTS 16-byte fragments per lane
+    constexpr int NCH = SLOTS / 8;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int col = lane & 15, g = lane >> 4;
+
+    // bf16 query image: entry [(qg*KS + s)*64 + lane] = q[16qg + col][32s + 8g .. +7]
+    uint4* qimg = reinterpret_cast<uint4*>(smem);
+    for (int idx = tid; idx < QG * KS * 64; idx += blockDim.x) {
+        const int l = idx & 63, s_ = (idx >> 6) % KS, qg = (idx >> 6) / KS;
+        const int c_ = qg * 16 + (l & 15), g_ = l >> 4;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (c_ < a.QA) {
+            const float* p = a.q + (size_t)c_ * E + 32 * s_ + 8 * g_;
+            v = make_uint4(pack2_bf16(p[0], p[1]), pack2_bf16(p[2], p[3]), pack2_bf16(p[4], p[5]), pack2_bf16(p[6], p[7]));
+        }
+        qimg[idx] = v;
+    }
+    uint2* list = reinterpret_cast<uint2*>(smem + QG * KS * 1024 + (size_t)wave * (COARSE_LIST * 8 + 16));
+    int* lcnt = reinterpret_cast<int*>(list + COARSE_LIST);
+    if (lane == 0) *lcnt = 0;
+    __syncthreads();
+
+    bool active[QG];
+    float tau[QG];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        active[qg] = qg * 16 + col < a.QA;
+        tau[qg] = active[qg] ? a.tauc[qg * 16 + col] : INFINITY;
+    }
+    auto flush = [&]() {
+        wave_lds_sync();
+        const int n = *lcnt;
+        for (int e = lane; e < n; e += 64) {
+            const uint2 c = list[e];
+            const unsigned pos = atomicAdd(&a.gcnt[c.x], 1u);
+            if ((long long)pos < a.cap) a.cand[(size_t)c.x * a.cap + pos] = make_uint2(0u, c.y);
+            else *a.overflow = 1u;
+        }
+        wave_lds_sync();
+        if (lane == 0) *lcnt = 0;
+        wave_lds_sync();
+    };
+
+    const long long nsteps = (a.nrows + 31) >> 5;
+    const long long wg = (long long)blockIdx.x * nwaves + wave;
+    const long long tw = (long long)gridDim.x * nwaves;
+    const long long last_row = a.nrows - 1;
+
+    long long step = wg;
+    if (step < nsteps) {
+        uint4 T[SLOTS];
+        auto frag_ptr = [&](long long st, int rt) {
+            long long r = st * 32 + rt * 16 + col;
+            r = r > last_row ? last_row : r;
+            return a.dbh + r * E + 8 * g;
+        };
+        {
+            const unsigned short* p0 = frag_ptr(step, 0);
+            const unsigned short* p1 = frag_ptr(step, 1);
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {
+                T[s_] = *reinterpret_cast<const uint4*>(p0 + 32 * s_);
+                T[KS + s_] = *reinterpret_cast<const uint4*>(p1 + 32 * s_);
+            }
+        }
+        while (true) {
+            const long long nxt = step + tw;
+            const bool has_next = nxt < nsteps;
+            const unsigned short* pn[2] = {frag_ptr(has_next ? nxt : step, 0), frag_ptr(has_next ? nxt : step, 1)};
+
+            f32x4 acc[2][QG];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg) acc[rt][qg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int slot = 8 * c + j;
+                    const int rt = slot / KS, s_ = slot % KS;
+                    const bf16x8 af = __builtin_bit_cast(bf16x8, T[slot]);
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg) {
+                        const bf16x8 bq = __builtin_bit_cast(bf16x8, qimg[(qg * KS + s_) * 64 + lane]);
+                        acc[rt][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bq, acc[rt][qg], 0, 0, 0);
+                    }
+                }
+                // keep the refill of this chunk's registers behind its last MFMA (see scan_topk_f32_kernel)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg) asm volatile("" : "+v"(acc[rt][qg]) : : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int slot = 8 * c + j;
+                    T[slot] = *reinterpret_cast<const uint4*>(pn[slot / KS] + 32 * (slot % KS));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+
+            bool any = false;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        any |= active[qg] && (step * 32 + rt * 16 + 4 * g + r <= last_row) && (acc[rt][qg][r] >= tau[qg]);
+            if (__ballot(any)) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const long long row = step * 32 + rt * 16 + 4 * g + r;
+                            if (active[qg] && row <= last_row && acc[rt][qg][r] >= tau[qg]) {
+                                const int pos = atomicAdd(lcnt, 1);
+                                list[pos] = make_uint2((unsigned)(qg * 16 + col), (unsigned)row);
+                            }
+                        }
+                wave_lds_sync();
+                if (*lcnt > COARSE_FLUSH) flush();
+            }
+            if (!has_next) break;
+            step = nxt;
+        }
+    }
+    flush();
+}
+
+// Exact f32 re-scoring of the coarse survivors. Each lane owns one (query, candidate) pair and runs the
+// SAME fmaf chain as the MFMA scan (t, c, g order), so the score bits equal the exact kernel's and the
+// oracle's. The rows are fetched COOPERATIVELY: a wave takes 64 candidates and walks their rows in
+// 256-byte chunks, 4 rows x 256 B contiguous per wave-instruction (16 in flight per chunk), through a
+// padded per-wave LDS tile from which every lane then reads its own row's chunk (a first version with
+// one thread fetching its own 2-KB row took ~1 ms for 175 k pairs: 4 uncoalesced loads in flight).
+template <int E>
+__global__ void __launch_bounds__(256) rescore_pairs_kernel(const float* __restrict__ db, const float* __restrict__ q,
+                                                            uint2* cand, const unsigned* __restrict__ gcnt, long long cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RS = 68;                                  // floats per staged row chunk (64 + 4 pad: conflict-free b128 reads)
+    float* qs = reinterpret_cast<float*>(smem);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* st = qs + E + wave * 64 * RS;
+    const int qi = blockIdx.y;
+    for (int k = threadIdx.x; k < E; k += 256) qs[k] = q[(size_t)qi * E + k];
+    __syncthreads();
+    long long M = gcnt[qi];
+    if (M > cap) M = cap;
+    uint2* lst = cand + (size_t)qi * cap;
+    for (long long base = ((long long)blockIdx.x * 4 + wave) * 64; base < M; base += (long long)gridDim.x * 4 * 64) {
+        const long long my = base + lane;
+        const unsigned id_my = lst[my < M ? my : M - 1].y;
+        float acc = 0.f;
+        for (int chunk = 0; chunk < E / 64; ++chunk) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = 4 * i + (lane >> 4);
+                const unsigned rid = __shfl(id_my, r);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(db + (size_t)rid * E + chunk * 64 + (lane & 15) * 4);
+                *reinterpret_cast<f32x4*>(st + r * RS + (lane & 15) * 4) = v;
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                f32x4 v[4];
+#pragma unroll
+                for (int g_ = 0; g_ < 4; ++g_) v[g_] = *reinterpret_cast<const f32x4*>(st + lane * RS + 16 * tt + 4 * g_);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g_ = 0; g_ < 4; ++g_)
+                        acc = __builtin_fmaf(v[g_][c], qs[64 * chunk + 16 * tt + 4 * g_ + c], acc);
+            }
+            wave_lds_sync();
+        }
+        if (my < M) lst[my].x = __float_as_uint(acc == acc ? acc : -INFINITY);      // NaN never ranks
+    }
+}
+
 struct Plan {
     int C, waves, QA, QG, grid, grid_sample, wave_bytes;
     size_t lds_scan, lds_sel;
@@ -564,6 +818,7 @@ static int topk_ip_impl(const void* db_dev, int db_dtype, int64_t N, int E, cons
         a.gcnt = gcnt;
         a.cap = p.cap;
         a.thr_in = nullptr;
+        a.run_if = nullptr;
         if (p.sample) {
             // pre-pass: exact K-th best score of the first S rows = a valid lower bound for the
             // K-th best of all rows; the main pass then only buffers scores >= that bound
@@ -572,7 +827,7 @@ static int topk_ip_impl(const void* db_dev, int db_dtype, int64_t N, int E, cons
             int rc = launch_scan<true>(E, p.QG, a, p.grid_sample, p.waves, p.lds_scan, st);
             if (rc) return rc;
             hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, cand, gcnt, p.cap, K,
-                               (long long)0, (float*)nullptr, (long long*)nullptr, thr0);
+                               (long long)0, (float*)nullptr, (long long*)nullptr, thr0, (const unsigned*)nullptr);
             CLIPMI_CHECK_LAUNCH("select_topk_kernel(sample)");
             a.thr_in = thr0;
         }
@@ -582,7 +837,7 @@ static int topk_ip_impl(const void* db_dev, int db_dtype, int64_t N, int E, cons
         if (rc) return rc;
         hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, cand, gcnt, p.cap, K,
                            (long long)id_base, out_score_dev + (size_t)q0 * K, (long long*)out_id_dev + (size_t)q0 * K,
-                           (float*)nullptr);
+                           (float*)nullptr, (const unsigned*)nullptr);
         CLIPMI_CHECK_LAUNCH("select_topk_kernel");
     }
     return 0;
@@ -593,6 +848,166 @@ extern "C" int clipmi_topk_ip(const void* db_dev, int db_dtype, int64_t N, int E
                               size_t ws_bytes, void* stream) {
     return topk_ip_impl(db_dev, db_dtype, N, E, q_dev, Q, K, id_base, out_score_dev, out_id_dev, ws_dev, ws_bytes,
                         stream, nullptr);
+}
+
+namespace clipmi {
+namespace {
+constexpr long long COARSE_CAP = 1ll << 18;      // candidate slots per query of the coarse pass
+constexpr int COARSE_Q = 64;                     // queries per coarse pass
+
+template <int QG>
+int launch_coarse(const CoarseArgs& a, int grid, hipStream_t st, hipEvent_t* ev) {
+    const size_t lds = (size_t)QG * (512 / 32) * 1024 + 4 * (COARSE_LIST * 8 + 16);
+    if (int rc = opt_in_lds((const void*)scan_coarse_bf16_kernel<512, QG>, lds)) return rc;
+    if (ev) (void)hipEventRecord(ev[0], st);
+    hipLaunchKernelGGL((scan_coarse_bf16_kernel<512, QG>), dim3(grid), dim3(256), lds, st, a);
+    if (ev) (void)hipEventRecord(ev[1], st);
+    CLIPMI_CHECK_LAUNCH("scan_coarse_bf16_kernel");
+    return 0;
+}
+
+struct CoarseWs {
+    uint2* cand_e; uint2* cand_c; unsigned* gcnt_e; unsigned* gcnt_c; float* thr0; float* tauc; unsigned* flag;
+};
+
+size_t carve_coarse(const Plan& p, void* base, size_t cap, CoarseWs* w) {
+    Arena ar(base ? base : reinterpret_cast<void*>(256), cap);
+    CoarseWs x;
+    x.cand_e = ar.take<uint2>((size_t)p.QA * p.cap);
+    x.cand_c = ar.take<uint2>((size_t)COARSE_Q * COARSE_CAP);
+    x.gcnt_e = ar.take<unsigned>(32);
+    x.gcnt_c = ar.take<unsigned>(64);
+    x.thr0 = ar.take<float>(64);
+    x.tauc = ar.take<float>(64);
+    x.flag = ar.take<unsigned>(4);
+    if (w) *w = x;
+    return ar.off + 256;
+}
+
+int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, int64_t N, int E, float rmax, const float* q_dev, int Q,
+                        int K, int64_t id_base, float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes,
+                        void* stream, hipEvent_t* scan_ev) {
+    if (!db_dev || !dbh_dev || !q_dev || !out_score_dev || !out_id_dev || !ws_dev)
+        return set_err(CLIPMI_EINVAL, "topk_ip_coarse: NULL pointer");
+    if (E != 512 || N < SAMPLE_MIN_N) return set_err(CLIPMI_EUNSUPPORTED, "topk_ip_coarse: needs E = 512 and N >= %d", SAMPLE_MIN_N);
+    if (!(rmax > 0.f) || N >= (1ll << 32) - 1) return set_err(CLIPMI_EINVAL, "topk_ip_coarse: rmax=%g N=%lld", rmax, (long long)N);
+    Plan p;
+    if (!make_plan(N, E, Q > 32 ? 32 : Q, K, p)) return set_err(CLIPMI_EINVAL, "topk_ip_coarse: unsupported Q=%d K=%d", Q, K);
+    if (ws_bytes < carve_coarse(p, nullptr, ~(size_t)0, nullptr))
+        return set_err(CLIPMI_EWORKSPACE, "topk_ip_coarse: workspace %zu too small", ws_bytes);
+    CoarseWs w;
+    carve_coarse(p, ws_dev, ws_bytes, &w);
+    hipStream_t st = as_stream(stream);
+    if (int rc = opt_in_lds((const void*)select_topk_kernel, p.lds_sel)) return rc;
+    if (int rc = opt_in_lds((const void*)rescore_pairs_kernel<512>, 512 * 4 + 4 * 64 * 68 * 4)) return rc;
+
+    for (int q0 = 0; q0 < Q; q0 += COARSE_Q) {
+        const int qa = (Q - q0) < COARSE_Q ? (Q - q0) : COARSE_Q;
+        const float* qg = q_dev + (size_t)q0 * E;
+        ScanArgs a;
+        a.db = static_cast<const float*>(db_dev);
+        a.K = K; a.C = p.C; a.wave_bytes = p.wave_bytes;
+        a.cand = w.cand_e; a.gcnt = w.gcnt_e; a.cap = p.cap;
+        // 1. exact two-level pre-pass: thr0[q] = exact K-th best score of the first S2 rows (S2 ~ N*K/2048,
+        //    so that only ~2-3 k rows per query survive the coarse pass; every survivor costs a 2-KB row
+        //    read in the re-scoring pass). Level 1 (S1 rows, no threshold) only feeds level 2's filter.
+        long long S2 = 32768;
+        while (S2 < N / 8 && S2 * 2048 < N * (long long)K) S2 *= 2;
+        if (S2 < p.sample_rows) S2 = p.sample_rows;
+        long long g2 = ((S2 + 15) / 16 + p.waves - 1) / p.waves;
+        if (g2 > NUM_CU) g2 = NUM_CU;
+        for (int sub = 0; sub < qa; sub += p.QA) {
+            const int qs = (qa - sub) < p.QA ? (qa - sub) : p.QA;
+            a.q = qg + (size_t)sub * E; a.QA = qs; a.run_if = nullptr;
+            a.nrows = p.sample_rows; a.thr_in = nullptr;
+            if (hipMemsetAsync(w.gcnt_e, 0, 128, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
+            if (int rc = launch_scan<true>(E, p.QG, a, p.grid_sample, p.waves, p.lds_scan, st)) return rc;
+            hipLaunchKernelGGL(select_topk_kernel, dim3(qs), dim3(SEL_THREADS), p.lds_sel, st, w.cand_e, w.gcnt_e, p.cap, K,
+                               (long long)0, (float*)nullptr, (long long*)nullptr, w.tauc + sub, (const unsigned*)nullptr);
+            CLIPMI_CHECK_LAUNCH("select_topk_kernel(sample 1)");
+            a.nrows = S2; a.thr_in = w.tauc + sub;
+            if (hipMemsetAsync(w.gcnt_e, 0, 128, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
+            if (int rc = launch_scan<true>(E, p.QG, a, (int)g2, p.waves, p.lds_scan, st)) return rc;
+            hipLaunchKernelGGL(select_topk_kernel, dim3(qs), dim3(SEL_THREADS), p.lds_sel, st, w.cand_e, w.gcnt_e, p.cap, K,
+                               (long long)0, (float*)nullptr, (long long*)nullptr, w.thr0 + sub, (const unsigned*)nullptr);
+            CLIPMI_CHECK_LAUNCH("select_topk_kernel(sample 2)");
+        }
+        // 2. coarse thresholds, 3. bf16 scan of all rows, 4. exact re-scoring, 5. select
+        hipLaunchKernelGGL(coarse_thresholds_kernel, dim3((qa + 3) / 4), dim3(256), 0, st, w.thr0, qg, E, rmax, qa, w.tauc);
+        CLIPMI_CHECK_LAUNCH("coarse_thresholds_kernel");
+        if (hipMemsetAsync(w.gcnt_c, 0, 256, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
+        if (hipMemsetAsync(w.flag, 0, 16, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
+        CoarseArgs c;
+        c.dbh = static_cast<const unsigned short*>(dbh_dev); c.nrows = N; c.q = qg; c.QA = qa; c.tauc = w.tauc;
+        c.cand = w.cand_c; c.gcnt = w.gcnt_c; c.cap = COARSE_CAP; c.overflow = w.flag;
+        const long long nsteps = (N + 31) / 32;
+        const int grid = (int)((nsteps + 3) / 4 < NUM_CU ? (nsteps + 3) / 4 : NUM_CU);
+        int rc = qa <= 16 ? launch_coarse<1>(c, grid, st, scan_ev) : qa <= 32 ? launch_coarse<2>(c, grid, st, scan_ev)
+                                                                              : launch_coarse<4>(c, grid, st, scan_ev);
+        if (rc) return rc;
+        hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(32, qa), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
+                           static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, COARSE_CAP);
+        CLIPMI_CHECK_LAUNCH("rescore_pairs_kernel");
+        hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, w.cand_c, w.gcnt_c, COARSE_CAP, K,
+                           (long long)id_base, out_score_dev + (size_t)q0 * K, (long long*)out_id_dev + (size_t)q0 * K,
+                           (float*)nullptr, (const unsigned*)nullptr);
+        CLIPMI_CHECK_LAUNCH("select_topk_kernel(coarse)");
+        // 6. fallback: exact scan + select, exiting at once unless a coarse list overflowed
+        for (int sub = 0; sub < qa; sub += p.QA) {
+            const int qs = (qa - sub) < p.QA ? (qa - sub) : p.QA;
+            a.q = qg + (size_t)sub * E; a.QA = qs; a.nrows = N; a.thr_in = w.thr0 + sub; a.run_if = w.flag;
+            if (hipMemsetAsync(w.gcnt_e, 0, 128, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
+            if (int rc2 = launch_scan<false>(E, p.QG, a, p.grid, p.waves, p.lds_scan, st)) return rc2;
+            hipLaunchKernelGGL(select_topk_kernel, dim3(qs), dim3(SEL_THREADS), p.lds_sel, st, w.cand_e, w.gcnt_e, p.cap, K,
+                               (long long)id_base, out_score_dev + (size_t)(q0 + sub) * K,
+                               (long long*)out_id_dev + (size_t)(q0 + sub) * K, (float*)nullptr, (const unsigned*)w.flag);
+            CLIPMI_CHECK_LAUNCH("select_topk_kernel(fallback)");
+        }
+    }
+    return 0;
+}
+}  // namespace
+}  // namespace clipmi
+
+extern "C" size_t clipmi_topk_ip_coarse_workspace_bytes(int64_t N, int E, int Q, int K) {
+    Plan p;
+    if (E != 512 || N < SAMPLE_MIN_N || !make_plan(N, E, Q > 32 ? 32 : Q, K, p)) {
+        set_err(CLIPMI_EUNSUPPORTED, "topk_ip_coarse: needs E = 512, N >= %d and a supported K", SAMPLE_MIN_N);
+        return 0;
+    }
+    return carve_coarse(p, nullptr, ~(size_t)0, nullptr);
+}
+
+extern "C" int clipmi_topk_ip_coarse(const void* db_dev, const void* db_bf16_dev, int64_t N, int E, float rmax,
+                                     const float* q_dev, int Q, int K, int64_t id_base, float* out_score_dev,
+                                     int64_t* out_id_dev, void* ws_dev, size_t ws_bytes, void* stream) {
+    return topk_ip_coarse_impl(db_dev, db_bf16_dev, N, E, rmax, q_dev, Q, K, id_base, out_score_dev, out_id_dev, ws_dev,
+                               ws_bytes, stream, nullptr);
+}
+
+// Measurement hook: clipmi_topk_ip_coarse `reps` times with events around the bf16 scan kernel (Q <= 64).
+extern "C" int clipmi_dbg_topk_coarse_scan_ms(const void* db_dev, const void* db_bf16_dev, int64_t N, int E, float rmax,
+                                              const float* q_dev, int Q, int K, float* out_score_dev, int64_t* out_id_dev,
+                                              void* ws_dev, size_t ws_bytes, void* stream, int reps, float* scan_ms) {
+    if (!scan_ms || reps < 1 || Q > COARSE_Q) return set_err(CLIPMI_EINVAL, "dbg_topk_coarse_scan_ms: bad arguments");
+    hipEvent_t ev[2];
+    if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess)
+        return set_err(CLIPMI_EHIP, "hipEventCreate");
+    double total = 0.0;
+    int rc = 0;
+    for (int i = 0; i < reps && rc == 0; ++i) {
+        rc = topk_ip_coarse_impl(db_dev, db_bf16_dev, N, E, rmax, q_dev, Q, K, 0, out_score_dev, out_id_dev, ws_dev, ws_bytes,
+                                 stream, ev);
+        if (rc) break;
+        if (hipEventSynchronize(ev[1]) != hipSuccess) { rc = set_err(CLIPMI_EHIP, "hipEventSynchronize"); break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+        total += ms;
+    }
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    if (rc == 0) *scan_ms = (float)(total / reps);
+    return rc;
 }
 
 // Measurement hook (bench.py roofline): the same call sequence as clipmi_topk_ip, `reps` times,

@@ -54,7 +54,15 @@ def merge_lists_host(scores, ids, K):
 class IndexFlatIP:
     """Exact inner-product index over f32 vectors resident in HBM."""
 
-    def __init__(self, d, device="cuda:0"):
+    def __init__(self, d, device="cuda:0", coarse=None):
+        """coarse="bf16": keep a bf16 copy of the matrix beside the f32 one (+50 % HBM) and search through
+        clipmi_topk_ip_coarse — a bf16-MFMA scan that keeps a provable superset, then exact f32
+        re-scoring: same bit-exact results, half the bytes per pass, 64 queries per pass."""
+        if coarse not in (None, "bf16"):
+            raise ValueError("IndexFlatIP: coarse must be None or 'bf16'")
+        self.coarse = coarse
+        self._dbh = None
+        self._rmax = None
         if d not in (512, 768):
             raise ValueError("IndexFlatIP: d must be 512 (ViT-B/32) or 768 (ViT-L/14)")
         self.d = int(d)
@@ -80,6 +88,7 @@ class IndexFlatIP:
         t = t.to(device=self.device, dtype=torch.float32).contiguous()
         self._chunks.append(t)
         self._db = None
+        self._dbh = None
 
     @property
     def ntotal(self):
@@ -97,6 +106,23 @@ class IndexFlatIP:
                 self._chunks = [self._db]
         return self._db
 
+    def matrix_bf16(self):
+        """(bf16 copy [N][d], upper bound of the largest row norm) for the coarse path; built once."""
+        if self._dbh is None:
+            db = self.matrix()
+            dbh = torch.empty(db.shape, dtype=torch.bfloat16, device=db.device)
+            rmax = 0.0
+            step = 1 << 20
+            for lo in range(0, db.shape[0], step):
+                blk = db[lo:lo + step]
+                dbh[lo:lo + step] = blk.to(torch.bfloat16)
+                rmax = max(rmax, float(torch.linalg.vector_norm(blk, dim=1).max()))
+            self._dbh, self._rmax = dbh, rmax * (1.0 + 1e-6)
+        return self._dbh, self._rmax
+
+    def _use_coarse(self):
+        return self.coarse == "bf16" and self.d == 512 and self.ntotal >= 65536
+
     # -- query side ---------------------------------------------------------------------------
     def search_device(self, q, K, out=None):
         """q: f32 [Q,d] device tensor -> (scores f32 [Q,K], ids i64 [Q,K]) device tensors. Async.
@@ -108,7 +134,11 @@ class IndexFlatIP:
         q = q.to(device=self.device, dtype=torch.float32).contiguous()
         Q = q.shape[0]
         N = db.shape[0]
-        need = L.clipmi_topk_ip_workspace_bytes(N, self.d, Q, K)
+        coarse = self._use_coarse()
+        if coarse:
+            dbh, rmax = self.matrix_bf16()
+            coarse = rmax > 0.0 and np.isfinite(rmax)
+        need = (L.clipmi_topk_ip_coarse_workspace_bytes if coarse else L.clipmi_topk_ip_workspace_bytes)(N, self.d, Q, K)
         if need == 0:
             raise _lib.ClipmiError("topk_ip: " + _lib.last_error())
         if self._ws is None or self._ws.numel() < need:
@@ -118,6 +148,12 @@ class IndexFlatIP:
             out_i = torch.empty((Q, K), dtype=torch.int64, device=self.device)
         else:
             out_s, out_i = out
+        if coarse:
+            rc = L.clipmi_topk_ip_coarse(db.data_ptr(), dbh.data_ptr(), N, self.d, rmax, q.data_ptr(), Q, K, self.id_base,
+                                         out_s.data_ptr(), out_i.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                         _lib.stream_ptr(self.device))
+            _lib.check(rc, "clipmi_topk_ip_coarse")
+            return out_s, out_i
         rc = L.clipmi_topk_ip(db.data_ptr(), _lib.F32, N, self.d, q.data_ptr(), Q, K, self.id_base,
                               out_s.data_ptr(), out_i.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
                               _lib.stream_ptr(self.device))

@@ -135,6 +135,17 @@ int clipmi_topk_ip(const void* db_dev, int db_dtype, int64_t N, int E,
                    float* out_score_dev, int64_t* out_id_dev,
                    void* ws_dev, size_t ws_bytes, void* stream);
 
+/* ---- a12, coarse-then-exact variant: the same exact result (bit-exact scores, same ordering rule) from a
+ * bf16 coarse scan of `db_bf16_dev` (the matrix rounded to bf16, [N][E]) that keeps a provable superset,
+ * followed by exact f32 re-scoring of the survivors from `db_dev` (DESIGN.md "coarse path"). Half the HBM
+ * bytes per pass and 64 queries per pass. `rmax` = an upper bound of the largest row L2 norm of db_dev.
+ * E = 512, N >= 65536; if a candidate list overflows, the exact scan runs as a device-side fallback. */
+size_t clipmi_topk_ip_coarse_workspace_bytes(int64_t N, int E, int Q, int K);
+int clipmi_topk_ip_coarse(const void* db_dev, const void* db_bf16_dev, int64_t N, int E, float rmax,
+                          const float* q_dev, int Q, int K, int64_t id_base,
+                          float* out_score_dev, int64_t* out_id_dev,
+                          void* ws_dev, size_t ws_bytes, void* stream);
+
 /* ---- multi-GPU merge of per-shard partial results (no reference counterpart: the reference
  * is single-process). Inputs are R lists per query as gathered by one
  * all-gather: scores f32 [R][Q][K], ids int64 [R][Q][K] (id -1 = empty slot). Same ordering
@@ -179,6 +190,11 @@ int clipmi_dbg_attention(const void* qkv_dev, void* out_dev, int B, int L, int h
 int clipmi_dbg_topk_scan_ms(const void* db_dev, int64_t N, int E, const float* q_dev, int Q, int K,
                             float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes,
                             void* stream, int reps, float* scan_ms);
+
+/* clipmi_topk_ip_coarse `reps` times with HIP events around the bf16 scan kernel (Q <= 64) */
+int clipmi_dbg_topk_coarse_scan_ms(const void* db_dev, const void* db_bf16_dev, int64_t N, int E, float rmax,
+                                   const float* q_dev, int Q, int K, float* out_score_dev, int64_t* out_id_dev,
+                                   void* ws_dev, size_t ws_bytes, void* stream, int reps, float* scan_ms);
 
 /* clipmi_encode_image `reps` times with HIP events around every launch of the GEMM whose
  * epilogue is `probe_epi` (1 = MLP c_fc + QuickGELU), on `stream`; synchronises;

@@ -151,3 +151,52 @@ def test_topk_errors(clipmi, gpu):
     idx.add(np.zeros((4, 512), np.float32))
     with pytest.raises(clipmi.ClipmiError):
         idx.search(np.zeros((1, 512), np.float32), 100000)
+
+
+def _run_coarse(clipmi, gpu, db, q, K, id_base=0):
+    idx = clipmi.IndexFlatIP(512, device=gpu, coarse="bf16")
+    idx.add(db)
+    idx.id_base = id_base
+    return idx.search(q, K)
+
+
+@pytest.mark.parametrize("N,Q,K", [(65536, 1, 51), (70001, 16, 51), (100000, 33, 11), (131072, 64, 51),
+                                   (200003, 70, 51), (80000, 5, 300)])
+def test_coarse_bf16_path_is_bit_exact(clipmi, gpu, topk_oracle, N, Q, K):
+    """bf16 coarse scan + exact re-scoring returns the SAME bits as the exact path and the oracle."""
+    rng = np.random.default_rng(N + Q + K)
+    db = unit_rows(rng, N, 512)
+    q = unit_rows(rng, Q, 512)
+    D, I = _run_coarse(clipmi, gpu, db, q, K, id_base=7)
+    Ds, Is = topk_oracle.topk(db, q, K, id_base=7)
+    _assert_exact(D, I, Ds, Is, f"coarse N={N} Q={Q} K={K}")
+
+
+def test_coarse_bf16_unnormalised_rows_and_clustered_scores(clipmi, gpu, topk_oracle):
+    """Row norms from 0 to 3 (margin scales with the largest norm), near-duplicate rows whose scores differ
+    by less than the bf16 error (all must survive the coarse pass), exact ties."""
+    rng = np.random.default_rng(77)
+    N = 90000
+    db = unit_rows(rng, N, 512) * rng.uniform(0.0, 3.0, size=(N, 1)).astype(np.float32)
+    q = unit_rows(rng, 9, 512) * np.float32(1.7)
+    base = db[np.argmax(db @ q[0])].copy()
+    for j in range(200):                              # 200 rows within ~1e-4 of the best score
+        db[1000 + 7 * j] = base * np.float32(1.0 - 1e-6 * j)
+    db[50000] = db[1000]
+    D, I = _run_coarse(clipmi, gpu, db, q, 51)
+    Ds, Is = topk_oracle.topk(db, q, 51)
+    _assert_exact(D, I, Ds, Is, "coarse unnormalised/clustered")
+
+
+def test_coarse_bf16_overflow_falls_back_to_exact(clipmi, gpu, topk_oracle):
+    """More survivors than the coarse candidate capacity (300k identical rows): the device-side fallback
+    must run the exact scan; ties resolve by ascending id."""
+    rng = np.random.default_rng(78)
+    N = 300000
+    v = unit_rows(rng, 1, 512)
+    db = np.repeat(v, N, axis=0)
+    db[123456] *= np.float32(1.5)
+    q = unit_rows(rng, 2, 512)
+    D, I = _run_coarse(clipmi, gpu, db, q, 20)
+    Ds, Is = topk_oracle.topk(db, q, 20)
+    _assert_exact(D, I, Ds, Is, "coarse overflow fallback")

@@ -9,8 +9,10 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 g = torch.Generator(device=dev); g.manual_seed(1)
 db = torch.randn((N, 512), generator=g, device=dev, dtype=torch.float32)
 db /= db.norm(dim=1, keepdim=True)
-idx = clipmi.IndexFlatIP(512, device=dev); idx.add(db)
-for Q in (1, 16, 32, 64):
+coarse = len(sys.argv) > 2 and sys.argv[2] == "coarse"
+idx = clipmi.IndexFlatIP(512, device=dev, coarse="bf16" if coarse else None); idx.add(db)
+print("coarse bf16 path" if coarse else "exact f32 path", flush=True)
+for Q in ((1, 16, 64, 128) if coarse else (1, 16, 32, 64)):
     for K in (11, 51, 101):
         q = torch.randn((Q, 512), generator=g, device=dev); q /= q.norm(dim=1, keepdim=True)
         for _ in range(3): idx.search_device(q, K)
@@ -21,5 +23,5 @@ for Q in (1, 16, 32, 64):
         for _ in range(reps): idx.search_device(q, K)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        passes = (Q + 31) // 32
-        print(f"N={N} Q={Q} K={K}: {ms:.3f} ms/batch  {Q/ms*1e3:.0f} q/s  {passes*N*2048/ms/1e6:.1f} GB/s algorithmic", flush=True)
+        passes = (Q + 63) // 64 if coarse else (Q + 31) // 32
+        print(f"N={N} Q={Q} K={K}: {ms:.3f} ms/batch  {Q/ms*1e3:.0f} q/s  {passes*N*(1024 if coarse else 2048)/ms/1e6:.1f} GB/s algorithmic", flush=True)
