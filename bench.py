@@ -238,12 +238,14 @@ def main():
     os_ = torch.empty((64, K), dtype=torch.float32, device=dev)
     oi_ = torch.empty((64, K), dtype=torch.int64, device=dev)
     scan_ms = C.c_float(0)
+    survivors = C.c_longlong(-1)
     if coarse:
         dbh, rmax = idx.matrix_bf16()
         ws = torch.empty(L.clipmi_topk_ip_coarse_workspace_bytes(n_local, 512, Qp, K), dtype=torch.uint8, device=dev)
         clipmi._lib.check(L.clipmi_dbg_topk_coarse_scan_ms(db.data_ptr(), dbh.data_ptr(), n_local, 512, rmax, q.data_ptr(), Qp,
                                                            K, os_.data_ptr(), oi_.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                           clipmi._lib.stream_ptr(dev), 10, C.byref(scan_ms)), "coarse_scan_ms")
+                                                           clipmi._lib.stream_ptr(dev), 10, C.byref(scan_ms),
+                                                           C.byref(survivors)), "coarse_scan_ms")
         scan_bytes = n_local * 512 * 2
         scan_name = f"scan_coarse_bf16_kernel<512,{1 if Qp <= 16 else 2 if Qp <= 32 else 4}>"
         traffic_key = "scan_coarse_bytes_per_launch"
@@ -288,6 +290,7 @@ def main():
                                 "achieved": scan_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": scan_gbs / PEAK_HBM_GBS, "traffic": pmc_traffic(traffic_key),
                                 "kernel_ms": scan_ms.value, "algorithmic_bytes_per_launch": scan_bytes,
+                                "coarse_survivors_per_query": (survivors.value / Qp) if survivors.value >= 0 else None,
                                 "whole_call_gbs_per_gpu": scan_bytes * ((Q + Qp - 1) // Qp) * a.steps / dt_s / 1e9}},
     }
     if world == 1 and not a.no_cpu_baseline:

@@ -78,7 +78,7 @@ def lib():
     L.clipmi_topk_ip_coarse.argtypes = [vp, vp, i64, i32, C.c_float, vp, i32, i32, i64, vp, vp, vp, sz, vp]
     L.clipmi_dbg_topk_coarse_scan_ms.restype = i32
     L.clipmi_dbg_topk_coarse_scan_ms.argtypes = [vp, vp, i64, i32, C.c_float, vp, i32, i32, vp, vp, vp, sz, vp, i32,
-                                                 C.POINTER(C.c_float)]
+                                                 C.POINTER(C.c_float), C.POINTER(C.c_longlong)]
     L.clipmi_merge_topk_workspace_bytes.restype = sz
     L.clipmi_merge_topk_workspace_bytes.argtypes = [i32, i32, i32]
     L.clipmi_merge_topk.restype = i32

@@ -270,10 +270,10 @@ constexpr int SEL_THREADS = 512;
 // keys differ), then a rank-count sort of the K survivors. All passes stream the list from
 // global memory (it is L2-resident: a few thousand 8-byte entries).
 __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* __restrict__ cand,
-                                                                 const unsigned* __restrict__ gcnt, long long cap,
+                                                                 unsigned* __restrict__ gcnt, long long cap,
                                                                  int K, long long id_base, float* out_s,
                                                                  long long* out_i, float* thr_out,
-                                                                 const unsigned* run_if) {
+                                                                 const unsigned* run_if, unsigned* m_out = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (run_if && *run_if == 0) return;
     unsigned long long* red = reinterpret_cast<unsigned long long*>(smem);   // [16] min, [16] max
@@ -381,6 +381,12 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
             out_i[(size_t)q * K + e] = -1;
         }
     if (thr_out && need < K && tid == 0) thr_out[q] = -INFINITY;
+    // leave the counter zeroed for the next scan of this call (every thread read M at entry; the
+    // barriers above order that read before this store) — saves a memset node per scan
+    if (tid == 0) {
+        gcnt[q] = 0;
+        if (m_out) m_out[q] = (unsigned)M;        // list length, for measurement hooks
+    }
 }
 
 __global__ void fill_empty_kernel(float* out_s, long long* out_i, long long n) {
@@ -632,7 +638,27 @@ __global__ void __launch_bounds__(256) scan_coarse_bf16_kernel(CoarseArgs a) {
             step = nxt;
         }
     }
-    flush();
+    // final publication, aggregated per BLOCK: one returning global atomic per (block, query) issued by
+    // 64 lanes at once, then entries scatter to base + an LDS-counted offset. (Per-entry global atomics
+    // here meant ~166 k same-address atomics at the end of every scan: ~250 us fixed, as much as
+    // streaming 1.25 M rows.)
+    __syncthreads();
+    unsigned* hist = reinterpret_cast<unsigned*>(smem);              // query image is dead now: [64] counts
+    unsigned* gbase = hist + 64;                                     // [64] global base per query
+    unsigned* hoff = hist + 128;                                     // [64] running offsets
+    if (tid < 64) { hist[tid] = 0; hoff[tid] = 0; }
+    __syncthreads();
+    const int n_mine = *lcnt;
+    for (int e = lane; e < n_mine; e += 64) atomicAdd(&hist[list[e].x], 1u);
+    __syncthreads();
+    if (tid < 64) gbase[tid] = hist[tid] ? atomicAdd(&a.gcnt[tid], hist[tid]) : 0u;
+    __syncthreads();
+    for (int e = lane; e < n_mine; e += 64) {
+        const uint2 c = list[e];
+        const unsigned pos = gbase[c.x] + atomicAdd(&hoff[c.x], 1u);
+        if ((long long)pos < a.cap) a.cand[(size_t)c.x * a.cap + pos] = make_uint2(0u, c.y);
+        else *a.overflow = 1u;
+    }
 }
 
 // Exact f32 re-scoring of the coarse survivors. Each lane owns one (query, candidate) pair and runs the
@@ -660,13 +686,23 @@ __global__ void __launch_bounds__(256) rescore_pairs_kernel(const float* __restr
         const long long my = base + lane;
         const unsigned id_my = lst[my < M ? my : M - 1].y;
         float acc = 0.f;
+        // chunk c+1's 16 loads are issued (to registers) before chunk c is consumed from LDS: one
+        // HBM round trip per chunk stays, but it overlaps the previous chunk's LDS reads and fmaf chain
+        f32x4 nx[16];
+        const float* rowp[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const unsigned rid = __shfl(id_my, 4 * i + (lane >> 4));
+            rowp[i] = db + (size_t)rid * E + (lane & 15) * 4;
+            nx[i] = *reinterpret_cast<const f32x4*>(rowp[i]);
+        }
         for (int chunk = 0; chunk < E / 64; ++chunk) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r = 4 * i + (lane >> 4);
-                const unsigned rid = __shfl(id_my, r);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(db + (size_t)rid * E + chunk * 64 + (lane & 15) * 4);
-                *reinterpret_cast<f32x4*>(st + r * RS + (lane & 15) * 4) = v;
+            for (int i = 0; i < 16; ++i)
+                *reinterpret_cast<f32x4*>(st + (4 * i + (lane >> 4)) * RS + (lane & 15) * 4) = nx[i];
+            if (chunk + 1 < E / 64) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) nx[i] = *reinterpret_cast<const f32x4*>(rowp[i] + (chunk + 1) * 64);
             }
             wave_lds_sync();
 #pragma unroll
@@ -805,6 +841,8 @@ static int topk_ip_impl(const void* db_dev, int db_dtype, int64_t N, int E, cons
 
     if (int rc = opt_in_lds((const void*)select_topk_kernel, p.lds_sel)) return rc;
 
+    // candidate counters: zeroed once here; every select_topk_kernel re-zeroes the ones it consumed
+    if (hipMemsetAsync(gcnt, 0, 128, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
     for (int q0 = 0; q0 < Q; q0 += p.QA) {
         const int qa = (Q - q0) < p.QA ? (Q - q0) : p.QA;
         ScanArgs a;
@@ -823,7 +861,6 @@ static int topk_ip_impl(const void* db_dev, int db_dtype, int64_t N, int E, cons
             // pre-pass: exact K-th best score of the first S rows = a valid lower bound for the
             // K-th best of all rows; the main pass then only buffers scores >= that bound
             a.nrows = p.sample_rows;
-            if (hipMemsetAsync(gcnt, 0, 128, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
             int rc = launch_scan<true>(E, p.QG, a, p.grid_sample, p.waves, p.lds_scan, st);
             if (rc) return rc;
             hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, cand, gcnt, p.cap, K,
@@ -832,7 +869,6 @@ static int topk_ip_impl(const void* db_dev, int db_dtype, int64_t N, int E, cons
             a.thr_in = thr0;
         }
         a.nrows = N;
-        if (hipMemsetAsync(gcnt, 0, 128, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
         int rc = launch_scan<false>(E, p.QG, a, p.grid, p.waves, p.lds_scan, st, scan_ev);
         if (rc) return rc;
         hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, cand, gcnt, p.cap, K,
@@ -868,6 +904,7 @@ int launch_coarse(const CoarseArgs& a, int grid, hipStream_t st, hipEvent_t* ev)
 
 struct CoarseWs {
     uint2* cand_e; uint2* cand_c; unsigned* gcnt_e; unsigned* gcnt_c; float* thr0; float* tauc; unsigned* flag;
+    unsigned* last_m;
 };
 
 size_t carve_coarse(const Plan& p, void* base, size_t cap, CoarseWs* w) {
@@ -875,11 +912,12 @@ size_t carve_coarse(const Plan& p, void* base, size_t cap, CoarseWs* w) {
     CoarseWs x;
     x.cand_e = ar.take<uint2>((size_t)p.QA * p.cap);
     x.cand_c = ar.take<uint2>((size_t)COARSE_Q * COARSE_CAP);
-    x.gcnt_e = ar.take<unsigned>(32);
-    x.gcnt_c = ar.take<unsigned>(64);
+    x.gcnt_e = ar.take<unsigned>(32 + 64 + 4);      // one control block, cleared by ONE memset per call
+    x.gcnt_c = x.gcnt_e + 32;
+    x.flag = x.gcnt_e + 96;
     x.thr0 = ar.take<float>(64);
     x.tauc = ar.take<float>(64);
-    x.flag = ar.take<unsigned>(4);
+    x.last_m = ar.take<unsigned>(64);
     if (w) *w = x;
     return ar.off + 256;
 }
@@ -904,6 +942,8 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, int64_t N, int 
     for (int q0 = 0; q0 < Q; q0 += COARSE_Q) {
         const int qa = (Q - q0) < COARSE_Q ? (Q - q0) : COARSE_Q;
         const float* qg = q_dev + (size_t)q0 * E;
+        // counters + overflow flag: one memset per 64-query group; selects re-zero what they consume
+        if (hipMemsetAsync(w.gcnt_e, 0, 400, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
         ScanArgs a;
         a.db = static_cast<const float*>(db_dev);
         a.K = K; a.C = p.C; a.wave_bytes = p.wave_bytes;
@@ -916,17 +956,21 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, int64_t N, int 
         if (S2 < p.sample_rows) S2 = p.sample_rows;
         long long g2 = ((S2 + 15) / 16 + p.waves - 1) / p.waves;
         if (g2 > NUM_CU) g2 = NUM_CU;
+        // (one unfiltered scan of S2 rows was tried for small shards: its 32 k-entry selects cost more
+        //  than the level-1 scan + select they replace)
+        const bool two_level = S2 > p.sample_rows;
         for (int sub = 0; sub < qa; sub += p.QA) {
             const int qs = (qa - sub) < p.QA ? (qa - sub) : p.QA;
-            a.q = qg + (size_t)sub * E; a.QA = qs; a.run_if = nullptr;
-            a.nrows = p.sample_rows; a.thr_in = nullptr;
-            if (hipMemsetAsync(w.gcnt_e, 0, 128, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
-            if (int rc = launch_scan<true>(E, p.QG, a, p.grid_sample, p.waves, p.lds_scan, st)) return rc;
-            hipLaunchKernelGGL(select_topk_kernel, dim3(qs), dim3(SEL_THREADS), p.lds_sel, st, w.cand_e, w.gcnt_e, p.cap, K,
-                               (long long)0, (float*)nullptr, (long long*)nullptr, w.tauc + sub, (const unsigned*)nullptr);
-            CLIPMI_CHECK_LAUNCH("select_topk_kernel(sample 1)");
-            a.nrows = S2; a.thr_in = w.tauc + sub;
-            if (hipMemsetAsync(w.gcnt_e, 0, 128, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
+            a.q = qg + (size_t)sub * E; a.QA = qs; a.run_if = nullptr; a.thr_in = nullptr;
+            if (two_level) {
+                a.nrows = p.sample_rows;
+                if (int rc = launch_scan<true>(E, p.QG, a, p.grid_sample, p.waves, p.lds_scan, st)) return rc;
+                hipLaunchKernelGGL(select_topk_kernel, dim3(qs), dim3(SEL_THREADS), p.lds_sel, st, w.cand_e, w.gcnt_e, p.cap, K,
+                                   (long long)0, (float*)nullptr, (long long*)nullptr, w.tauc + sub, (const unsigned*)nullptr);
+                CLIPMI_CHECK_LAUNCH("select_topk_kernel(sample 1)");
+                a.thr_in = w.tauc + sub;
+            }
+            a.nrows = S2;
             if (int rc = launch_scan<true>(E, p.QG, a, (int)g2, p.waves, p.lds_scan, st)) return rc;
             hipLaunchKernelGGL(select_topk_kernel, dim3(qs), dim3(SEL_THREADS), p.lds_sel, st, w.cand_e, w.gcnt_e, p.cap, K,
                                (long long)0, (float*)nullptr, (long long*)nullptr, w.thr0 + sub, (const unsigned*)nullptr);
@@ -935,8 +979,6 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, int64_t N, int 
         // 2. coarse thresholds, 3. bf16 scan of all rows, 4. exact re-scoring, 5. select
         hipLaunchKernelGGL(coarse_thresholds_kernel, dim3((qa + 3) / 4), dim3(256), 0, st, w.thr0, qg, E, rmax, qa, w.tauc);
         CLIPMI_CHECK_LAUNCH("coarse_thresholds_kernel");
-        if (hipMemsetAsync(w.gcnt_c, 0, 256, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
-        if (hipMemsetAsync(w.flag, 0, 16, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
         CoarseArgs c;
         c.dbh = static_cast<const unsigned short*>(dbh_dev); c.nrows = N; c.q = qg; c.QA = qa; c.tauc = w.tauc;
         c.cand = w.cand_c; c.gcnt = w.gcnt_c; c.cap = COARSE_CAP; c.overflow = w.flag;
@@ -945,18 +987,18 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, int64_t N, int 
         int rc = qa <= 16 ? launch_coarse<1>(c, grid, st, scan_ev) : qa <= 32 ? launch_coarse<2>(c, grid, st, scan_ev)
                                                                               : launch_coarse<4>(c, grid, st, scan_ev);
         if (rc) return rc;
-        hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(32, qa), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
+        // ~2-3 k survivors per query = ~11 blocks of 256 pairs; a larger grid only queues idle blocks
+        hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(12, qa), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
                            static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, COARSE_CAP);
         CLIPMI_CHECK_LAUNCH("rescore_pairs_kernel");
         hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, w.cand_c, w.gcnt_c, COARSE_CAP, K,
                            (long long)id_base, out_score_dev + (size_t)q0 * K, (long long*)out_id_dev + (size_t)q0 * K,
-                           (float*)nullptr, (const unsigned*)nullptr);
+                           (float*)nullptr, (const unsigned*)nullptr, w.last_m);
         CLIPMI_CHECK_LAUNCH("select_topk_kernel(coarse)");
         // 6. fallback: exact scan + select, exiting at once unless a coarse list overflowed
         for (int sub = 0; sub < qa; sub += p.QA) {
             const int qs = (qa - sub) < p.QA ? (qa - sub) : p.QA;
             a.q = qg + (size_t)sub * E; a.QA = qs; a.nrows = N; a.thr_in = w.thr0 + sub; a.run_if = w.flag;
-            if (hipMemsetAsync(w.gcnt_e, 0, 128, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
             if (int rc2 = launch_scan<false>(E, p.QG, a, p.grid, p.waves, p.lds_scan, st)) return rc2;
             hipLaunchKernelGGL(select_topk_kernel, dim3(qs), dim3(SEL_THREADS), p.lds_sel, st, w.cand_e, w.gcnt_e, p.cap, K,
                                (long long)id_base, out_score_dev + (size_t)(q0 + sub) * K,
@@ -988,7 +1030,8 @@ extern "C" int clipmi_topk_ip_coarse(const void* db_dev, const void* db_bf16_dev
 // Measurement hook: clipmi_topk_ip_coarse `reps` times with events around the bf16 scan kernel (Q <= 64).
 extern "C" int clipmi_dbg_topk_coarse_scan_ms(const void* db_dev, const void* db_bf16_dev, int64_t N, int E, float rmax,
                                               const float* q_dev, int Q, int K, float* out_score_dev, int64_t* out_id_dev,
-                                              void* ws_dev, size_t ws_bytes, void* stream, int reps, float* scan_ms) {
+                                              void* ws_dev, size_t ws_bytes, void* stream, int reps, float* scan_ms,
+                                              long long* survivors) {
     if (!scan_ms || reps < 1 || Q > COARSE_Q) return set_err(CLIPMI_EINVAL, "dbg_topk_coarse_scan_ms: bad arguments");
     hipEvent_t ev[2];
     if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess)
@@ -1007,6 +1050,19 @@ extern "C" int clipmi_dbg_topk_coarse_scan_ms(const void* db_dev, const void* db
     (void)hipEventDestroy(ev[0]);
     (void)hipEventDestroy(ev[1]);
     if (rc == 0) *scan_ms = (float)(total / reps);
+    if (rc == 0 && survivors) {       // rows that survived the coarse pass, summed over the Q queries of the last call
+        Plan p;
+        CoarseWs w;
+        make_plan(N, E, Q > 32 ? 32 : Q, K, p);
+        carve_coarse(p, ws_dev, ws_bytes, &w);
+        unsigned host[64];
+        if (hipStreamSynchronize(as_stream(stream)) != hipSuccess ||
+            hipMemcpy(host, w.last_m, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess)
+            return set_err(CLIPMI_EHIP, "hipMemcpy(gcnt)");
+        long long tot = 0;
+        for (int i = 0; i < Q; ++i) tot += host[i] < COARSE_CAP ? host[i] : COARSE_CAP;
+        *survivors = tot;
+    }
     return rc;
 }
 

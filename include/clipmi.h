@@ -194,7 +194,8 @@ int clipmi_dbg_topk_scan_ms(const void* db_dev, int64_t N, int E, const float* q
 /* clipmi_topk_ip_coarse `reps` times with HIP events around the bf16 scan kernel (Q <= 64) */
 int clipmi_dbg_topk_coarse_scan_ms(const void* db_dev, const void* db_bf16_dev, int64_t N, int E, float rmax,
                                    const float* q_dev, int Q, int K, float* out_score_dev, int64_t* out_id_dev,
-                                   void* ws_dev, size_t ws_bytes, void* stream, int reps, float* scan_ms);
+                                   void* ws_dev, size_t ws_bytes, void* stream, int reps, float* scan_ms,
+                                   long long* survivors /* optional: rows kept by the coarse pass, summed over Q */);
 
 /* clipmi_encode_image `reps` times with HIP events around every launch of the GEMM whose
  * epilogue is `probe_epi` (1 = MLP c_fc + QuickGELU), on `stream`; synchronises;
