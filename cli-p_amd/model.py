@@ -57,10 +57,12 @@ class CLIP:
         if self.device.type != "cuda":
             raise _lib.ClipmiError(f"{what} needs the HIP path (device {self.device} is not a GPU); no CPU fallback")
 
-    def encode_image(self, image, normalize=False):
+    def encode_image(self, image, normalize=False, out=None, stream=None):
         """image: [B,3,R,R] f32/bf16 (output of `transform`, already normalised) or uint8 raw RGB
         (normalisation fused on the device). Returns f32 [B,E]; `normalize=True` also applies
-        build-index.py:50 (x / x.norm(dim=-1, keepdim=True)) in the same stream."""
+        build-index.py:50 (x / x.norm(dim=-1, keepdim=True)) in the same stream.
+        `out` (f32 [B,E] device tensor) and `stream` (a raw hipStream_t as int, e.g. one created with a
+        CU mask) let a caller run several encoders concurrently; defaults: fresh tensor, torch's stream."""
         self._require_gpu("encode_image")
         L = _lib.lib()
         if not isinstance(image, torch.Tensor):
@@ -72,7 +74,10 @@ class CLIP:
             image = image.float()
         image = image.to(self.device).contiguous()
         B = image.shape[0]
-        out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=self.device)
+        import ctypes as _C
+        sp = _lib.stream_ptr(self.device) if stream is None else _C.c_void_p(int(stream))
         for lo in range(0, B, self.max_batch):
             hi = min(B, lo + self.max_batch)
             need = L.clipmi_encode_image_workspace_bytes(self.vision, hi - lo)
@@ -81,7 +86,7 @@ class CLIP:
             ws = self._workspace(need)
             rc = L.clipmi_encode_image(self.vision, self._vblob.data_ptr(), image[lo:hi].data_ptr(),
                                        _DTYPES[image.dtype], hi - lo, out[lo:hi].data_ptr(), int(bool(normalize)),
-                                       ws.data_ptr(), ws.numel(), _lib.stream_ptr(self.device))
+                                       ws.data_ptr(), ws.numel(), sp)
             _lib.check(rc, "clipmi_encode_image")
         return out
 
