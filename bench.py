@@ -217,7 +217,7 @@ def main():
         db[s:e] = blk / blk.norm(dim=1, keepdim=True)
     idx = clipmi.IndexFlatIP(512, device=dev, coarse=None if a.exact_only else "bf16")
     idx.add(db)
-    coarse = idx._use_coarse()
+    coarse = idx.uses_coarse()
     if coarse:
         idx.matrix_bf16()        # bf16 copy + row-norm bound are part of the index, built once
     gq = torch.Generator(device=dev)

@@ -13,8 +13,6 @@ calls clipmi_topk_ip through the C ABI. Multi-GPU: one process per GPU, rows spl
 by rank, per-rank top-K, ONE all-gather (RCCL when the tensors are on the GPU), then the same
 K-way merge on every rank (clipmi_merge_topk) — SURVEY.md §8e.
 """
-import ctypes as C
-import os
 import struct
 
 import numpy as np
@@ -120,7 +118,8 @@ class IndexFlatIP:
             self._dbh, self._rmax = dbh, rmax * (1.0 + 1e-6)
         return self._dbh, self._rmax
 
-    def _use_coarse(self):
+    def uses_coarse(self):
+        """True when searches go through the coarse-then-exact path (bf16 copy present, d = 512, N >= 65536)."""
         return self.coarse == "bf16" and self.d == 512 and self.ntotal >= 65536
 
     # -- query side ---------------------------------------------------------------------------
@@ -134,7 +133,7 @@ class IndexFlatIP:
         q = q.to(device=self.device, dtype=torch.float32).contiguous()
         Q = q.shape[0]
         N = db.shape[0]
-        coarse = self._use_coarse()
+        coarse = self.uses_coarse()
         if coarse:
             dbh, rmax = self.matrix_bf16()
             coarse = rmax > 0.0 and np.isfinite(rmax)

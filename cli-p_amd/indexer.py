@@ -12,7 +12,6 @@ synthetic model. Knobs: CLIPMI_BATCH (default 435 = whole rounds of GEMM tiles o
 CLIPMI_WORKERS (decode threads, default 8).
 """
 import os
-import sys
 
 from . import pipeline, store as vstore
 from .index import IndexFlatIP, write_index

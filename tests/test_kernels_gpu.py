@@ -3,7 +3,6 @@ against plain torch fp32 references of the same op computed on the SAME bf16-rou
 the only differences are accumulation order and the kernel's own output rounding.
 Tolerances: f32 outputs 2e-4 relative to the output scale (f32 accumulation over K <= 3072);
 bf16 outputs one bf16 ulp (2^-8 relative) on top of that."""
-import numpy as np
 import pytest
 import torch
 

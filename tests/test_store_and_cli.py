@@ -1,7 +1,7 @@
 """CPU tests of the storage schema, the host transform and the CLI glue (no GPU: the model and the
 search are stubbed; what is under test is keys, ordering, resume semantics, REPL arithmetic)."""
 import importlib.util
-import io
+
 import os
 import sys
 
