@@ -211,6 +211,8 @@ class ShardedFlatIP:
             self._gath = torch.empty(self.world * nbytes, dtype=torch.uint8, device=device)
             self._rec_s = self._rec[:Q * K * 4].view(torch.float32).view(Q, K)
             self._rec_i = self._rec[ids_off:].view(torch.int64).view(Q, K)
+            self._out_s = torch.empty((Q, K), dtype=torch.float32, device=device)
+            self._out_i = torch.empty((Q, K), dtype=torch.int64, device=device)
             self._rec_key = key
         return self._rec, self._gath, self._rec_s, self._rec_i
 
@@ -225,8 +227,7 @@ class ShardedFlatIP:
             self.local.search_device(q, K, out=(rec_s, rec_i))
             dist.all_gather_into_tensor(gath, rec, group=self.group)
             L = _lib.lib()
-            out_s = torch.empty((Q, K), dtype=torch.float32, device=dev)
-            out_i = torch.empty((Q, K), dtype=torch.int64, device=dev)
+            out_s, out_i = self._out_s, self._out_i      # reused across calls of the same (Q, K): copy to keep
             rc = L.clipmi_merge_topk_packed(gath.data_ptr(), rec.numel(), self.world, Q, K, out_s.data_ptr(),
                                             out_i.data_ptr(), _lib.stream_ptr(dev))
             _lib.check(rc, "clipmi_merge_topk_packed")
