@@ -108,8 +108,50 @@ def load_state_dict(path):
             if "state_dict" in sd:
                 sd = sd["state_dict"]
     sd = {k: v.float() for k, v in sd.items() if torch.is_tensor(v)}
+    if "visual.conv1.weight" not in sd and "vision_model.embeddings.patch_embedding.weight" in sd:
+        sd = from_hf_state_dict(sd)          # a Hugging Face CLIPModel checkpoint
     if "visual.conv1.weight" not in sd:
         raise ValueError(f"{path}: no 'visual.conv1.weight' — expected OpenAI CLIP ViT key names")
+    return sd
+
+
+def from_hf_state_dict(hf):
+    """Map a Hugging Face `CLIPModel` state-dict (keys `vision_model.*`, `text_model.*`,
+    `visual_projection.weight`, `text_projection.weight`) onto the OpenAI key names the packer expects:
+    q/k/v projections are concatenated in that order into `in_proj_*`, `visual_projection.weight`
+    ([E, W]) is `visual.proj` transposed, `pre_layrnorm` is `ln_pre`."""
+    hf = {k: v.float() for k, v in hf.items() if torch.is_tensor(v)}
+    sd = {}
+
+    def layers(src, dst):
+        i = 0
+        while f"{src}.encoder.layers.{i}.layer_norm1.weight" in hf:
+            s_, d_ = f"{src}.encoder.layers.{i}", f"{dst}.resblocks.{i}"
+            sd[f"{d_}.attn.in_proj_weight"] = torch.cat([hf[f"{s_}.self_attn.{x}_proj.weight"] for x in "qkv"], 0)
+            sd[f"{d_}.attn.in_proj_bias"] = torch.cat([hf[f"{s_}.self_attn.{x}_proj.bias"] for x in "qkv"], 0)
+            sd[f"{d_}.attn.out_proj.weight"] = hf[f"{s_}.self_attn.out_proj.weight"]
+            sd[f"{d_}.attn.out_proj.bias"] = hf[f"{s_}.self_attn.out_proj.bias"]
+            for a, b in (("layer_norm1", "ln_1"), ("layer_norm2", "ln_2")):
+                sd[f"{d_}.{b}.weight"], sd[f"{d_}.{b}.bias"] = hf[f"{s_}.{a}.weight"], hf[f"{s_}.{a}.bias"]
+            for a, b in (("fc1", "c_fc"), ("fc2", "c_proj")):
+                sd[f"{d_}.mlp.{b}.weight"], sd[f"{d_}.mlp.{b}.bias"] = hf[f"{s_}.mlp.{a}.weight"], hf[f"{s_}.mlp.{a}.bias"]
+            i += 1
+        return i
+
+    sd["visual.conv1.weight"] = hf["vision_model.embeddings.patch_embedding.weight"]
+    sd["visual.class_embedding"] = hf["vision_model.embeddings.class_embedding"]
+    sd["visual.positional_embedding"] = hf["vision_model.embeddings.position_embedding.weight"]
+    sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"] = hf["vision_model.pre_layrnorm.weight"], hf["vision_model.pre_layrnorm.bias"]
+    sd["visual.ln_post.weight"], sd["visual.ln_post.bias"] = hf["vision_model.post_layernorm.weight"], hf["vision_model.post_layernorm.bias"]
+    sd["visual.proj"] = hf["visual_projection.weight"].t().contiguous()
+    layers("vision_model", "visual.transformer")
+    sd["token_embedding.weight"] = hf["text_model.embeddings.token_embedding.weight"]
+    sd["positional_embedding"] = hf["text_model.embeddings.position_embedding.weight"]
+    sd["ln_final.weight"], sd["ln_final.bias"] = hf["text_model.final_layer_norm.weight"], hf["text_model.final_layer_norm.bias"]
+    sd["text_projection"] = hf["text_projection.weight"].t().contiguous()
+    layers("text_model", "transformer")
+    if "logit_scale" in hf:
+        sd["logit_scale"] = hf["logit_scale"]
     return sd
 
 

@@ -89,6 +89,21 @@ def test_encode_image_l14_geometry(clipmi, gpu):
     assert err <= 3 * noise + 1e-3 and cos >= 0.9995
 
 
+def test_encode_image_vit_b16_full_size(clipmi, gpu):
+    """ViT-B/16 (197 tokens: flash attention with a 5-key tail block; 16-px patches, K = 768), two images."""
+    sd = clipmi.weights.random_state_dict("ViT-B/16", seed=2)
+    g = torch.Generator(device="cpu"); g.manual_seed(11)
+    images = torch.randn(2, 3, 224, 224, generator=g)
+    model = clipmi.CLIP(sd, device=gpu)
+    assert model.vision.tokens == 197 and model.vision.patch_k == 768
+    got = model.encode_image(images).cpu()
+    ref, noise = _tolerances(clipmi, sd, clip_oracle.encode_image, images)
+    err = (got - ref).abs().max().item()
+    cos = _cos(got, ref).min().item()
+    print(f"ViT-B/16: image err {err:.4g} (bf16-emulation noise {noise:.4g}), min cosine {cos:.6f}")
+    assert err <= 3 * noise + 1e-3 and cos >= 0.9995
+
+
 def test_encode_image_vit_l14_336_full_size(clipmi, gpu):
     """BASELINE.json configs[3]: ViT-L/14@336px (24 layers, width 1024, 577 tokens, 768-D) on seeded
     weights, two images against the oracle."""

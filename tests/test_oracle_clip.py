@@ -48,3 +48,33 @@ def test_normalize_helpers():
     assert torch.allclose(clip_oracle.normalize_rows(x), torch.tensor([[0.6, 0.8], [0.0, 1.0]]))
     z = np.zeros((1, 4), np.float32)
     assert clip_oracle.normalize_query(z) is z
+
+
+def test_hf_named_checkpoint_maps_onto_openai_names(tmp_path):
+    """weights.from_hf_state_dict / load_state_dict on a Hugging Face CLIPModel checkpoint (random, built
+    from a config: no network): the mapped state-dict through the oracle equals the HF model's own output."""
+    import clipmi
+    from safetensors.torch import save_file
+    from transformers import CLIPConfig, CLIPModel, CLIPTextConfig, CLIPVisionConfig
+    torch.manual_seed(0)
+    vc = dict(hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, image_size=64,
+              patch_size=32, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+    tc = dict(vocab_size=512, hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+              max_position_embeddings=16, hidden_act="quick_gelu", layer_norm_eps=1e-5, eos_token_id=511, bos_token_id=510,
+              pad_token_id=0)
+    model = CLIPModel(CLIPConfig(text_config=tc, vision_config=vc, projection_dim=128)).eval()
+    for p_ in model.parameters():
+        p_.data.normal_(0, 0.05)
+    path = str(tmp_path / "hf_clip.safetensors")
+    save_file({k: v.contiguous() for k, v in model.state_dict().items() if "position_ids" not in k}, path)
+    sd = clipmi.weights.load_state_dict(path)
+    assert clipmi.weights.infer_dims(sd) == dict(v_width=128, v_layers=2, patch=32, res=64, v_tokens=5, t_width=128,
+                                                 t_layers=2, ctx=16, vocab=512, embed=128)
+    images, ids = clip_case.inputs("toy_seed0")
+    with torch.no_grad():
+        want_i = model.get_image_features(pixel_values=images)
+        want_t = model.get_text_features(input_ids=ids)
+    want_i = want_i if torch.is_tensor(want_i) else want_i.pooler_output
+    want_t = want_t if torch.is_tensor(want_t) else want_t.pooler_output
+    assert (clip_oracle.encode_image(sd, images) - want_i).abs().max() < 1e-4
+    assert (clip_oracle.encode_text(sd, ids) - want_t).abs().max() < 1e-4

@@ -1,0 +1,19 @@
+"""Latency of encode_text (+ normalise) at interactive batch sizes (development aid)."""
+import sys, os
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import clipmi
+dev = torch.device("cuda:0")
+model = clipmi.CLIP(clipmi.weights.random_state_dict("ViT-B/32", seed=0), device=dev)
+for Q in (1, 16, 64, 256):
+    ids = torch.zeros(Q, 77, dtype=torch.int64)
+    ids[:, 0] = 49406; ids[:, 1:9] = torch.randint(1, 40000, (Q, 8)); ids[:, 9] = 49407
+    ids = ids.to(dev)
+    for _ in range(3): model.encode_text(ids, normalize=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): model.encode_text(ids, normalize=True)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    print(f"encode_text Q={Q}: {ms:.3f} ms  {Q/ms*1e3:.0f} q/s", flush=True)
