@@ -492,7 +492,7 @@ struct CoarseArgs {
     int QA;                      // 1..16*QG
     const float* tauc;           // [QA]
     uint2* cand;                 // [QA][cap]: .y = row id (.x filled by the re-scoring pass)
-    unsigned* gcnt;              // [64]
+    unsigned* gcnt;              // [128]
     long long cap;
     unsigned* overflow;          // set to 1 when a list would exceed cap
 };
@@ -643,15 +643,16 @@ __global__ void __launch_bounds__(256) scan_coarse_bf16_kernel(CoarseArgs a) {
     // here meant ~166 k same-address atomics at the end of every scan: ~250 us fixed, as much as
     // streaming 1.25 M rows.)
     __syncthreads();
-    unsigned* hist = reinterpret_cast<unsigned*>(smem);              // query image is dead now: [64] counts
-    unsigned* gbase = hist + 64;                                     // [64] global base per query
-    unsigned* hoff = hist + 128;                                     // [64] running offsets
-    if (tid < 64) { hist[tid] = 0; hoff[tid] = 0; }
+    constexpr int QMAXC = 16 * QG;                                   // <= blockDim.x for every launch shape
+    unsigned* hist = reinterpret_cast<unsigned*>(smem);              // query image is dead now: [QMAXC] counts
+    unsigned* gbase = hist + QMAXC;                                  // global base per query
+    unsigned* hoff = hist + 2 * QMAXC;                               // running offsets
+    if (tid < QMAXC) { hist[tid] = 0; hoff[tid] = 0; }
     __syncthreads();
     const int n_mine = *lcnt;
     for (int e = lane; e < n_mine; e += 64) atomicAdd(&hist[list[e].x], 1u);
     __syncthreads();
-    if (tid < 64) gbase[tid] = hist[tid] ? atomicAdd(&a.gcnt[tid], hist[tid]) : 0u;
+    if (tid < QMAXC) gbase[tid] = hist[tid] ? atomicAdd(&a.gcnt[tid], hist[tid]) : 0u;
     __syncthreads();
     for (int e = lane; e < n_mine; e += 64) {
         const uint2 c = list[e];
@@ -889,14 +890,20 @@ extern "C" int clipmi_topk_ip(const void* db_dev, int db_dtype, int64_t N, int E
 namespace clipmi {
 namespace {
 constexpr long long COARSE_CAP = 1ll << 18;      // candidate slots per query of the coarse pass
-constexpr int COARSE_Q = 64;                     // queries per coarse pass
+constexpr int COARSE_Q = 64;                     // queries per coarse pass. (128 per pass was tried: its 128-KiB query image
+                                                 // leaves LDS for only 2 waves per CU = 2 of 4 SIMDs, and the pass turns
+                                                 // MFMA-bound: 5.29 ms per 128 queries vs 2 x 2.21 ms)
 
 template <int QG>
-int launch_coarse(const CoarseArgs& a, int grid, hipStream_t st, hipEvent_t* ev) {
-    const size_t lds = (size_t)QG * (512 / 32) * 1024 + 4 * (COARSE_LIST * 8 + 16);
+int launch_coarse(const CoarseArgs& a, long long nsteps, hipStream_t st, hipEvent_t* ev) {
+    // 128 queries need a 128-KiB bf16 query image: only two waves' candidate lists fit beside it
+    constexpr int WAVES = QG > 4 ? 2 : 4;
+    const size_t lds = (size_t)QG * (512 / 32) * 1024 + WAVES * (COARSE_LIST * 8 + 16);
     if (int rc = opt_in_lds((const void*)scan_coarse_bf16_kernel<512, QG>, lds)) return rc;
+    long long g_ = (nsteps + WAVES - 1) / WAVES;
+    const int grid = (int)(g_ < NUM_CU ? g_ : NUM_CU);
     if (ev) (void)hipEventRecord(ev[0], st);
-    hipLaunchKernelGGL((scan_coarse_bf16_kernel<512, QG>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((scan_coarse_bf16_kernel<512, QG>), dim3(grid), dim3(WAVES * 64), lds, st, a);
     if (ev) (void)hipEventRecord(ev[1], st);
     CLIPMI_CHECK_LAUNCH("scan_coarse_bf16_kernel");
     return 0;
@@ -912,12 +919,12 @@ size_t carve_coarse(const Plan& p, void* base, size_t cap, CoarseWs* w) {
     CoarseWs x;
     x.cand_e = ar.take<uint2>((size_t)p.QA * p.cap);
     x.cand_c = ar.take<uint2>((size_t)COARSE_Q * COARSE_CAP);
-    x.gcnt_e = ar.take<unsigned>(32 + 64 + 4);      // one control block, cleared by ONE memset per call
+    x.gcnt_e = ar.take<unsigned>(32 + COARSE_Q + 4);   // one control block, cleared by ONE memset per call
     x.gcnt_c = x.gcnt_e + 32;
-    x.flag = x.gcnt_e + 96;
-    x.thr0 = ar.take<float>(64);
-    x.tauc = ar.take<float>(64);
-    x.last_m = ar.take<unsigned>(64);
+    x.flag = x.gcnt_e + 32 + COARSE_Q;
+    x.thr0 = ar.take<float>(COARSE_Q);
+    x.tauc = ar.take<float>(COARSE_Q);
+    x.last_m = ar.take<unsigned>(COARSE_Q);
     if (w) *w = x;
     return ar.off + 256;
 }
@@ -943,7 +950,7 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, int64_t N, int 
         const int qa = (Q - q0) < COARSE_Q ? (Q - q0) : COARSE_Q;
         const float* qg = q_dev + (size_t)q0 * E;
         // counters + overflow flag: one memset per 64-query group; selects re-zero what they consume
-        if (hipMemsetAsync(w.gcnt_e, 0, 400, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
+        if (hipMemsetAsync(w.gcnt_e, 0, (32 + COARSE_Q + 4) * 4, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
         ScanArgs a;
         a.db = static_cast<const float*>(db_dev);
         a.K = K; a.C = p.C; a.wave_bytes = p.wave_bytes;
@@ -983,9 +990,9 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, int64_t N, int 
         c.dbh = static_cast<const unsigned short*>(dbh_dev); c.nrows = N; c.q = qg; c.QA = qa; c.tauc = w.tauc;
         c.cand = w.cand_c; c.gcnt = w.gcnt_c; c.cap = COARSE_CAP; c.overflow = w.flag;
         const long long nsteps = (N + 31) / 32;
-        const int grid = (int)((nsteps + 3) / 4 < NUM_CU ? (nsteps + 3) / 4 : NUM_CU);
-        int rc = qa <= 16 ? launch_coarse<1>(c, grid, st, scan_ev) : qa <= 32 ? launch_coarse<2>(c, grid, st, scan_ev)
-                                                                              : launch_coarse<4>(c, grid, st, scan_ev);
+        int rc = qa <= 16 ? launch_coarse<1>(c, nsteps, st, scan_ev)
+               : qa <= 32 ? launch_coarse<2>(c, nsteps, st, scan_ev)
+                          : launch_coarse<4>(c, nsteps, st, scan_ev);
         if (rc) return rc;
         // ~2-3 k survivors per query = ~11 blocks of 256 pairs; a larger grid only queues idle blocks
         hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(12, qa), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
@@ -1055,7 +1062,7 @@ extern "C" int clipmi_dbg_topk_coarse_scan_ms(const void* db_dev, const void* db
         CoarseWs w;
         make_plan(N, E, Q > 32 ? 32 : Q, K, p);
         carve_coarse(p, ws_dev, ws_bytes, &w);
-        unsigned host[64];
+        unsigned host[COARSE_Q];
         if (hipStreamSynchronize(as_stream(stream)) != hipSuccess ||
             hipMemcpy(host, w.last_m, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess)
             return set_err(CLIPMI_EHIP, "hipMemcpy(gcnt)");

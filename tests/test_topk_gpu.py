@@ -161,7 +161,7 @@ def _run_coarse(clipmi, gpu, db, q, K, id_base=0):
 
 
 @pytest.mark.parametrize("N,Q,K", [(65536, 1, 51), (70001, 16, 51), (100000, 33, 11), (131072, 64, 51),
-                                   (200003, 70, 51), (80000, 5, 300)])
+                                   (200003, 70, 51), (80000, 5, 300), (150000, 128, 51), (99999, 130, 21)])
 def test_coarse_bf16_path_is_bit_exact(clipmi, gpu, topk_oracle, N, Q, K):
     """bf16 coarse scan + exact re-scoring returns the SAME bits as the exact path and the oracle."""
     rng = np.random.default_rng(N + Q + K)

@@ -12,7 +12,7 @@ db /= db.norm(dim=1, keepdim=True)
 coarse = len(sys.argv) > 2 and sys.argv[2] == "coarse"
 idx = clipmi.IndexFlatIP(512, device=dev, coarse="bf16" if coarse else None); idx.add(db)
 print("coarse bf16 path" if coarse else "exact f32 path", flush=True)
-for Q in ((1, 16, 64, 128) if coarse else (1, 16, 32, 64)):
+for Q in ((1, 16, 64, 128, 256) if coarse else (1, 16, 32, 64)):
     for K in (11, 51, 101):
         q = torch.randn((Q, 512), generator=g, device=dev); q /= q.norm(dim=1, keepdim=True)
         for _ in range(3): idx.search_device(q, K)
