@@ -960,18 +960,22 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, int64_t N, int 
         //    read in the re-scoring pass). Level 1 (S1 rows, no threshold) only feeds level 2's filter.
         long long S2 = 32768;
         while (S2 < N / 8 && S2 * 2048 < N * (long long)K) S2 *= 2;
-        if (S2 < p.sample_rows) S2 = p.sample_rows;
+        // level 1 only has to thin level 2's candidates (S2*K/S1 per query): 8 k rows are enough, and its
+        // select then ranks 8 k entries per query instead of 32 k
+        const long long S1 = p.sample_rows < 8192 ? p.sample_rows : 8192;
+        const int g1 = (int)((S1 / 16 + p.waves - 1) / p.waves);
+        if (S2 < S1) S2 = S1;
         long long g2 = ((S2 + 15) / 16 + p.waves - 1) / p.waves;
         if (g2 > NUM_CU) g2 = NUM_CU;
         // (one unfiltered scan of S2 rows was tried for small shards: its 32 k-entry selects cost more
         //  than the level-1 scan + select they replace)
-        const bool two_level = S2 > p.sample_rows;
+        const bool two_level = S2 > S1;
         for (int sub = 0; sub < qa; sub += p.QA) {
             const int qs = (qa - sub) < p.QA ? (qa - sub) : p.QA;
             a.q = qg + (size_t)sub * E; a.QA = qs; a.run_if = nullptr; a.thr_in = nullptr;
             if (two_level) {
-                a.nrows = p.sample_rows;
-                if (int rc = launch_scan<true>(E, p.QG, a, p.grid_sample, p.waves, p.lds_scan, st)) return rc;
+                a.nrows = S1;
+                if (int rc = launch_scan<true>(E, p.QG, a, g1, p.waves, p.lds_scan, st)) return rc;
                 hipLaunchKernelGGL(select_topk_kernel, dim3(qs), dim3(SEL_THREADS), p.lds_sel, st, w.cand_e, w.gcnt_e, p.cap, K,
                                    (long long)0, (float*)nullptr, (long long*)nullptr, w.tauc + sub, (const unsigned*)nullptr);
                 CLIPMI_CHECK_LAUNCH("select_topk_kernel(sample 1)");
