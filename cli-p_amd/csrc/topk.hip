@@ -469,7 +469,7 @@ __device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
 }
 
 // tauc[q] = thr0[q] - 0.0041 * rmax * ||q||   (one wave per query)
-__global__ void __launch_bounds__(256) coarse_thresholds_kernel(const float* __restrict__ thr0, const float* __restrict__ q,
+__global__ void __launch_bounds__(256) coarse_thresholds_kernel(const float* thr0, const float* __restrict__ q,
                                                                 int E, float rmax, int QA, float* tauc) {
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -970,42 +970,49 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, int64_t N, int 
         // (one unfiltered scan of S2 rows was tried for small shards: its 32 k-entry selects cost more
         //  than the level-1 scan + select they replace)
         const bool two_level = S2 > S1;
+        CoarseArgs c;
+        c.dbh = static_cast<const unsigned short*>(dbh_dev); c.q = qg; c.QA = qa; c.tauc = w.tauc;
+        c.cand = w.cand_c; c.gcnt = w.gcnt_c; c.cap = COARSE_CAP; c.overflow = w.flag;
+        auto coarse_pass = [&](long long rows, float* thr_out, float* os, long long* oi, long long idb, hipEvent_t* ev,
+                               unsigned* m_out) -> int {
+            c.nrows = rows;
+            const long long nsteps = (rows + 31) / 32;
+            int rc_ = qa <= 16 ? launch_coarse<1>(c, nsteps, st, ev) : qa <= 32 ? launch_coarse<2>(c, nsteps, st, ev)
+                                                                               : launch_coarse<4>(c, nsteps, st, ev);
+            if (rc_) return rc_;
+            // ~2-3 k survivors per query = ~11 blocks of 256 pairs; a larger grid only queues idle blocks
+            hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(12, qa), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
+                               static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, COARSE_CAP);
+            CLIPMI_CHECK_LAUNCH("rescore_pairs_kernel");
+            hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, w.cand_c, w.gcnt_c, COARSE_CAP, K,
+                               idb, os, oi, thr_out, (const unsigned*)nullptr, m_out);
+            CLIPMI_CHECK_LAUNCH("select_topk_kernel(coarse)");
+            return 0;
+        };
+        // level 1 (exact, S1 rows, no threshold): in sub-passes of <= 32 queries
         for (int sub = 0; sub < qa; sub += p.QA) {
             const int qs = (qa - sub) < p.QA ? (qa - sub) : p.QA;
             a.q = qg + (size_t)sub * E; a.QA = qs; a.run_if = nullptr; a.thr_in = nullptr;
-            if (two_level) {
-                a.nrows = S1;
-                if (int rc = launch_scan<true>(E, p.QG, a, g1, p.waves, p.lds_scan, st)) return rc;
-                hipLaunchKernelGGL(select_topk_kernel, dim3(qs), dim3(SEL_THREADS), p.lds_sel, st, w.cand_e, w.gcnt_e, p.cap, K,
-                                   (long long)0, (float*)nullptr, (long long*)nullptr, w.tauc + sub, (const unsigned*)nullptr);
-                CLIPMI_CHECK_LAUNCH("select_topk_kernel(sample 1)");
-                a.thr_in = w.tauc + sub;
-            }
-            a.nrows = S2;
-            if (int rc = launch_scan<true>(E, p.QG, a, (int)g2, p.waves, p.lds_scan, st)) return rc;
+            a.nrows = two_level ? S1 : S2;
+            if (int rc = launch_scan<true>(E, p.QG, a, two_level ? g1 : (int)g2, p.waves, p.lds_scan, st)) return rc;
             hipLaunchKernelGGL(select_topk_kernel, dim3(qs), dim3(SEL_THREADS), p.lds_sel, st, w.cand_e, w.gcnt_e, p.cap, K,
-                               (long long)0, (float*)nullptr, (long long*)nullptr, w.thr0 + sub, (const unsigned*)nullptr);
-            CLIPMI_CHECK_LAUNCH("select_topk_kernel(sample 2)");
+                               (long long)0, (float*)nullptr, (long long*)nullptr, (two_level ? w.tauc : w.thr0) + sub,
+                               (const unsigned*)nullptr);
+            CLIPMI_CHECK_LAUNCH("select_topk_kernel(sample 1)");
+        }
+        // level 2 (S2 rows): the coarse machinery itself, all queries at once, filtered by level 1's bound;
+        // its exact re-scored K-th best is thr0
+        if (two_level) {
+            hipLaunchKernelGGL(coarse_thresholds_kernel, dim3((qa + 3) / 4), dim3(256), 0, st, w.tauc, qg, E, rmax, qa, w.tauc);
+            CLIPMI_CHECK_LAUNCH("coarse_thresholds_kernel(level 2)");
+            if (int rc = coarse_pass(S2, w.thr0, nullptr, nullptr, 0, nullptr, nullptr)) return rc;
         }
         // 2. coarse thresholds, 3. bf16 scan of all rows, 4. exact re-scoring, 5. select
         hipLaunchKernelGGL(coarse_thresholds_kernel, dim3((qa + 3) / 4), dim3(256), 0, st, w.thr0, qg, E, rmax, qa, w.tauc);
         CLIPMI_CHECK_LAUNCH("coarse_thresholds_kernel");
-        CoarseArgs c;
-        c.dbh = static_cast<const unsigned short*>(dbh_dev); c.nrows = N; c.q = qg; c.QA = qa; c.tauc = w.tauc;
-        c.cand = w.cand_c; c.gcnt = w.gcnt_c; c.cap = COARSE_CAP; c.overflow = w.flag;
-        const long long nsteps = (N + 31) / 32;
-        int rc = qa <= 16 ? launch_coarse<1>(c, nsteps, st, scan_ev)
-               : qa <= 32 ? launch_coarse<2>(c, nsteps, st, scan_ev)
-                          : launch_coarse<4>(c, nsteps, st, scan_ev);
-        if (rc) return rc;
-        // ~2-3 k survivors per query = ~11 blocks of 256 pairs; a larger grid only queues idle blocks
-        hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(12, qa), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
-                           static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, COARSE_CAP);
-        CLIPMI_CHECK_LAUNCH("rescore_pairs_kernel");
-        hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, w.cand_c, w.gcnt_c, COARSE_CAP, K,
-                           (long long)id_base, out_score_dev + (size_t)q0 * K, (long long*)out_id_dev + (size_t)q0 * K,
-                           (float*)nullptr, (const unsigned*)nullptr, w.last_m);
-        CLIPMI_CHECK_LAUNCH("select_topk_kernel(coarse)");
+        if (int rc = coarse_pass(N, nullptr, out_score_dev + (size_t)q0 * K, (long long*)out_id_dev + (size_t)q0 * K,
+                                 (long long)id_base, scan_ev, w.last_m))
+            return rc;
         // 6. fallback: exact scan + select, exiting at once unless a coarse list overflowed
         for (int sub = 0; sub < qa; sub += p.QA) {
             const int qs = (qa - sub) < p.QA ? (qa - sub) : p.QA;
