@@ -247,7 +247,7 @@ def main():
                                                            clipmi._lib.stream_ptr(dev), 10, C.byref(scan_ms),
                                                            C.byref(survivors)), "coarse_scan_ms")
         scan_bytes = n_local * 512 * 2
-        scan_name = f"scan_coarse_bf16_kernel<512,{1 if Qp <= 16 else 2 if Qp <= 32 else 4}>"
+        scan_name = f"scan_coarse_bf16_kernel<512,{1 if Qp <= 16 else 2 if Qp <= 32 else 4},false>"
         traffic_key = "scan_coarse_bytes_per_launch"
     else:
         ws = torch.empty(L.clipmi_topk_ip_workspace_bytes(n_local, 512, Qp, K), dtype=torch.uint8, device=dev)

@@ -500,7 +500,9 @@ struct CoarseArgs {
 constexpr int COARSE_LIST = 1536;       // per-wave (query, row) list entries in LDS
 constexpr int COARSE_FLUSH = 512;       // flush when more than this many are pending (a step adds <= 1024)
 
-template <int E, int QG>
+// PREPASS only changes the kernel's NAME (the level-2 pre-pass over S2 rows must not dilute the profiler's
+// per-name average of the main scan).
+template <int E, int QG, bool PREPASS>
 __global__ void __launch_bounds__(256) scan_coarse_bf16_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = E / 32;          // bf16 MFMA k-steps per 16-row tile
@@ -894,16 +896,16 @@ constexpr int COARSE_Q = 64;                     // queries per coarse pass. (12
                                                  // leaves LDS for only 2 waves per CU = 2 of 4 SIMDs, and the pass turns
                                                  // MFMA-bound: 5.29 ms per 128 queries vs 2 x 2.21 ms)
 
-template <int QG>
+template <int QG, bool PREPASS>
 int launch_coarse(const CoarseArgs& a, long long nsteps, hipStream_t st, hipEvent_t* ev) {
     // 128 queries need a 128-KiB bf16 query image: only two waves' candidate lists fit beside it
     constexpr int WAVES = QG > 4 ? 2 : 4;
     const size_t lds = (size_t)QG * (512 / 32) * 1024 + WAVES * (COARSE_LIST * 8 + 16);
-    if (int rc = opt_in_lds((const void*)scan_coarse_bf16_kernel<512, QG>, lds)) return rc;
+    if (int rc = opt_in_lds((const void*)scan_coarse_bf16_kernel<512, QG, PREPASS>, lds)) return rc;
     long long g_ = (nsteps + WAVES - 1) / WAVES;
     const int grid = (int)(g_ < NUM_CU ? g_ : NUM_CU);
     if (ev) (void)hipEventRecord(ev[0], st);
-    hipLaunchKernelGGL((scan_coarse_bf16_kernel<512, QG>), dim3(grid), dim3(WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((scan_coarse_bf16_kernel<512, QG, PREPASS>), dim3(grid), dim3(WAVES * 64), lds, st, a);
     if (ev) (void)hipEventRecord(ev[1], st);
     CLIPMI_CHECK_LAUNCH("scan_coarse_bf16_kernel");
     return 0;
@@ -977,8 +979,10 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, int64_t N, int 
                                unsigned* m_out) -> int {
             c.nrows = rows;
             const long long nsteps = (rows + 31) / 32;
-            int rc_ = qa <= 16 ? launch_coarse<1>(c, nsteps, st, ev) : qa <= 32 ? launch_coarse<2>(c, nsteps, st, ev)
-                                                                               : launch_coarse<4>(c, nsteps, st, ev);
+            const bool pre = thr_out != nullptr;
+            int rc_ = qa <= 16 ? (pre ? launch_coarse<1, true>(c, nsteps, st, ev) : launch_coarse<1, false>(c, nsteps, st, ev))
+                    : qa <= 32 ? (pre ? launch_coarse<2, true>(c, nsteps, st, ev) : launch_coarse<2, false>(c, nsteps, st, ev))
+                               : (pre ? launch_coarse<4, true>(c, nsteps, st, ev) : launch_coarse<4, false>(c, nsteps, st, ev));
             if (rc_) return rc_;
             // ~2-3 k survivors per query = ~11 blocks of 256 pairs; a larger grid only queues idle blocks
             hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(12, qa), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
