@@ -200,3 +200,55 @@ def test_coarse_bf16_overflow_falls_back_to_exact(clipmi, gpu, topk_oracle):
     D, I = _run_coarse(clipmi, gpu, db, q, 20)
     Ds, Is = topk_oracle.topk(db, q, 20)
     _assert_exact(D, I, Ds, Is, "coarse overflow fallback")
+
+
+def test_full_size_10m_properties(clipmi, gpu, topk_oracle):
+    """BASELINE.json's full size (10 M x 512, K = 51): size-independent properties instead of a CPU sort of
+    10 M rows — (i) the coarse-then-exact path and the exact f32 scan return identical bits; (ii) every
+    returned score equals the oracle's score of that row; (iii) rows are sorted (score desc, id asc), ids
+    unique; (iv) no row outside the result beats the K-th score, checked on a 200 k-row random subset with
+    the oracle; (v) an 8-way sharded search + merge equals the single pass."""
+    N, Q, K = 10_000_000, 64, 51
+    g = torch.Generator(device=gpu); g.manual_seed(42)
+    db = torch.empty((N, 512), dtype=torch.float32, device=gpu)
+    for s in range(0, N, 1 << 20):
+        e = min(N, s + (1 << 20))
+        blk = torch.randn((e - s, 512), generator=g, device=gpu)
+        db[s:e] = blk / blk.norm(dim=1, keepdim=True)
+    db[9_999_999] = db[17]                                   # duplicate row at the far end
+    q = torch.randn((Q, 512), generator=g, device=gpu)
+    q = q / q.norm(dim=1, keepdim=True)
+    q[3] = db[17]                                            # a query with an exact tie pair at rank 0/1
+    exact = clipmi.IndexFlatIP(512, device=gpu); exact.add(db)
+    coarse = clipmi.IndexFlatIP(512, device=gpu, coarse="bf16"); coarse.add(db)
+    De, Ie = exact.search(q, K)
+    Dc, Ic = coarse.search(q, K)
+    _assert_exact(Dc, Ic, De, Ie, "coarse vs exact at 10M")
+    assert list(Ie[3, :2]) == [17, 9_999_999] and De[3, 0] == De[3, 1]
+    qh = q.cpu().numpy()
+    for j in (0, 3, 31, 63):
+        rows = Ie[j]
+        assert len(set(rows.tolist())) == K
+        sc = topk_oracle.scores(db[torch.from_numpy(rows).to(gpu)].cpu().numpy(), qh[j])
+        assert np.array_equal(sc.view(np.uint32), De[j].view(np.uint32))
+        order = np.lexsort((rows, -De[j].astype(np.float64)))
+        assert np.array_equal(order, np.arange(K))
+    rng = np.random.default_rng(7)
+    sub = np.sort(rng.choice(N, 200_000, replace=False))
+    subdb = db[torch.from_numpy(sub).to(gpu)].cpu().numpy()
+    for j in (0, 63):
+        sc = topk_oracle.scores(subdb, qh[j])
+        inside = set(Ie[j].tolist())
+        better = [(s_, int(i_)) for s_, i_ in zip(sc, sub) if int(i_) not in inside and
+                  (s_ > De[j, -1] or (s_ == De[j, -1] and i_ < Ie[j, -1]))]
+        assert not better, better[:3]
+    # (v) sharded == single
+    parts_s, parts_i = [], []
+    for r in range(8):
+        lo, hi = clipmi.shard_bounds(N, 8, r)
+        sh = clipmi.IndexFlatIP(512, device=gpu, coarse="bf16")
+        sh.add(db[lo:hi]); sh.id_base = lo
+        s_, i_ = sh.search(q, K)
+        parts_s.append(s_); parts_i.append(i_)
+    Ms, Mi = topk_oracle.merge(np.stack(parts_s), np.stack(parts_i), K)
+    _assert_exact(Ms, Mi, De, Ie, "8 shards + merge vs single at 10M")
