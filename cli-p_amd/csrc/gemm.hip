@@ -59,7 +59,10 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st) {
     if (algo == 0 && ok256 && g.M >= 1024) {
         const long long tiles = (long long)(g.N / 256) * ((g.M + 255) / 256);
         const long long rounds = (tiles + NUM_CU - 1) / NUM_CU;
-        use256 = tiles * 10 >= rounds * NUM_CU * 8;         // >= 80 % of the last round's slots used
+        // calibrated with tools/gemm_rule.py: the 256x256 kernel wins from ~0.74-0.78 fill of its rounds
+        // (earlier for long K, where its mainloop advantage outweighs the idle CUs of the last round)
+        const long long pct = g.K >= 2048 ? 72 : 78;
+        use256 = tiles * 100 >= rounds * NUM_CU * pct;
     }
     if (!use256) return launch_gemm(g, epi, st);
     if (g.M < 1 || !g.A || !g.W || !g.out) return set_err(CLIPMI_EINVAL, "gemm: bad arguments");
