@@ -1,6 +1,7 @@
 // gemm.hip — instantiation and launch of the bf16 NT GEMM (see gemm.hpp).
-#include "gemm256.hpp"
+#include "gemm256p.hpp"
 #include <hip/hip_ext.h>
+#include <cstdlib>
 
 namespace clipmi {
 
@@ -49,13 +50,44 @@ static int launch_epi256(const GemmArgs& g, hipStream_t st) {
     return 0;
 }
 
-// algo: 0 = choose by shape, 1 = force the 128x128 kernel, 2 = force the 256x256 kernel
+// persistent, role-split 256x256 kernel (gemm256p.hpp): pure-store epilogues only
+template <int EPI>
+static int launch_epi256p(const GemmArgs& g, hipStream_t st) {
+    const int tiles = (g.N / 256) * ((g.M + 255) / 256);
+    const int grid = tiles < NUM_CU ? tiles : NUM_CU;
+    const int lds = G256_LDS + g.N * 4 + ((g.dbg & 12) ? 2048 : 0);
+    static thread_local int opted = 0;
+    if (opted < lds) {
+        if (hipFuncSetAttribute((const void*)gemm256p_bf16_nt_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G256_LDS + G256P_MAX_N * 4) != hipSuccess)
+            return set_err(CLIPMI_EHIP, "hipFuncSetAttribute(gemm256p, %d B LDS)", G256_LDS + G256P_MAX_N * 4);
+        opted = G256_LDS + G256P_MAX_N * 4;
+    }
+    GemmProbe& p = gemm_probe();
+    if (p.active && p.epi == EPI && p.n < GemmProbe::MAX) {
+        hipExtLaunchKernelGGL(gemm256p_bf16_nt_kernel<EPI>, dim3(grid), dim3(512), lds, st, p.ev[2 * p.n],
+                              p.ev[2 * p.n + 1], 0, g);
+        ++p.n;
+    } else {
+        hipLaunchKernelGGL(gemm256p_bf16_nt_kernel<EPI>, dim3(grid), dim3(512), lds, st, g);
+    }
+    CLIPMI_CHECK_LAUNCH("gemm256p_bf16_nt_kernel");
+    return 0;
+}
+
+// algo: 0 = choose by shape, 1 = force the 128x128 kernel, 2 = force the 256x256 kernel,
+//       3 = force the persistent 256x256 kernel
 int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st) {
     const bool ok256 = g.N % 256 == 0 && g.K % 64 == 0 && g.K >= 128;
     if (algo == 2 && !ok256) return set_err(CLIPMI_EINVAL, "gemm256: N=%d K=%d (need N %% 256 == 0, K %% 64 == 0, K >= 128)", g.N, g.K);
+    const bool ok256p = ok256 && g.K % 128 == 0 && g.N <= G256P_MAX_N && (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_QGELU_BF16) &&
+                        g.K <= (1 << 20);
+    if (algo == 3 && !ok256p)
+        return set_err(CLIPMI_EINVAL, "gemm256p: M=%d N=%d K=%d epi=%d (need N %% 256 == 0, K %% 128 == 0, bf16-store epilogue)", g.M, g.N, g.K, epi);
     // by shape: the 256x256 pipeline wins when its tiles fill the 256 CUs in whole rounds (r01 on MI355X,
     // M=25600: N=2304/3072 -> 781/841 TF vs 702/685; N=768 -> 300 tiles = 1.17 rounds, 408/769 vs 521/904)
-    bool use256 = algo == 2;
+    bool use256 = algo == 2 || algo == 3;
+    bool use256p = algo == 3;
     if (algo == 0 && ok256 && g.M >= 1024) {
         const long long tiles = (long long)(g.N / 256) * ((g.M + 255) / 256);
         const long long rounds = (tiles + NUM_CU - 1) / NUM_CU;
@@ -63,9 +95,16 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st) {
         // (earlier for long K, where its mainloop advantage outweighs the idle CUs of the last round)
         const long long pct = g.K >= 2048 ? 72 : 78;
         use256 = tiles * 100 >= rounds * NUM_CU * pct;
+        // more than one round of tiles: the persistent kernel overlaps each tile's write-out with the next
+        // tile's K-loop
+        use256p = use256 && ok256p && tiles > NUM_CU;
     }
     if (!use256) return launch_gemm(g, epi, st);
     if (g.M < 1 || !g.A || !g.W || !g.out) return set_err(CLIPMI_EINVAL, "gemm: bad arguments");
+    if (use256p) {
+        if (epi == EPI_BIAS_BF16) return launch_epi256p<EPI_BIAS_BF16>(g, st);
+        return launch_epi256p<EPI_BIAS_QGELU_BF16>(g, st);
+    }
     switch (epi) {
         case EPI_BIAS_BF16: return launch_epi256<EPI_BIAS_BF16>(g, st);
         case EPI_BIAS_QGELU_BF16: return launch_epi256<EPI_BIAS_QGELU_BF16>(g, st);
@@ -105,5 +144,7 @@ extern "C" int clipmi_dbg_gemm_bf16(const void* a_dev, const void* w_dev, const 
     g.bias = bias_dev;
     g.out = out_dev;
     g.M = M; g.N = N; g.K = K;
+    if (const char* e = getenv("CLIPMI_GEMM_DBG")) g.dbg = atoi(e);
+    if (g.dbg & 12) { g.pos = bias_dev; g.bias = nullptr; }     // stamps land in the caller's "bias" buffer (>= 4 KiB)
     return launch_gemm_algo(g, epi, algo, as_stream(stream));
 }

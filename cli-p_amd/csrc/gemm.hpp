@@ -35,11 +35,23 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
+// x * sigmoid(1.702 x)   (OpenAI CLIP QuickGELU) = x / (1 + 2^(-1.702 log2(e) x)): one v_exp_f32
+// and one v_rcp_f32 (1 ulp each; the result is rounded to bf16 right after). The transcendental pair is
+// what the epilogue of the largest GEMM pays for (quarter-rate units): everything else is packed f32 math.
+constexpr float QGELU_C = -2.4554669595930157f;        // -1.702 * log2(e)
 __device__ __forceinline__ float quick_gelu(float x) {
-    // x * sigmoid(1.702 x)   (OpenAI CLIP QuickGELU). v_exp_f32 + v_rcp_f32 (1 ulp): the
-    // result is rounded to bf16 right after, and an IEEE divide costs ~10 VALU ops per element in the
-    // epilogue of the largest GEMM.
-    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * QGELU_C));
+}
+__device__ __forceinline__ f32x4 quick_gelu4(f32x4 x) {
+    const f32x4 t = x * QGELU_C;
+    f32x4 e;
+    e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+    e.z = __builtin_amdgcn_exp2f(t.z); e.w = __builtin_amdgcn_exp2f(t.w);
+    const f32x4 d = e + 1.0f;
+    f32x4 r;
+    r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+    r.z = __builtin_amdgcn_rcpf(d.z); r.w = __builtin_amdgcn_rcpf(d.w);
+    return x * r;
 }
 
 enum Epilogue {
@@ -59,6 +71,7 @@ struct GemmArgs {
     // EPI_PATCH_F32 only
     const float* pos;          // [L][N]
     int np, L;
+    int dbg;                   // development experiments only (tools/gemm_persist.py); 0 in every product path
 };
 
 // Tile order shared by both GEMM kernels. (1) XCD split: hardware deals workgroups round-robin over
@@ -213,7 +226,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
             f32x4 v = acc[mt][nt] + bz[nt];
             if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16) {
                 if (EPI == EPI_BIAS_QGELU_BF16) {
-                    v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
+                    v = quick_gelu4(v);
                 }
                 if (valid)
                     *reinterpret_cast<uint2*>(static_cast<unsigned short*>(g.out) + orow * g.N + n) =

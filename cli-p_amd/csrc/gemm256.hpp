@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(512, 2) gemm256_bf16_nt_kernel(GemmArgs g) {
                 for (int nt = 0; nt < 2; ++nt) {
                     f32x4 v = acc[idx >> 2][idx & 3][b][nt] + bz[b][nt];
                     if (EPI == EPI_BIAS_QGELU_BF16) {
-                        v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
+                        v = quick_gelu4(v);
                     }
                     const int colbyte = (b * 128 + wn * 32 + nt * 16 + 4 * fg) * 2;
                     const int off = row * 512 + ((((colbyte >> 4) ^ (row & 15)) << 4) | (colbyte & 8));

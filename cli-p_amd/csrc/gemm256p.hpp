@@ -1,0 +1,333 @@
+// gemm256p.hpp — persistent, role-split form of the 256x256x64 bf16 NT GEMM (gemm256.hpp) for the
+// pure-store epilogues (bias -> bf16, bias + QuickGELU -> bf16) when a launch has more than one round
+// of tiles (ViT-B/32 at B = 435: qkv = 765 tiles, c_fc = 1020 tiles on 256 CUs).
+//
+// Why: in gemm256 every round of tiles ends with all 256 CUs writing their 128 KiB of output at the same
+// moment; the write burst (33.5 MB) drains at ~4.2 TB/s = ~8 us during which no MFMA runs, then the next
+// round pays a cold prologue. vmcnt on gfx9 is ONE in-order counter per wave for loads
+// and stores, so a wave that has issued stores cannot use a counted wait for younger DMA loads without
+// also waiting for the stores' acknowledgements. Hence the split:
+//   * waves with wm == 0 ("loaders") issue every LDS-DMA load (4 instructions per half-tile each) and
+//     own all counted vmcnt waits; they never issue a store;
+//   * waves with wm == 1 ("storers") issue every global store of the epilogue and never wait on vmcnt:
+//     their stores drain while the next tile's K-loop runs.
+// One workgroup per CU walks tiles v = blockIdx.x, +gridDim.x, ... (same XCD-aware tile map as gemm256);
+// the last K-tile of a tile prefetches K-tile 0 of the NEXT tile into the other LDS buffer, so the K-loop
+// of the next tile starts warm right after the epilogue has been issued.
+//
+// Arithmetic is identical to gemm256 (same MFMA order per output element): results are bit-identical.
+// Requires N % 256 == 0, K % 128 == 0 (an even number of K-tiles keeps "K-tile t lives in buffer t & 1"
+// true across tiles), 256 rows x K x 2 B < 2^31 (lane offsets are 32-bit), N <= 8192 (bias row kept in LDS).
+//
+// LDS: [buffer 0 | buffer 1] as in gemm256 (128 KiB) + bias[N] f32. The epilogue stages the tile through
+// buffer 1 (dead after the last K-tile; buffer 0 holds the next tile's K-tile 0 in flight) in two passes
+// of 128 rows x 512 B.
+#pragma once
+#include "gemm256.hpp"
+
+namespace clipmi {
+
+constexpr int G256P_MAX_N = 8192;
+
+template <int EPI>
+__global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
+    static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16, "pure-store epilogues only");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool loader = wm == 0;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int ntn = g.N >> 8, mtiles = (g.M + 255) >> 8, ntiles = ntn * mtiles;
+    const int K = g.K, nk = K >> 6;
+    const int stride = gridDim.x;
+    int v = blockIdx.x;
+
+    // ---- DMA addressing: buffer descriptors (wave-uniform, rebuilt per tile: base = the tile's first A row /
+    // W row) + one 32-bit lane offset per piece + a scalar offset for (K-tile, half, piece). Loader wave wn
+    // moves rows [32 wn, 32 wn + 32) of every half-tile as four 8-row pieces. A rows past M are clamped to
+    // row M-1 (their products are never stored); W needs no clamp (N % 256 == 0).
+    const int srow = lane >> 3, spos = lane & 7;
+    const unsigned lane_chunk = (unsigned)(spos ^ srow) * 16u;          // row & 7 == srow for every piece
+    const unsigned wvoff = (unsigned)(wn * 32 + srow) * (unsigned)K * 2u + lane_chunk;
+    unsigned avoff[2][4];                // [A half][piece], bytes from the tile's first A row
+    auto tile_origin = [&](int vv, int& mm, int& nn) {
+        int bm, bn;
+        gemm_tile_coords(vv, ntiles, mtiles, ntn, 8, 4, bm, bn);
+        mm = bm << 8;
+        nn = bn << 8;
+    };
+    __amdgpu_buffer_rsrc_t rsA, rsW;
+    auto set_tile = [&](int mm, int nn) {
+        const int last = g.M - 1 - mm;                                  // >= 0: last valid local row
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int lr = h * 128 + wn * 32 + i * 8 + srow;
+                lr = lr < last ? lr : last;
+                avoff[h][i] = (unsigned)lr * (unsigned)K * 2u + lane_chunk;
+            }
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)mm * K), 0, 0x7fffffff, 0x00020000);
+        rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(g.W + (size_t)nn * K), 0, 0x7fffffff, 0x00020000);
+    };
+    const int dma_off = wn * 32 * 128;
+    const unsigned piece_stride = 8u * (unsigned)K * 2u, half_stride = 128u * (unsigned)K * 2u;
+    // issue half-tile H (0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi) of K-tile kt of the current descriptors into `buf`
+#define P_ISSUE(H, kt, buf)                                                                                           \
+    do {                                                                                                              \
+        if (loader) {                                                                                                 \
+            __attribute__((address_space(3))) char* d_ =                                                              \
+                (__attribute__((address_space(3))) char*)(smem + (buf) * G256_BUF + (H) * G256_HALF + dma_off);       \
+            const unsigned ko_ = (unsigned)(kt) * 128u;                                                               \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+                if ((H) < 2)                                                                                          \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, d_ + i_ * 1024, 16, avoff[(H) & 1][i_], ko_, 0, 0); \
+                else                                                                                                  \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, d_ + i_ * 1024, 16, wvoff,                          \
+                                                             ko_ + ((H) & 1) * half_stride + i_ * piece_stride, 0, 0); \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+#define P_WAIT(N)                                                                                                     \
+    do {                                                                                                              \
+        if (loader) wait_vmcnt<N>();                                                                                  \
+    } while (0)
+
+    // ---- fragment read offsets (as gemm256)
+    const int sw = fr & 7;
+    const int c0 = ((0 + fg) ^ sw) * 16, c1 = ((4 + fg) ^ sw) * 16;
+    const int offA = (wm * 64 + fr) * 128;
+    const int offB = 2 * G256_HALF + (wn * 32 + fr) * 128;
+
+    f32x4 acc[2][4][2][2];     // [A half][mt][B half][nt]
+    bf16x8 af[4][2];
+    bf16x8 bl[2][2], bh[2][2];
+
+#define P_READ_A(base, half)                                                                         \
+    _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                               \
+        af[t_][0] = *reinterpret_cast<const bf16x8*>((base) + (half) * G256_HALF + offA + t_ * 2048 + c0); \
+        af[t_][1] = *reinterpret_cast<const bf16x8*>((base) + (half) * G256_HALF + offA + t_ * 2048 + c1); \
+    }
+#define P_READ_B(dst, base, half)                                                                    \
+    _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {                                               \
+        dst[t_][0] = *reinterpret_cast<const bf16x8*>((base) + (half) * G256_HALF + offB + t_ * 2048 + c0); \
+        dst[t_][1] = *reinterpret_cast<const bf16x8*>((base) + (half) * G256_HALF + offB + t_ * 2048 + c1); \
+    }
+#define P_MFMA(a, bfr, b)                                                                            \
+    do {                                                                                             \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        __builtin_amdgcn_s_setprio(1);                                                               \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                          \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
+                _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                     \
+                    acc[a][i_][b][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j_][ks_], af[i_][ks_], acc[a][i_][b][j_], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        __builtin_amdgcn_s_barrier();                                                                \
+    } while (0)
+    // one K-tile out of buffer CUR; with PRE, phase p issues half-tile [A-lo, B-lo, B-hi, A-hi][p] of
+    // (current offsets, K-tile KT) into buffer NB. W0/W1/W3: loader vmcnt at P0/P1/P3 (-1 = none).
+#define P_KSTAMP(i)                                                                                  \
+    do {                                                                                             \
+        if (g.dbg & 8) {                                                                             \
+            const unsigned long long c_ = clock64();                                                 \
+            if (t == 5) kst[i] = c_;                                                                 \
+        }                                                                                            \
+    } while (0)
+#define P_KTILE(CUR, PRE, KT, NB, W0, W1, W3)                                                        \
+    do {                                                                                             \
+        P_KSTAMP(0);                                                                                 \
+        P_READ_B(bl, CUR, 0);                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        P_READ_A(CUR, 0);                                                                            \
+        if (PRE) P_ISSUE(0, KT, NB);                                                                 \
+        if ((W0) >= 0) P_WAIT(((W0) < 0 ? 0 : (W0)));                                                \
+        __builtin_amdgcn_s_barrier();                                                                \
+        P_KSTAMP(1);                                                                                \
+        P_MFMA(0, bl, 0);                                                                            \
+        P_KSTAMP(2);                                                                                \
+        P_READ_B(bh, CUR, 1);                                                                        \
+        if (PRE) P_ISSUE(2, KT, NB);                                                                 \
+        if ((W1) >= 0) P_WAIT(((W1) < 0 ? 0 : (W1)));                                                \
+        __builtin_amdgcn_s_barrier();                                                                \
+        P_KSTAMP(3);                                                                                \
+        P_MFMA(0, bh, 1);                                                                            \
+        P_KSTAMP(4);                                                                                \
+        P_READ_A(CUR, 1);                                                                            \
+        if (PRE) P_ISSUE(3, KT, NB);                                                                 \
+        __builtin_amdgcn_s_barrier();                                                                \
+        P_KSTAMP(5);                                                                                \
+        P_MFMA(1, bh, 1);                                                                            \
+        P_KSTAMP(6);                                                                                \
+        if (PRE) P_ISSUE(1, KT, NB);                                                                 \
+        if ((W3) >= 0) P_WAIT(((W3) < 0 ? 0 : (W3)));                                                \
+        __builtin_amdgcn_s_barrier();                                                                \
+        P_KSTAMP(7);                                                                                \
+        P_MFMA(1, bl, 0);                                                                            \
+        P_KSTAMP(8);                                                                                \
+    } while (0)
+
+    // ---- prologue: first tile's K-tile 0 in flight, then the bias row of the whole GEMM into LDS
+    int m0, n0;
+    tile_origin(v, m0, n0);
+    set_tile(m0, n0);
+    P_ISSUE(0, 0, 0);
+    P_ISSUE(2, 0, 0);
+    P_ISSUE(3, 0, 0);
+    P_ISSUE(1, 0, 0);
+    float* sbias = reinterpret_cast<float*>(smem + G256_LDS);
+    for (int i = tid; i < g.N; i += 512) sbias[i] = g.bias ? g.bias[i] : 0.f;
+    // (the compiler's wait for these loads also retires the loaders' DMA above; harmless, once per launch.
+    //  The tile-start barrier below publishes sbias: every wave reaches it after its ds_write + lgkmcnt(0).)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    char* const buf0 = smem;
+    char* const buf1 = smem + G256_BUF;
+    unsigned short* const outp = static_cast<unsigned short*>(g.out);
+
+    // development stamps (dbg & 4): [wave][tile][stamp] 100 MHz wall-clock ticks in LDS, dumped at the end
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + G256_LDS + g.N * 4);
+    int tile_i = 0;
+    unsigned long long kst[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define P_STAMP(k)                                                                                   \
+    do {                                                                                             \
+        if ((g.dbg & 4) && lane == 0 && tile_i < 4) stamps[(wave * 4 + tile_i) * 8 + (k)] = wall_clock64(); \
+    } while (0)
+    for (;;) {
+        P_STAMP(0);
+        // ---- tile start: A-lo(0), B-lo(0) of this tile landed (B-hi(0), A-hi(0) may still be in flight)
+        P_WAIT(8);
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one slot behind
+        const int vn = v + stride;
+        const bool has_next = vn < ntiles;
+        int nm0 = 0, nn0 = 0;
+        if (has_next) tile_origin(vn, nm0, nn0);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        P_STAMP(1);
+        // One K-tile body for every K-tile of every tile (a single copy keeps the 128 accumulators in one
+        // register assignment). K-tile t < nk-1 prefetches K-tile t+1 of this tile; the last one prefetches
+        // K-tile 0 of the NEXT tile (of this tile again when there is none: never read, retired before exit),
+        // and its P3 wait already retires that tile's A-lo(0), B-lo(0).
+        for (int t = 0; t < nk; ++t) {
+            const char* cur = smem + (t & 1) * G256_BUF;
+            const int nb = (t + 1) & 1;
+            int ktn = t + 1;
+            if (t == nk - 1) {
+                ktn = 0;
+                if (has_next) set_tile(nm0, nn0);      // the current offsets are dead: K-tile nk-1 is issued
+            }
+            P_KTILE(cur, 1, ktn, nb, 8, 8, 8);
+        }
+        P_STAMP(2);
+        if ((g.dbg & 8) && tile_i == 1 && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) stamps[128 + wave * 9 + i] = kst[i];     // after the 4 x 8 x 4 tile stamps
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();     // balance the stagger; all reads of buffer 1 are done
+
+        // ---- epilogue through buffer 1: two passes of 128 rows x 512 B
+        f32x4 bz[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                bz[b][nt] = *reinterpret_cast<const f32x4*>(sbias + n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg);
+        // Staging writes go through asm ds_write: a compiler-visible LDS store would be preceded by
+        // vmcnt(0) (the compiler cannot prove it does not overlap the LDS-DMA in flight into buffer 0).
+        const unsigned stage_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)buf1;
+        unsigned stage_addr[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            stage_addr[nt] = stage_base + (wm * 64 + fr) * 512 +
+                             ((((wn * 4 + nt * 2 + (fg >> 1)) ^ fr) << 4) | ((fg & 1) * 8));
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            if (g.dbg & 2) { asm volatile("" :: "v"(acc[a][0][0][0]), "v"(acc[a][3][1][1])); continue; }
+            if (a) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // storers: pass-0 rows are in registers
+                __builtin_amdgcn_s_barrier();
+            }
+            // row = wm*64 + mt*16 + fr (row & 15 == fr); 16-B chunk index = b*16 + ((wn*4 + nt*2 + fg/2) ^ fr):
+            // two lane addresses (nt = 0, 1) + immediates mt*8192 + b*256
+#define P_STAGE(mt, b, nt)                                                                           \
+    do {                                                                                             \
+        f32x4 x_ = acc[a][mt][b][nt] + bz[b][nt];                                                    \
+        if (EPI == EPI_BIAS_QGELU_BF16) x_ = quick_gelu4(x_);                                        \
+        const uint2 pk_ = make_uint2(pack_bf16x2(x_.x, x_.y), pack_bf16x2(x_.z, x_.w));              \
+        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(stage_addr[nt]), "v"(pk_), "n"((mt) * 8192 + (b) * 256) : "memory"); \
+    } while (0)
+#define P_STAGE_MT(mt) P_STAGE(mt, 0, 0); P_STAGE(mt, 0, 1); P_STAGE(mt, 1, 0); P_STAGE(mt, 1, 1)
+            P_STAGE_MT(0); P_STAGE_MT(1); P_STAGE_MT(2); P_STAGE_MT(3);
+#undef P_STAGE_MT
+#undef P_STAGE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            P_STAMP(3 + 2 * a);
+            if (!loader) {
+                // Storer wave wn writes out rows 16 k + (4 wn + 2 s + hi), k < 8, s < 2, hi = lane / 32: two
+                // rows x 512 B per instruction, and row & 15 does not depend on k, so the swizzled read address
+                // is one lane address per s + the immediate 8192 k. asm reads (8 in flight, one wait): a
+                // compiler-visible ds_read here is preceded by vmcnt(0) (LDS-DMA in flight), which on a storer
+                // means "wait for every store issued so far".
+#pragma unroll
+                for (int sidx = 0; sidx < 2; ++sidx) {
+                    const int rlow = wn * 4 + sidx * 2 + (lane >> 5);
+                    const unsigned ra = stage_base + rlow * 512 + (((lane & 31) ^ rlow) << 4);
+                    uint4 x0, x1, x2, x3, x4, x5, x6, x7;
+                    asm volatile(
+                        "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:8192\n\tds_read_b128 %2, %8 offset:16384\n\t"
+                        "ds_read_b128 %3, %8 offset:24576\n\tds_read_b128 %4, %8 offset:32768\n\tds_read_b128 %5, %8 offset:40960\n\t"
+                        "ds_read_b128 %6, %8 offset:49152\n\tds_read_b128 %7, %8 offset:57344\n\ts_waitcnt lgkmcnt(0)"
+                        : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7)
+                        : "v"(ra)
+                        : "memory");
+                    const uint4 xs[8] = {x0, x1, x2, x3, x4, x5, x6, x7};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int m = m0 + a * 128 + k * 16 + rlow;
+                        if (m < g.M && !(g.dbg & 1))
+                            *reinterpret_cast<uint4*>(outp + (size_t)m * g.N + n0 + (lane & 31) * 8) = xs[k];
+                    }
+                }
+            }
+            P_STAMP(4 + 2 * a);
+        }
+        P_STAMP(7);
+        ++tile_i;
+        if (!has_next) break;
+        v = vn;
+        m0 = nm0;
+        n0 = nn0;
+        // buffer 1 is refilled (K-tile 1 of the next tile) only after the tile-start barrier, which the
+        // storers reach after their last staging read has returned
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    P_WAIT(0);                                         // the last tile's idle prefetch must not outlive the LDS
+    if ((g.dbg & 12) && g.pos && (blockIdx.x == 0 || blockIdx.x == 100)) {
+        __syncthreads();
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.pos)) + (blockIdx.x ? 256 : 0);
+        if (tid < 256) dst[tid] = stamps[tid];
+    }
+#undef P_STAMP
+#undef P_ISSUE
+#undef P_WAIT
+#undef P_READ_A
+#undef P_READ_B
+#undef P_MFMA
+#undef P_KTILE
+}
+
+}  // namespace clipmi

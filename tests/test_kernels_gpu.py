@@ -204,3 +204,62 @@ def test_gemm256_layout_asymmetric_and_race_screen(clipmi, gpu):
         clipmi._lib.check(L.clipmi_dbg_gemm_bf16(a.data_ptr(), w.data_ptr(), None, out.data_ptr(), M, N, K, 3 | (2 << 8), None), "gemm256")
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1, 256, 128), (300, 512, 256), (6400, 2304, 768),
+                                   (21750, 2304, 768), (21750, 3072, 768), (70000, 256, 128), (33000, 1024, 1024),
+                                   (25601, 3072, 768)])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_gemm256p_matches_gemm256(clipmi, gpu, M, N, K, epi):
+    """The persistent, role-split kernel (algo 3: loader waves / storer waves, tiles walked by 256
+    workgroups) performs the same MFMA sequence per output element as gemm256: bit-identical output,
+    including M-edge tiles and workgroups that walk 1, 2, 3 or 4 tiles; twice for determinism."""
+    L = clipmi._lib.lib()
+    g = torch.Generator(device="cpu"); g.manual_seed(M * 3 + N + K + epi)
+    a = _bf16(torch.randn(M, K, generator=g)).to(gpu)
+    w = _bf16(torch.randn(N, K, generator=g) * K ** -0.5).to(gpu)
+    bias = torch.randn(N, generator=g).to(gpu)
+    ref = a.float() @ w.float().t() + bias
+    if epi == 1:
+        ref = _qgelu(ref)
+    outs = []
+    for algo in (2, 3, 3):
+        out = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device=gpu)   # +1 guard row
+        rc = L.clipmi_dbg_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, epi | (algo << 8), None)
+        clipmi._lib.check(rc, "gemm256p")
+        torch.cuda.synchronize()
+        assert torch.isnan(out[M]).all(), "wrote past row M"
+        outs.append(out[:M])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    scale = ref.abs().max().item()
+    err = (outs[1].float() - ref).abs().max().item()
+    assert err <= 2e-4 * scale + (2.0 ** -8) * scale, f"M={M} N={N} K={K} epi={epi}: err {err}"
+
+
+def test_gemm256p_race_screen(clipmi, gpu):
+    """Exact small-integer data (sums exact in f32 and in bf16: |c| <= 9*128 needs 11 bits... kept
+    <= 256 by construction): a stale, early or torn LDS read anywhere in the tile-to-tile pipeline
+    (next tile's K-tile 0 prefetched under the epilogue, staging through buffer 1) shows as a wrong
+    integer. 20 launches, 3 tiles per workgroup, many K-tiles."""
+    L = clipmi._lib.lib()
+    M, N, K = 12288, 4096, 1024          # 48 x 16 = 768 tiles
+    g = torch.Generator(device="cpu"); g.manual_seed(9)
+    a = torch.randint(-1, 2, (M, K), generator=g).float()
+    w = (torch.rand(N, K, generator=g) < 0.05).float() * torch.randint(-1, 2, (N, K), generator=g).float()
+    ref = a.to(gpu) @ w.to(gpu).t()
+    assert ref.abs().max().item() <= 256          # exactly representable in bf16
+    a, w = _bf16(a).to(gpu), _bf16(w).to(gpu)
+    ref = ref.to(torch.bfloat16)
+    for _ in range(20):
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=gpu)
+        clipmi._lib.check(L.clipmi_dbg_gemm_bf16(a.data_ptr(), w.data_ptr(), None, out.data_ptr(), M, N, K, 0 | (3 << 8), None), "gemm256p")
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+
+
+def test_gemm256p_rejects(clipmi, gpu):
+    L = clipmi._lib.lib()
+    x = torch.zeros(1 << 20, dtype=torch.bfloat16, device=gpu)
+    # K = 192: three K-tiles (odd) -> refused; f32 epilogues -> refused
+    assert L.clipmi_dbg_gemm_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 256, 256, 192, 0 | (3 << 8), None) == 1
+    assert L.clipmi_dbg_gemm_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 256, 256, 128, 3 | (3 << 8), None) == 1
