@@ -51,6 +51,12 @@ static int launch_epi256(const GemmArgs& g, hipStream_t st) {
 }
 
 // persistent, role-split 256x256 kernel (gemm256p.hpp): pure-store epilogues only
+static int persist_mode() {
+    // development switch for A/B runs on one box: CLIPMI_GEMM_PERSIST=0 keeps every GEMM on gemm256
+    static const int mode = [] { const char* e = getenv("CLIPMI_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
+    return mode;
+}
+
 template <int EPI>
 static int launch_epi256p(const GemmArgs& g, hipStream_t st) {
     const int tiles = (g.N / 256) * ((g.M + 255) / 256);
@@ -97,7 +103,7 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st) {
         use256 = tiles * 100 >= rounds * NUM_CU * pct;
         // more than one round of tiles: the persistent kernel overlaps each tile's write-out with the next
         // tile's K-loop
-        use256p = use256 && ok256p && tiles > NUM_CU;
+        use256p = use256 && ok256p && tiles > NUM_CU && persist_mode() != 0;
     }
     if (!use256) return launch_gemm(g, epi, st);
     if (g.M < 1 || !g.A || !g.W || !g.out) return set_err(CLIPMI_EINVAL, "gemm: bad arguments");

@@ -25,6 +25,10 @@
 #pragma once
 #include "gemm256.hpp"
 
+#ifndef CLIPMI_GEMM_STAMPS
+#define CLIPMI_GEMM_STAMPS 0      // 1: in-kernel time stamps (tools/gp_stamps.py); costs a few % of the K-loop
+#endif
+
 namespace clipmi {
 
 constexpr int G256P_MAX_N = 8192;
@@ -133,7 +137,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     // (current offsets, K-tile KT) into buffer NB. W0/W1/W3: loader vmcnt at P0/P1/P3 (-1 = none).
 #define P_KSTAMP(i)                                                                                  \
     do {                                                                                             \
-        if (g.dbg & 8) {                                                                             \
+        if (CLIPMI_GEMM_STAMPS && (g.dbg & 8)) {                                                     \
             const unsigned long long c_ = clock64();                                                 \
             if (t == 5) kst[i] = c_;                                                                 \
         }                                                                                            \
@@ -195,7 +199,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     unsigned long long kst[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define P_STAMP(k)                                                                                   \
     do {                                                                                             \
-        if ((g.dbg & 4) && lane == 0 && tile_i < 4) stamps[(wave * 4 + tile_i) * 8 + (k)] = wall_clock64(); \
+        if (CLIPMI_GEMM_STAMPS && (g.dbg & 4) && lane == 0 && tile_i < 4) stamps[(wave * 4 + tile_i) * 8 + (k)] = wall_clock64(); \
     } while (0)
     for (;;) {
         P_STAMP(0);
@@ -232,7 +236,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
             P_KTILE(cur, 1, ktn, nb, 8, 8, 8);
         }
         P_STAMP(2);
-        if ((g.dbg & 8) && tile_i == 1 && lane == 0) {
+        if (CLIPMI_GEMM_STAMPS && (g.dbg & 8) && tile_i == 1 && lane == 0) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) stamps[128 + wave * 9 + i] = kst[i];     // after the 4 x 8 x 4 tile stamps
         }
@@ -316,7 +320,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     P_WAIT(0);                                         // the last tile's idle prefetch must not outlive the LDS
-    if ((g.dbg & 12) && g.pos && (blockIdx.x == 0 || blockIdx.x == 100)) {
+    if (CLIPMI_GEMM_STAMPS && (g.dbg & 12) && g.pos && (blockIdx.x == 0 || blockIdx.x == 100)) {
         __syncthreads();
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.pos)) + (blockIdx.x ? 256 : 0);
         if (tid < 256) dst[tid] = stamps[tid];

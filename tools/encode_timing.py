@@ -6,6 +6,7 @@ import clipmi
 dev = torch.device("cuda:0")
 sd = clipmi.weights.random_state_dict("ViT-B/32", seed=0)
 model = clipmi.CLIP(sd, device=dev)
+model.max_batch = 8192
 bs = [int(x) for x in sys.argv[1:]] or [64, 128, 256, 512, 1024]
 g = torch.Generator(device=dev); g.manual_seed(0)
 for B in bs:

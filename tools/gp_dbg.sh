@@ -1,3 +1,4 @@
 #!/bin/bash
-# development aid: per-K-tile cost of both 256x256 kernels (K = 768 vs 3072, same M, N)
-for d in 0 2; do echo "== CLIPMI_GEMM_DBG=$d"; CLIPMI_GEMM_DBG=$d timeout -k 10 200 python tools/gemm_persist.py 21750,3072,768,1 21750,3072,3072,1 21750,3072,1536,1 || exit 1; done
+# development aid: whole encode step with the persistent GEMM off (0) / loader-only DMA (1) / shared DMA (2), twice
+timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "gemm256p" || exit 1
+for rep in 1 2; do for d in 0 1 2; do echo "== CLIPMI_GEMM_PERSIST=$d"; CLIPMI_GEMM_PERSIST=$d timeout -k 10 200 python tools/encode_timing.py 435 870 || exit 1; done; done
