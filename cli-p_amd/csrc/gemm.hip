@@ -86,10 +86,11 @@ static int launch_epi256p(const GemmArgs& g, hipStream_t st) {
 int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st) {
     const bool ok256 = g.N % 256 == 0 && g.K % 64 == 0 && g.K >= 128;
     if (algo == 2 && !ok256) return set_err(CLIPMI_EINVAL, "gemm256: N=%d K=%d (need N %% 256 == 0, K %% 64 == 0, K >= 128)", g.N, g.K);
-    const bool ok256p = ok256 && g.K % 128 == 0 && g.N <= G256P_MAX_N && (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_QGELU_BF16) &&
+    const bool ok256p = ok256 && g.K % 128 == 0 && g.N <= G256P_MAX_N &&
+                        (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_QGELU_BF16 || epi == EPI_BIAS_RESID_F32) &&
                         g.K <= (1 << 20);
     if (algo == 3 && !ok256p)
-        return set_err(CLIPMI_EINVAL, "gemm256p: M=%d N=%d K=%d epi=%d (need N %% 256 == 0, K %% 128 == 0, bf16-store epilogue)", g.M, g.N, g.K, epi);
+        return set_err(CLIPMI_EINVAL, "gemm256p: M=%d N=%d K=%d epi=%d (need N %% 256 == 0, K %% 128 == 0, epilogue 0, 1 or 2)", g.M, g.N, g.K, epi);
     // by shape: the 256x256 pipeline wins when its tiles fill the 256 CUs in whole rounds (r01 on MI355X,
     // M=25600: N=2304/3072 -> 781/841 TF vs 702/685; N=768 -> 300 tiles = 1.17 rounds, 408/769 vs 521/904)
     bool use256 = algo == 2 || algo == 3;
@@ -109,6 +110,7 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st) {
     if (g.M < 1 || !g.A || !g.W || !g.out) return set_err(CLIPMI_EINVAL, "gemm: bad arguments");
     if (use256p) {
         if (epi == EPI_BIAS_BF16) return launch_epi256p<EPI_BIAS_BF16>(g, st);
+        if (epi == EPI_BIAS_RESID_F32) return launch_epi256p<EPI_BIAS_RESID_F32>(g, st);
         return launch_epi256p<EPI_BIAS_QGELU_BF16>(g, st);
     }
     switch (epi) {

@@ -35,7 +35,7 @@ constexpr int G256P_MAX_N = 8192;
 
 template <int EPI>
 __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
-    static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16, "pure-store epilogues only");
+    static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_RESID_F32, "store-only epilogues");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -99,6 +99,30 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     do {                                                                                                              \
         if (loader) wait_vmcnt<N>();                                                                                  \
     } while (0)
+    // EPI_BIAS_RESID_F32: the tile's residual rows (f32 out[m0 + r][n0 .. n0+255], 1 KiB each) come in by
+    // LDS-DMA too: loader wn moves rows rbase + 4 wn + i, i < 4, into 16-KiB region H of buffer 0, lane-linear
+    // (rows past M are clamped to row M-1: never stored).
+    __amdgpu_buffer_rsrc_t rsO;
+    int last_lr = 0;
+    auto set_out = [&](int mm, int nn) {
+        if constexpr (EPI == EPI_BIAS_RESID_F32) {
+            rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<float*>(g.out) + (size_t)mm * g.N + nn), 0, 0x7fffffff, 0x00020000);
+            last_lr = g.M - 1 - mm;
+        }
+    };
+#define P_ISSUE_RESID(H, rbase)                                                                                       \
+    do {                                                                                                              \
+        if (loader) {                                                                                                 \
+            __attribute__((address_space(3))) char* d_ =                                                              \
+                (__attribute__((address_space(3))) char*)(smem + (H) * G256_HALF + wn * 4096);                        \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+                int lr_ = (rbase) + wn * 4 + i_;                                                                      \
+                lr_ = lr_ < last_lr ? lr_ : last_lr;                                                                  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, d_ + i_ * 1024, 16, (unsigned)lane * 16u,               \
+                                                         (unsigned)lr_ * (unsigned)g.N * 4u, 0, 0);                   \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
 
     // ---- fragment read offsets (as gemm256)
     const int sw = fr & 7;
@@ -142,32 +166,41 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
             if (t == 5) kst[i] = c_;                                                                 \
         }                                                                                            \
     } while (0)
+    // the DMA slot of a phase: half-tile H of (K-tile KT -> buffer NB), or - residual epilogue, last K-tile
+    // of a tile - the residual rows that belong in region H of buffer 0 (sub-pass 0 = rows 0..31 of the tile
+    // -> regions A-lo, B-lo; sub-pass 1 = rows 64..95 -> regions A-hi, B-hi; issue order = region order of
+    // the K-loop, so the write-after-read distances are the K-loop's)
+#define P_SLOT(H, KT, NB)                                                                            \
+    do {                                                                                             \
+        if (EPI == EPI_BIAS_RESID_F32 && last_kt) P_ISSUE_RESID(H, ((H) & 1) * 64 + ((H) >> 1) * 16); \
+        else P_ISSUE(H, KT, NB);                                                                     \
+    } while (0)
 #define P_KTILE(CUR, PRE, KT, NB, W0, W1, W3)                                                        \
     do {                                                                                             \
         P_KSTAMP(0);                                                                                 \
         P_READ_B(bl, CUR, 0);                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                           \
         P_READ_A(CUR, 0);                                                                            \
-        if (PRE) P_ISSUE(0, KT, NB);                                                                 \
+        if (PRE) P_SLOT(0, KT, NB);                                                                 \
         if ((W0) >= 0) P_WAIT(((W0) < 0 ? 0 : (W0)));                                                \
         __builtin_amdgcn_s_barrier();                                                                \
         P_KSTAMP(1);                                                                                \
         P_MFMA(0, bl, 0);                                                                            \
         P_KSTAMP(2);                                                                                \
         P_READ_B(bh, CUR, 1);                                                                        \
-        if (PRE) P_ISSUE(2, KT, NB);                                                                 \
+        if (PRE) P_SLOT(2, KT, NB);                                                                 \
         if ((W1) >= 0) P_WAIT(((W1) < 0 ? 0 : (W1)));                                                \
         __builtin_amdgcn_s_barrier();                                                                \
         P_KSTAMP(3);                                                                                \
         P_MFMA(0, bh, 1);                                                                            \
         P_KSTAMP(4);                                                                                \
         P_READ_A(CUR, 1);                                                                            \
-        if (PRE) P_ISSUE(3, KT, NB);                                                                 \
+        if (PRE) P_SLOT(3, KT, NB);                                                                 \
         __builtin_amdgcn_s_barrier();                                                                \
         P_KSTAMP(5);                                                                                \
         P_MFMA(1, bh, 1);                                                                            \
         P_KSTAMP(6);                                                                                \
-        if (PRE) P_ISSUE(1, KT, NB);                                                                 \
+        if (PRE) P_SLOT(1, KT, NB);                                                                 \
         if ((W3) >= 0) P_WAIT(((W3) < 0 ? 0 : (W3)));                                                \
         __builtin_amdgcn_s_barrier();                                                                \
         P_KSTAMP(7);                                                                                \
@@ -179,6 +212,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     int m0, n0;
     tile_origin(v, m0, n0);
     set_tile(m0, n0);
+    set_out(m0, n0);
     P_ISSUE(0, 0, 0);
     P_ISSUE(2, 0, 0);
     P_ISSUE(3, 0, 0);
@@ -229,7 +263,8 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
             const char* cur = smem + (t & 1) * G256_BUF;
             const int nb = (t + 1) & 1;
             int ktn = t + 1;
-            if (t == nk - 1) {
+            const bool last_kt = t == nk - 1;
+            if (last_kt) {
                 ktn = 0;
                 if (has_next) set_tile(nm0, nn0);      // the current offsets are dead: K-tile nk-1 is issued
             }
@@ -249,65 +284,148 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
                 bz[b][nt] = *reinterpret_cast<const f32x4*>(sbias + n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg);
-        // Staging writes go through asm ds_write: a compiler-visible LDS store would be preceded by
-        // vmcnt(0) (the compiler cannot prove it does not overlap the LDS-DMA in flight into buffer 0).
-        const unsigned stage_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)buf1;
-        unsigned stage_addr[2];
+        if constexpr (EPI == EPI_BIAS_RESID_F32) {
+            // Residual stream update out[m][n] = (acc + bias) + out[m][n] (the add order of gemm256: bit-identical).
+            // acc + bias goes through buffer 1 in four passes of 64 rows x 1 KiB (pass j = A half j/2, mt in
+            // {2(j&1), 2(j&1)+1}; local row = wm*32 + (mt&1)*16 + fr; 16-B chunk ^ (row & 15)); the residual rows
+            // arrive by LDS-DMA in buffer 0, eight sub-passes s of 32 rows (tile rows (s>>2)*128 + (s&1)*64 +
+            // ((s>>1)&1)*32 ..+31), alternating between regions {A-lo, B-lo} (s even) and {A-hi, B-hi} (s odd):
+            // sub-passes 0, 1 were issued under the last K-tile, s+2 is issued when s has been written out, and
+            // the region pair freed by s = 6 / 7 receives the next tile's K-tile 0 in the K-loop's own order
+            // (A-lo, B-lo, then B-hi, A-hi). Loaders: DMA + counted waits only; storers: LDS reads, the add and
+            // the global stores (fire-and-forget: they drain under the next tile's K-loop).
+            const unsigned stage_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)buf1;
+            const unsigned resid_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+            unsigned stage_addr[2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-            stage_addr[nt] = stage_base + (wm * 64 + fr) * 512 +
-                             ((((wn * 4 + nt * 2 + (fg >> 1)) ^ fr) << 4) | ((fg & 1) * 8));
+            for (int nt = 0; nt < 2; ++nt)
+                stage_addr[nt] = stage_base + (wm * 32 + fr) * 1024 + (wn >> 1) * 256 +
+                                 (((((wn & 1) * 8 + nt * 4 + fg) ^ fr)) << 4);
+            float* const outf = static_cast<float*>(g.out);
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            if (g.dbg & 2) { asm volatile("" :: "v"(acc[a][0][0][0]), "v"(acc[a][3][1][1])); continue; }
-            if (a) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // storers: pass-0 rows are in registers
-                __builtin_amdgcn_s_barrier();
-            }
-            // row = wm*64 + mt*16 + fr (row & 15 == fr); 16-B chunk index = b*16 + ((wn*4 + nt*2 + fg/2) ^ fr):
-            // two lane addresses (nt = 0, 1) + immediates mt*8192 + b*256
-#define P_STAGE(mt, b, nt)                                                                           \
+            for (int sp = 0; sp < 8; ++sp) {
+                const int j = sp >> 1, h = sp & 1;
+                if (h == 0) {
+#define P_STAGE32(mt, b, nt)                                                                         \
     do {                                                                                             \
-        f32x4 x_ = acc[a][mt][b][nt] + bz[b][nt];                                                    \
-        if (EPI == EPI_BIAS_QGELU_BF16) x_ = quick_gelu4(x_);                                        \
-        const uint2 pk_ = make_uint2(pack_bf16x2(x_.x, x_.y), pack_bf16x2(x_.z, x_.w));              \
-        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(stage_addr[nt]), "v"(pk_), "n"((mt) * 8192 + (b) * 256) : "memory"); \
+        const f32x4 x_ = acc[j >> 1][(j & 1) * 2 + (mt)][b][nt] + bz[b][nt];                         \
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(stage_addr[nt]), "v"(x_), "n"((mt) * 16384 + (b) * 512) : "memory"); \
     } while (0)
-#define P_STAGE_MT(mt) P_STAGE(mt, 0, 0); P_STAGE(mt, 0, 1); P_STAGE(mt, 1, 0); P_STAGE(mt, 1, 1)
-            P_STAGE_MT(0); P_STAGE_MT(1); P_STAGE_MT(2); P_STAGE_MT(3);
-#undef P_STAGE_MT
-#undef P_STAGE
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            P_STAMP(3 + 2 * a);
-            if (!loader) {
-                // Storer wave wn writes out rows 16 k + (4 wn + 2 s + hi), k < 8, s < 2, hi = lane / 32: two
-                // rows x 512 B per instruction, and row & 15 does not depend on k, so the swizzled read address
-                // is one lane address per s + the immediate 8192 k. asm reads (8 in flight, one wait): a
-                // compiler-visible ds_read here is preceded by vmcnt(0) (LDS-DMA in flight), which on a storer
-                // means "wait for every store issued so far".
+#define P_STAGE32_MT(mt) P_STAGE32(mt, 0, 0); P_STAGE32(mt, 0, 1); P_STAGE32(mt, 1, 0); P_STAGE32(mt, 1, 1)
+                    P_STAGE32_MT(0); P_STAGE32_MT(1);
+#undef P_STAGE32_MT
+#undef P_STAGE32
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                P_WAIT(8);                                 // residual sub-pass sp has landed (sp+1 / next K-tile 0 may be in flight)
+                __builtin_amdgcn_s_barrier();
+                if (!loader) {
+                    // storer wn: rows r = 8 wn + i of the sub-pass; acc image row = 32 h + r, residual row r lives in
+                    // region (r < 16 ? h : 2 + h) at (r & 15) KiB, lane-linear
+                    const int rl0 = h * 32 + wn * 8;
+                    const unsigned ra = resid_base + ((wn < 2 ? h : 2 + h) * G256_HALF) + ((wn & 1) * 8) * 1024 + lane * 16;
+                    unsigned aa[8];
 #pragma unroll
-                for (int sidx = 0; sidx < 2; ++sidx) {
-                    const int rlow = wn * 4 + sidx * 2 + (lane >> 5);
-                    const unsigned ra = stage_base + rlow * 512 + (((lane & 31) ^ rlow) << 4);
-                    uint4 x0, x1, x2, x3, x4, x5, x6, x7;
+                    for (int i = 0; i < 8; ++i)
+                        aa[i] = stage_base + (rl0 + i) * 1024 + ((lane ^ ((wn & 1) * 8 + i)) << 4);
+                    f32x4 x0, x1, x2, x3, x4, x5, x6, x7, r0, r1, r2, r3, r4, r5, r6, r7;
+                    // one statement: 16 reads in flight and their wait (asm destinations are unprotected until it)
                     asm volatile(
-                        "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:8192\n\tds_read_b128 %2, %8 offset:16384\n\t"
-                        "ds_read_b128 %3, %8 offset:24576\n\tds_read_b128 %4, %8 offset:32768\n\tds_read_b128 %5, %8 offset:40960\n\t"
-                        "ds_read_b128 %6, %8 offset:49152\n\tds_read_b128 %7, %8 offset:57344\n\ts_waitcnt lgkmcnt(0)"
-                        : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7)
-                        : "v"(ra)
+                        "ds_read_b128 %0, %16\n\tds_read_b128 %1, %17\n\tds_read_b128 %2, %18\n\tds_read_b128 %3, %19\n\t"
+                        "ds_read_b128 %4, %20\n\tds_read_b128 %5, %21\n\tds_read_b128 %6, %22\n\tds_read_b128 %7, %23\n\t"
+                        "ds_read_b128 %8, %24\n\tds_read_b128 %9, %24 offset:1024\n\tds_read_b128 %10, %24 offset:2048\n\t"
+                        "ds_read_b128 %11, %24 offset:3072\n\tds_read_b128 %12, %24 offset:4096\n\tds_read_b128 %13, %24 offset:5120\n\t"
+                        "ds_read_b128 %14, %24 offset:6144\n\tds_read_b128 %15, %24 offset:7168\n\ts_waitcnt lgkmcnt(0)"
+                        : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7),
+                          "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+                        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(aa[4]), "v"(aa[5]), "v"(aa[6]), "v"(aa[7]), "v"(ra)
                         : "memory");
-                    const uint4 xs[8] = {x0, x1, x2, x3, x4, x5, x6, x7};
+                    const f32x4 xs[8] = {x0, x1, x2, x3, x4, x5, x6, x7};
+                    const f32x4 rs[8] = {r0, r1, r2, r3, r4, r5, r6, r7};
+                    const int lr0 = (sp >> 2) * 128 + (sp & 1) * 64 + ((sp >> 1) & 1) * 32 + wn * 8;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int m = m0 + a * 128 + k * 16 + rlow;
+                    for (int i = 0; i < 8; ++i) {
+                        const int m = m0 + lr0 + i;
                         if (m < g.M && !(g.dbg & 1))
-                            *reinterpret_cast<uint4*>(outp + (size_t)m * g.N + n0 + (lane & 31) * 8) = xs[k];
+                            *reinterpret_cast<f32x4*>(outf + (size_t)m * g.N + n0 + lane * 4) = xs[i] + rs[i];
                     }
                 }
+                __builtin_amdgcn_s_barrier();              // sub-pass sp is out of LDS: its regions may be refilled
+                if (sp < 6) {
+                    const int s2 = sp + 2;
+                    const int rb = (s2 >> 2) * 128 + (s2 & 1) * 64 + ((s2 >> 1) & 1) * 32;
+                    P_ISSUE_RESID(h, rb);
+                    P_ISSUE_RESID(2 + h, rb + 16);
+                } else if (sp == 6) {
+                    P_ISSUE(0, 0, 0);                      // next tile's K-tile 0 (this tile's again when there is none)
+                    P_ISSUE(2, 0, 0);
+                } else {
+                    P_ISSUE(3, 0, 0);
+                    P_ISSUE(1, 0, 0);
+                }
             }
-            P_STAMP(4 + 2 * a);
+        } else {
+            // Staging writes go through asm ds_write: a compiler-visible LDS store would be preceded by
+            // vmcnt(0) (the compiler cannot prove it does not overlap the LDS-DMA in flight into buffer 0).
+            const unsigned stage_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)buf1;
+            unsigned stage_addr[2];
+    #pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                stage_addr[nt] = stage_base + (wm * 64 + fr) * 512 +
+                                 ((((wn * 4 + nt * 2 + (fg >> 1)) ^ fr) << 4) | ((fg & 1) * 8));
+    #pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (g.dbg & 2) { asm volatile("" :: "v"(acc[a][0][0][0]), "v"(acc[a][3][1][1])); continue; }
+                if (a) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // storers: pass-0 rows are in registers
+                    __builtin_amdgcn_s_barrier();
+                }
+                // row = wm*64 + mt*16 + fr (row & 15 == fr); 16-B chunk index = b*16 + ((wn*4 + nt*2 + fg/2) ^ fr):
+                // two lane addresses (nt = 0, 1) + immediates mt*8192 + b*256
+    #define P_STAGE(mt, b, nt)                                                                           \
+        do {                                                                                             \
+            f32x4 x_ = acc[a][mt][b][nt] + bz[b][nt];                                                    \
+            if (EPI == EPI_BIAS_QGELU_BF16) x_ = quick_gelu4(x_);                                        \
+            const uint2 pk_ = make_uint2(pack_bf16x2(x_.x, x_.y), pack_bf16x2(x_.z, x_.w));              \
+            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(stage_addr[nt]), "v"(pk_), "n"((mt) * 8192 + (b) * 256) : "memory"); \
+        } while (0)
+    #define P_STAGE_MT(mt) P_STAGE(mt, 0, 0); P_STAGE(mt, 0, 1); P_STAGE(mt, 1, 0); P_STAGE(mt, 1, 1)
+                P_STAGE_MT(0); P_STAGE_MT(1); P_STAGE_MT(2); P_STAGE_MT(3);
+    #undef P_STAGE_MT
+    #undef P_STAGE
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                P_STAMP(3 + 2 * a);
+                if (!loader) {
+                    // Storer wave wn writes out rows 16 k + (4 wn + 2 s + hi), k < 8, s < 2, hi = lane / 32: two
+                    // rows x 512 B per instruction, and row & 15 does not depend on k, so the swizzled read address
+                    // is one lane address per s + the immediate 8192 k. asm reads (8 in flight, one wait): a
+                    // compiler-visible ds_read here is preceded by vmcnt(0) (LDS-DMA in flight), which on a storer
+                    // means "wait for every store issued so far".
+    #pragma unroll
+                    for (int sidx = 0; sidx < 2; ++sidx) {
+                        const int rlow = wn * 4 + sidx * 2 + (lane >> 5);
+                        const unsigned ra = stage_base + rlow * 512 + (((lane & 31) ^ rlow) << 4);
+                        uint4 x0, x1, x2, x3, x4, x5, x6, x7;
+                        asm volatile(
+                            "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:8192\n\tds_read_b128 %2, %8 offset:16384\n\t"
+                            "ds_read_b128 %3, %8 offset:24576\n\tds_read_b128 %4, %8 offset:32768\n\tds_read_b128 %5, %8 offset:40960\n\t"
+                            "ds_read_b128 %6, %8 offset:49152\n\tds_read_b128 %7, %8 offset:57344\n\ts_waitcnt lgkmcnt(0)"
+                            : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7)
+                            : "v"(ra)
+                            : "memory");
+                        const uint4 xs[8] = {x0, x1, x2, x3, x4, x5, x6, x7};
+    #pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int m = m0 + a * 128 + k * 16 + rlow;
+                            if (m < g.M && !(g.dbg & 1))
+                                *reinterpret_cast<uint4*>(outp + (size_t)m * g.N + n0 + (lane & 31) * 8) = xs[k];
+                        }
+                    }
+                }
+                P_STAMP(4 + 2 * a);
+            }
+
         }
         P_STAMP(7);
         ++tile_i;
@@ -315,6 +433,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
         v = vn;
         m0 = nm0;
         n0 = nn0;
+        set_out(m0, n0);
         // buffer 1 is refilled (K-tile 1 of the next tile) only after the tile-start barrier, which the
         // storers reach after their last staging read has returned
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -209,22 +209,31 @@ def test_gemm256_layout_asymmetric_and_race_screen(clipmi, gpu):
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1, 256, 128), (300, 512, 256), (6400, 2304, 768),
                                    (21750, 2304, 768), (21750, 3072, 768), (70000, 256, 128), (33000, 1024, 1024),
                                    (25601, 3072, 768)])
-@pytest.mark.parametrize("epi", [0, 1])
+@pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm256p_matches_gemm256(clipmi, gpu, M, N, K, epi):
     """The persistent, role-split kernel (algo 3: loader waves / storer waves, tiles walked by 256
     workgroups) performs the same MFMA sequence per output element as gemm256: bit-identical output,
-    including M-edge tiles and workgroups that walk 1, 2, 3 or 4 tiles; twice for determinism."""
+    including M-edge tiles and workgroups that walk 1, 2, 3 or 4 tiles; twice for determinism.
+    epi 2 (residual stream, out += acc + bias) goes out as no-return f32 atomic adds, one per element:
+    the same single IEEE add as gemm256's read-modify-write."""
     L = clipmi._lib.lib()
     g = torch.Generator(device="cpu"); g.manual_seed(M * 3 + N + K + epi)
     a = _bf16(torch.randn(M, K, generator=g)).to(gpu)
     w = _bf16(torch.randn(N, K, generator=g) * K ** -0.5).to(gpu)
     bias = torch.randn(N, generator=g).to(gpu)
     ref = a.float() @ w.float().t() + bias
+    res = torch.randn(M, N, generator=g).to(gpu) if epi == 2 else None
     if epi == 1:
         ref = _qgelu(ref)
+    if epi == 2:
+        ref = ref + res
     outs = []
     for algo in (2, 3, 3):
-        out = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device=gpu)   # +1 guard row
+        if epi == 2:
+            out = torch.full((M + 1, N), float("nan"), dtype=torch.float32, device=gpu)
+            out[:M] = res
+        else:
+            out = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device=gpu)   # +1 guard row
         rc = L.clipmi_dbg_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, epi | (algo << 8), None)
         clipmi._lib.check(rc, "gemm256p")
         torch.cuda.synchronize()
@@ -233,7 +242,7 @@ def test_gemm256p_matches_gemm256(clipmi, gpu, M, N, K, epi):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
     scale = ref.abs().max().item()
     err = (outs[1].float() - ref).abs().max().item()
-    assert err <= 2e-4 * scale + (2.0 ** -8) * scale, f"M={M} N={N} K={K} epi={epi}: err {err}"
+    assert err <= 2e-4 * scale + (2.0 ** -8) * scale * (epi != 2), f"M={M} N={N} K={K} epi={epi}: err {err}"
 
 
 def test_gemm256p_race_screen(clipmi, gpu):
