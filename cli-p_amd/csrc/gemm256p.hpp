@@ -286,29 +286,35 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                 bz[b][nt] = *reinterpret_cast<const f32x4*>(sbias + n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg);
         if constexpr (EPI == EPI_BIAS_RESID_F32) {
             // Residual stream update out[m][n] = (acc + bias) + out[m][n] (the add order of gemm256: bit-identical).
-            // acc + bias goes through buffer 1 in four passes of 64 rows x 1 KiB (pass j = A half j/2, mt in
-            // {2(j&1), 2(j&1)+1}; local row = wm*32 + (mt&1)*16 + fr; 16-B chunk ^ (row & 15)); the residual rows
-            // arrive by LDS-DMA in buffer 0, eight sub-passes s of 32 rows (tile rows (s>>2)*128 + (s&1)*64 +
-            // ((s>>1)&1)*32 ..+31), alternating between regions {A-lo, B-lo} (s even) and {A-hi, B-hi} (s odd):
-            // sub-passes 0, 1 were issued under the last K-tile, s+2 is issued when s has been written out, and
-            // the region pair freed by s = 6 / 7 receives the next tile's K-tile 0 in the K-loop's own order
-            // (A-lo, B-lo, then B-hi, A-hi). Loaders: DMA + counted waits only; storers: LDS reads, the add and
-            // the global stores (fire-and-forget: they drain under the next tile's K-loop).
-            const unsigned stage_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)buf1;
+            // Eight sub-passes sp of 32 tile rows ((sp>>2)*128 + (sp&1)*64 + ((sp>>1)&1)*32 ..+31: the rows the
+            // wave group wm = sp&1 holds for A half sp>>2, mt in {2((sp>>1)&1), +1}):
+            //   * that group drops acc + bias into a 32-KiB image at [96K,128K) (row = (mt&1)*16 + fr, 16-B chunk ^
+            //     (row & 15));
+            //   * the residual rows arrive by LDS-DMA, lane-linear, in one of THREE 32-KiB buffers used in turn
+            //     X = regions {A-lo, B-lo}, Y = {A-hi, B-hi}, Z = [64K,96K): sub-passes 0, 1 were issued under the
+            //     last K-tile, 2 at the start of the epilogue, sp+3 when sp has been written out - three sub-passes
+            //     in flight cover the HBM round trip (two did not: 13 us per tile, r01 stamps);
+            //   * X and Y, freed by sp = 6 and 7, receive the next tile's K-tile 0 in the K-loop's own order (A-lo,
+            //     B-lo, then B-hi, A-hi), so the next K-loop's counted waits hold unchanged.
+            // Loaders: DMA + counted waits only; storers: LDS reads, the add and the global stores (fire-and-forget:
+            // they drain under the next tile's K-loop).
+            const unsigned img_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + 6 * G256_HALF;
             const unsigned resid_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
             unsigned stage_addr[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
-                stage_addr[nt] = stage_base + (wm * 32 + fr) * 1024 + (wn >> 1) * 256 +
-                                 (((((wn & 1) * 8 + nt * 4 + fg) ^ fr)) << 4);
+                stage_addr[nt] = img_base + fr * 1024 + (wn >> 1) * 256 + (((((wn & 1) * 8 + nt * 4 + fg) ^ fr)) << 4);
             float* const outf = static_cast<float*>(g.out);
+            P_ISSUE_RESID(4, 32);                          // sub-pass 2 (tile rows 32..63) -> Z
+            P_ISSUE_RESID(5, 48);
 #pragma unroll
             for (int sp = 0; sp < 8; ++sp) {
-                const int j = sp >> 1, h = sp & 1;
-                if (h == 0) {
+                const int h = sp & 1;
+                const int lo = sp % 3 == 0 ? 0 : (sp % 3 == 1 ? 1 : 4), hi = sp % 3 == 0 ? 2 : (sp % 3 == 1 ? 3 : 5);
+                if (wm == h) {
 #define P_STAGE32(mt, b, nt)                                                                         \
     do {                                                                                             \
-        const f32x4 x_ = acc[j >> 1][(j & 1) * 2 + (mt)][b][nt] + bz[b][nt];                         \
+        const f32x4 x_ = acc[sp >> 2][((sp >> 1) & 1) * 2 + (mt)][b][nt] + bz[b][nt];                \
         asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(stage_addr[nt]), "v"(x_), "n"((mt) * 16384 + (b) * 512) : "memory"); \
     } while (0)
 #define P_STAGE32_MT(mt) P_STAGE32(mt, 0, 0); P_STAGE32(mt, 0, 1); P_STAGE32(mt, 1, 0); P_STAGE32(mt, 1, 1)
@@ -317,17 +323,18 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
 #undef P_STAGE32
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
-                P_WAIT(8);                                 // residual sub-pass sp has landed (sp+1 / next K-tile 0 may be in flight)
+                // residual sub-pass sp has landed; younger in flight: sp+1, sp+2 (sp <= 5), then sp+1 or the
+                // first half of the next K-tile 0
+                if (sp <= 5) P_WAIT(16); else P_WAIT(8);
                 __builtin_amdgcn_s_barrier();
                 if (!loader) {
-                    // storer wn: rows r = 8 wn + i of the sub-pass; acc image row = 32 h + r, residual row r lives in
-                    // region (r < 16 ? h : 2 + h) at (r & 15) KiB, lane-linear
-                    const int rl0 = h * 32 + wn * 8;
-                    const unsigned ra = resid_base + ((wn < 2 ? h : 2 + h) * G256_HALF) + ((wn & 1) * 8) * 1024 + lane * 16;
+                    // storer wn: rows r = 8 wn + i of the sub-pass (image row r; residual row r in region
+                    // (r < 16 ? lo : hi) at (r & 15) KiB, lane-linear)
+                    const unsigned ra = resid_base + (wn < 2 ? lo : hi) * G256_HALF + ((wn & 1) * 8) * 1024 + lane * 16;
                     unsigned aa[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        aa[i] = stage_base + (rl0 + i) * 1024 + ((lane ^ ((wn & 1) * 8 + i)) << 4);
+                        aa[i] = img_base + (wn * 8 + i) * 1024 + ((lane ^ ((wn & 1) * 8 + i)) << 4);
                     f32x4 x0, x1, x2, x3, x4, x5, x6, x7, r0, r1, r2, r3, r4, r5, r6, r7;
                     // one statement: 16 reads in flight and their wait (asm destinations are unprotected until it)
                     asm volatile(
@@ -350,16 +357,17 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                             *reinterpret_cast<f32x4*>(outf + (size_t)m * g.N + n0 + lane * 4) = xs[i] + rs[i];
                     }
                 }
-                __builtin_amdgcn_s_barrier();              // sub-pass sp is out of LDS: its regions may be refilled
-                if (sp < 6) {
-                    const int s2 = sp + 2;
-                    const int rb = (s2 >> 2) * 128 + (s2 & 1) * 64 + ((s2 >> 1) & 1) * 32;
-                    P_ISSUE_RESID(h, rb);
-                    P_ISSUE_RESID(2 + h, rb + 16);
+                __builtin_amdgcn_s_barrier();              // sub-pass sp is out of LDS: image and buffer may be refilled
+                if (sp & 1) P_STAMP(3 + (sp >> 1));
+                if (sp < 5) {
+                    const int s3 = sp + 3;
+                    const int rb = (s3 >> 2) * 128 + (s3 & 1) * 64 + ((s3 >> 1) & 1) * 32;
+                    P_ISSUE_RESID(lo, rb);
+                    P_ISSUE_RESID(hi, rb + 16);
                 } else if (sp == 6) {
                     P_ISSUE(0, 0, 0);                      // next tile's K-tile 0 (this tile's again when there is none)
                     P_ISSUE(2, 0, 0);
-                } else {
+                } else if (sp == 7) {
                     P_ISSUE(3, 0, 0);
                     P_ISSUE(1, 0, 0);
                 }

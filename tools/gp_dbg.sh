@@ -1,3 +1,2 @@
 #!/bin/bash
-# development aid: whole encode step with the persistent GEMMs off (0) / on (1), twice, one box
-for rep in 1 2; do for d in 0 1; do echo "== CLIPMI_GEMM_PERSIST=$d"; CLIPMI_GEMM_PERSIST=$d timeout -k 10 200 python tools/encode_timing.py 435 870 1740 || exit 1; done; done
+timeout -k 10 200 python tools/gemm_persist.py 43500,768,768,2 43500,768,3072,2 87000,768,768,2 87000,768,3072,2 || exit 1

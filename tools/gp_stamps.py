@@ -10,7 +10,7 @@ M, N, K, epi = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "21750,30
 a = torch.randn(M, K, device=dev).to(torch.bfloat16)
 w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
 st = torch.zeros(1024, dtype=torch.int64, device=dev)
-out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+out = torch.zeros(M, N, dtype=torch.float32 if epi == 2 else torch.bfloat16, device=dev)
 for _ in range(5):
     clipmi._lib.check(L.clipmi_dbg_gemm_bf16(a.data_ptr(), w.data_ptr(), st.data_ptr(), out.data_ptr(), M, N, K, epi | (3 << 8), None), "gemm")
 torch.cuda.synchronize()
