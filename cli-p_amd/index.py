@@ -280,27 +280,104 @@ def write_index(index, path, format="clipmi"):
         f.write(db.tobytes())
 
 
+def _read_faiss_header(f):
+    """faiss write_index_header: d i32, ntotal i64, two dummy i64, is_trained u8, metric i32."""
+    d, n, _, _ = struct.unpack("<iqqq", f.read(28))
+    trained, metric = struct.unpack("<Bi", f.read(5))
+    return d, n, metric
+
+
+def _read_faiss_ivfflat(f, path):
+    """The file the REFERENCE writes (build-index.py:80-81,109: IndexIVFFlat(IndexFlatIP(512), 512, 100,
+    METRIC_INNER_PRODUCT) -> faiss.write_index): fourcc "IwFl", index header, nlist u64, nprobe u64, the
+    quantizer as a nested index ("IxFI" + centroids), the direct map (u8 type, i64 vector[, hashtable]),
+    then ArrayInvertedLists: fourcc "ilar", nlist u64, code_size u64, list sizes ("full": u64 vector of nlist
+    sizes; "sprs": u64 vector of (list, size) pairs), then per non-empty list its codes (n * code_size bytes =
+    n rows of d f32) and its ids (n i64). Layout as in faiss impl/index_write.cpp (write_ivf_header,
+    write_direct_map, write_InvertedLists). Returns the rows in ID order: exact search over them returns a
+    superset-quality answer of what the IVF index (nprobe of 100 lists) would.
+    PARITY UNPINNED: no faiss build exists in this environment to produce or check a real file; the test
+    fixture is written by tests/ from the same layout."""
+    d, n, metric = _read_faiss_header(f)
+    if metric != METRIC_INNER_PRODUCT:
+        raise ValueError(f"{path}: faiss IVF index with metric {metric}; only inner product is supported")
+    nlist, _nprobe = struct.unpack("<QQ", f.read(16))
+    q4 = f.read(4)
+    if q4 not in (b"IxFI", b"IxF2", b"IxFl"):
+        raise ValueError(f"{path}: IVF quantizer {q4!r} is not a flat index")
+    qd, qn, _ = _read_faiss_header(f)
+    (cnt,) = struct.unpack("<Q", f.read(8))
+    if qd != d or cnt != qn * qd:
+        raise ValueError(f"{path}: malformed IVF quantizer")
+    f.seek(cnt * 4, 1)                                   # centroids: not needed for exact search
+    (dm_type,) = struct.unpack("<B", f.read(1))
+    (dm_n,) = struct.unpack("<Q", f.read(8))
+    f.seek(dm_n * 8, 1)
+    if dm_type == 2:                                     # hashtable: vector of (key, value) pairs
+        (hn,) = struct.unpack("<Q", f.read(8))
+        f.seek(hn * 16, 1)
+    if f.read(4) != b"ilar":
+        raise ValueError(f"{path}: only ArrayInvertedLists ('ilar') are supported")
+    il_nlist, code_size = struct.unpack("<QQ", f.read(16))
+    if il_nlist != nlist or code_size != 4 * d:
+        raise ValueError(f"{path}: inverted lists nlist {il_nlist} / code size {code_size} do not match IVFFlat d={d}")
+    kind = f.read(4)
+    (sz_n,) = struct.unpack("<Q", f.read(8))
+    raw = np.fromfile(f, dtype="<u8", count=sz_n)
+    sizes = np.zeros(nlist, dtype=np.int64)
+    if kind == b"full":
+        if sz_n != nlist:
+            raise ValueError(f"{path}: 'full' list sizes vector has {sz_n} entries for {nlist} lists")
+        sizes[:] = raw
+    elif kind == b"sprs":
+        sizes[raw[0::2].astype(np.int64)] = raw[1::2]
+    else:
+        raise ValueError(f"{path}: unknown inverted-list size encoding {kind!r}")
+    if int(sizes.sum()) != n:
+        raise ValueError(f"{path}: inverted lists hold {int(sizes.sum())} vectors, header says {n}")
+    mat = np.empty((n, d), dtype=np.float32)
+    seen = np.zeros(n, dtype=bool)
+    for ln in sizes:
+        ln = int(ln)
+        if ln == 0:
+            continue
+        codes = np.fromfile(f, dtype="<f4", count=ln * d)
+        ids = np.fromfile(f, dtype="<i8", count=ln)
+        if codes.size != ln * d or ids.size != ln:
+            raise ValueError(f"{path}: truncated inverted list")
+        if ids.min() < 0 or ids.max() >= n or seen[ids].any():
+            raise ValueError(f"{path}: ids are not a permutation of 0..{n - 1} (custom ids are not supported)")
+        seen[ids] = True
+        mat[ids] = codes.reshape(ln, d)
+    return d, mat
+
+
 def read_index(path, device="cuda:0"):
-    """faiss.read_index stand-in (query-index.py:29); reads both formats write_index produces."""
+    """faiss.read_index stand-in (query-index.py:29): reads both formats write_index produces and the
+    IndexIVFFlat file the reference's build-index.py writes (rows come back in id order and are searched
+    exactly; `nprobe` is accepted and ignored)."""
     with open(path, "rb") as f:
         head = f.read(8)
         if head[:4] == FAISS_FOURCC_FLAT_IP:
             f.seek(4)
-            d, n, _, _ = struct.unpack("<iqqq", f.read(28))
-            trained, metric = struct.unpack("<Bi", f.read(5))
+            d, n, metric = _read_faiss_header(f)
             if metric != METRIC_INNER_PRODUCT:
                 raise ValueError(f"{path}: faiss flat index with metric {metric}; only inner product is supported")
             (count,) = struct.unpack("<Q", f.read(8))
             if count != n * d:
                 raise ValueError(f"{path}: vector count {count} != ntotal*d {n * d}")
+            data = np.fromfile(f, dtype="<f4", count=n * d)
+        elif head[:4] == b"IwFl":
+            f.seek(4)
+            d, mat = _read_faiss_ivfflat(f, path)
+            n, data = mat.shape[0], mat.reshape(-1)
         elif head == MAGIC:
             ver, d, n = struct.unpack("<IIQ", f.read(16))
             if ver != 1:
                 raise ValueError(f"{path}: unsupported version {ver}")
+            data = np.fromfile(f, dtype="<f4", count=n * d)
         else:
-            raise ValueError(f"{path}: not a clipmi or faiss IndexFlatIP file (an IVF index must be rebuilt: "
-                             "re-run build-index.py)")
-        data = np.fromfile(f, dtype="<f4", count=n * d)
+            raise ValueError(f"{path}: not a clipmi, faiss IndexFlatIP or faiss IndexIVFFlat file")
     if data.size != n * d:
         raise ValueError(f"{path}: truncated ({data.size} of {n * d} floats)")
     idx = IndexFlatIP(d, device=device)

@@ -55,8 +55,51 @@ def test_faiss_flat_ip_file_layout(clipmi, tmp_path):
     assert raw[45:] == x.astype("<f4").tobytes()
     back = clipmi.read_index(p, device="cpu")
     assert back.ntotal == 7 and np.array_equal(back.matrix().numpy(), x)
-    open(p, "wb").write(b"IwFl" + raw[4:])
-    with pytest.raises(ValueError, match="rebuilt"):
+    open(p, "wb").write(b"IwXX" + raw[4:])
+    with pytest.raises(ValueError, match="not a clipmi"):
+        clipmi.read_index(p, device="cpu")
+
+
+def _write_faiss_ivfflat(path, x, nlist, sparse, rng):
+    """An IndexIVFFlat file as faiss impl/index_write.cpp lays it out (what the reference's build-index.py:
+    80-81,109 produces): restated from upstream by the test, independently of the reader."""
+    import struct
+    n, d = x.shape
+    cent = unit_rows(rng, nlist, d)
+    assign = np.argmax(x @ cent.T, axis=1) if not sparse else rng.integers(0, 3, n)     # sparse: 3 of nlist lists used
+    hdr = lambda d_, n_: struct.pack("<iqqq", d_, n_, 1 << 20, 1 << 20) + struct.pack("<Bi", 1, 0)
+    with open(path, "wb") as f:
+        f.write(b"IwFl" + hdr(d, n) + struct.pack("<QQ", nlist, 1))
+        f.write(b"IxFI" + hdr(d, nlist) + struct.pack("<Q", nlist * d) + cent.astype("<f4").tobytes())
+        f.write(struct.pack("<B", 0) + struct.pack("<Q", 0))                             # direct map: none
+        f.write(b"ilar" + struct.pack("<QQ", nlist, 4 * d))
+        sizes = np.bincount(assign, minlength=nlist).astype("<u8")
+        if sparse:
+            nz = np.nonzero(sizes)[0]
+            pairs = np.stack([nz.astype("<u8"), sizes[nz]], axis=1).reshape(-1)
+            f.write(b"sprs" + struct.pack("<Q", pairs.size) + pairs.astype("<u8").tobytes())
+        else:
+            f.write(b"full" + struct.pack("<Q", nlist) + sizes.tobytes())
+        for l in range(nlist):
+            ids = np.nonzero(assign == l)[0].astype("<i8")
+            if ids.size:
+                f.write(x[ids].astype("<f4").tobytes() + ids.tobytes())
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_reads_reference_ivfflat_index_file(clipmi, tmp_path, sparse):
+    """next-3: an `images.index` written by the reference (IndexIVFFlat, 100 lists, inner product) opens and
+    its rows come back in id order (format restated from upstream; PARITY UNPINNED: no faiss here)."""
+    rng = np.random.default_rng(7)
+    x = unit_rows(rng, 333, 512)
+    p = str(tmp_path / "images.index")
+    _write_faiss_ivfflat(p, x, 100, sparse, rng)
+    idx = clipmi.read_index(p, device="cpu")
+    idx.nprobe = 32                                   # query-index.py:30
+    assert idx.ntotal == 333 and np.array_equal(idx.matrix().numpy(), x)
+    raw = bytearray(open(p, "rb").read())
+    open(p, "wb").write(raw[:-100])
+    with pytest.raises(ValueError):
         clipmi.read_index(p, device="cpu")
 
 
