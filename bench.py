@@ -46,7 +46,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=870, help="images per GPU per step")
     ap.add_argument("--rows", type=int, default=10_000_000, help="total rows of the flat index")
     ap.add_argument("--queries", type=int, default=64, help="queries per search batch (64 = one pass of the coarse scan)")
-    ap.add_argument("--exact-only", action="store_true", help="search with the exact f32 scan only (no bf16 coarse pass)")
+    ap.add_argument("--exact-only", action="store_true", help="search with the exact f32 scan only (no coarse pass)")
+    ap.add_argument("--coarse", choices=["int8", "bf16"], default="int8",
+                    help="coarse copy scanned before the exact f32 re-scoring (results are identical either way)")
     ap.add_argument("--k", type=int, default=50, help="results per query (K = k + 1 is searched)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -216,11 +218,12 @@ def main():
         e = min(n_local, s + chunk)
         blk = torch.randn((e - s, 512), generator=gd, device=dev)
         db[s:e] = blk / blk.norm(dim=1, keepdim=True)
-    idx = clipmi.IndexFlatIP(512, device=dev, coarse=None if a.exact_only else "bf16")
+    idx = clipmi.IndexFlatIP(512, device=dev, coarse=None if a.exact_only else a.coarse)
     idx.add(db)
     coarse = idx.uses_coarse()
-    if coarse:
-        idx.matrix_bf16()        # bf16 copy + row-norm bound are part of the index, built once
+    i8 = coarse and a.coarse == "int8"
+    if coarse:                   # the coarse copy + row-norm bounds are part of the index, built once
+        idx.matrix_i8() if i8 else idx.matrix_bf16()
     gq = torch.Generator(device=dev)
     gq.manual_seed(2)
     q = torch.randn((Q, 512), generator=gq, device=dev)
@@ -240,7 +243,17 @@ def main():
     oi_ = torch.empty((64, K), dtype=torch.int64, device=dev)
     scan_ms = C.c_float(0)
     survivors = C.c_longlong(-1)
-    if coarse:
+    if i8:
+        db8, meta, amax, rmax = idx.matrix_i8()
+        ws = torch.empty(L.clipmi_topk_ip_coarse_workspace_bytes(n_local, 512, Qp, K), dtype=torch.uint8, device=dev)
+        clipmi._lib.check(L.clipmi_dbg_topk_coarse_i8_scan_ms(db.data_ptr(), db8.data_ptr(), meta.data_ptr(), amax, n_local, 512,
+                                                              rmax, q.data_ptr(), Qp, K, os_.data_ptr(), oi_.data_ptr(),
+                                                              ws.data_ptr(), ws.numel(), clipmi._lib.stream_ptr(dev), 10,
+                                                              C.byref(scan_ms), C.byref(survivors)), "coarse_i8_scan_ms")
+        scan_bytes = n_local * (512 + 8)         # int8 row + its (scale, error norm) pair
+        scan_name = f"scan_coarse_kernel<512,{1 if Qp <= 16 else 2 if Qp <= 32 else 4},false,true>"
+        traffic_key = "scan_coarse_i8_bytes_per_launch"
+    elif coarse:
         dbh, rmax = idx.matrix_bf16()
         ws = torch.empty(L.clipmi_topk_ip_coarse_workspace_bytes(n_local, 512, Qp, K), dtype=torch.uint8, device=dev)
         clipmi._lib.check(L.clipmi_dbg_topk_coarse_scan_ms(db.data_ptr(), dbh.data_ptr(), n_local, 512, rmax, q.data_ptr(), Qp,
@@ -248,7 +261,7 @@ def main():
                                                            clipmi._lib.stream_ptr(dev), 10, C.byref(scan_ms),
                                                            C.byref(survivors)), "coarse_scan_ms")
         scan_bytes = n_local * 512 * 2
-        scan_name = f"scan_coarse_bf16_kernel<512,{1 if Qp <= 16 else 2 if Qp <= 32 else 4},false>"
+        scan_name = f"scan_coarse_kernel<512,{1 if Qp <= 16 else 2 if Qp <= 32 else 4},false,false>"
         traffic_key = "scan_coarse_bytes_per_launch"
     else:
         ws = torch.empty(L.clipmi_topk_ip_workspace_bytes(n_local, 512, Qp, K), dtype=torch.uint8, device=dev)
@@ -285,8 +298,10 @@ def main():
                      "whole_step_frac": FLOP_PER_IMAGE * B * a.steps / dt_enc / 1e12 / PEAK_BF16_TFLOPS},
         "search": {"metric": f"queries/sec top-{a.k} over {a.rows}x512 flat IP (exact results, f32 scores)", "value": qps,
                    "unit": "queries/s", "ms_per_step": dt_s / a.steps * 1e3, "scaling": "strong",
-                   "dtype": "bf16 coarse scan + f32 exact re-scoring" if coarse else "f32",
-                   "path": "coarse-then-exact (clipmi_topk_ip_coarse)" if coarse else "exact scan (clipmi_topk_ip)",
+                   "dtype": ("int8 coarse scan (i32 MFMA) + f32 exact re-scoring" if i8 else
+                             "bf16 coarse scan + f32 exact re-scoring" if coarse else "f32"),
+                   "path": ("coarse-then-exact (clipmi_topk_ip_coarse_i8)" if i8 else
+                            "coarse-then-exact (clipmi_topk_ip_coarse)" if coarse else "exact scan (clipmi_topk_ip)"),
                    "queries_per_batch": Q, "rows_per_gpu": n_local,
                    "roofline": {"bound": "hbm", "kernel": scan_name,
                                 "achieved": scan_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -18,6 +18,7 @@ SYMBOLS = [
     "clipmi_encode_text_workspace_bytes", "clipmi_encode_text",
     "clipmi_topk_ip_workspace_bytes", "clipmi_topk_ip",
     "clipmi_topk_ip_coarse_workspace_bytes", "clipmi_topk_ip_coarse", "clipmi_dbg_topk_coarse_scan_ms",
+    "clipmi_quantize_rows_i8", "clipmi_topk_ip_coarse_i8", "clipmi_dbg_topk_coarse_i8_scan_ms",
     "clipmi_merge_topk_workspace_bytes", "clipmi_merge_topk", "clipmi_merge_topk_packed",
     "clipmi_l2_normalize_rows", "clipmi_last_error", "clipmi_abi_version",
     "clipmi_dbg_gemm_bf16", "clipmi_dbg_layernorm", "clipmi_dbg_attention", "clipmi_dbg_topk_scan_ms",
@@ -76,6 +77,13 @@ def lib():
     L.clipmi_topk_ip_coarse_workspace_bytes.argtypes = [i64, i32, i32, i32]
     L.clipmi_topk_ip_coarse.restype = i32
     L.clipmi_topk_ip_coarse.argtypes = [vp, vp, i64, i32, C.c_float, vp, i32, i32, i64, vp, vp, vp, sz, vp]
+    L.clipmi_quantize_rows_i8.restype = i32
+    L.clipmi_quantize_rows_i8.argtypes = [vp, i64, i32, vp, vp, vp]
+    L.clipmi_topk_ip_coarse_i8.restype = i32
+    L.clipmi_topk_ip_coarse_i8.argtypes = [vp, vp, vp, C.c_float, i64, i32, C.c_float, vp, i32, i32, i64, vp, vp, vp, sz, vp]
+    L.clipmi_dbg_topk_coarse_i8_scan_ms.restype = i32
+    L.clipmi_dbg_topk_coarse_i8_scan_ms.argtypes = [vp, vp, vp, C.c_float, i64, i32, C.c_float, vp, i32, i32, vp, vp, vp, sz, vp,
+                                                    i32, C.POINTER(C.c_float), C.POINTER(C.c_longlong)]
     L.clipmi_dbg_topk_coarse_scan_ms.restype = i32
     L.clipmi_dbg_topk_coarse_scan_ms.argtypes = [vp, vp, i64, i32, C.c_float, vp, i32, i32, vp, vp, vp, sz, vp, i32,
                                                  C.POINTER(C.c_float), C.POINTER(C.c_longlong)]

@@ -15,6 +15,7 @@
 //     a beats b  <=>  a.score > b.score || (a.score == b.score && a.id < b.id); NaN never selected.
 #include "common.hpp"
 #include <float.h>
+#include <type_traits>
 #include <hip/hip_ext.h>
 
 namespace clipmi {
@@ -485,8 +486,90 @@ __global__ void __launch_bounds__(256) coarse_thresholds_kernel(const float* thr
     }
 }
 
+// ---- int8 coarse copy (clipmi_quantize_rows_i8 / clipmi_topk_ip_coarse_i8) -------------------------------
+// Row r: s_r = max|x_rk| / 127, q_rk = rint(x_rk / s_r) in [-127, 127], a_r = 1.001 * ||x_r - s_r q_r||_2.
+// Query: t_q, p_qk the same way, f_q = y - t_q p_q. The int8 MFMA gives the EXACT integer D = q_r . p_q
+// (|D| <= 512 * 127^2 < 2^24), and
+//      x.y = s_r t_q D + e_r.y + (s_r q_r).f_q      =>      |x.y - s_r t_q D| <= a_r ||y|| + (R_max + A_max) ||f_q||
+// (Cauchy-Schwarz twice; ||s_r q_r|| <= ||x_r|| + a_r). A row can be in the exact top-K only if its exact score is
+// >= tau_q (the exact K-th best of a sample), so the scan keeps row r for query q when
+//      s_r t_q D + a_r * 1.001 ||y|| >= tau_q - 1.001 (R_max + A_max) ||f_q|| - 1e-4 R_max ||y||
+// (the last term covers f32 rounding of both sides and of the exact kernel's fmaf chain: < 512 * 2^-23 relative).
+// Divided by t_q > 0 so that the kernel's test is one convert + one multiply + one fma + one compare per pair.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) quantize_rows_i8_kernel(const float* __restrict__ db, long long N, int E,
+                                                               signed char* __restrict__ out, float2* __restrict__ meta) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= N) return;
+    const float* x = db + (size_t)r * E;
+    float mx = 0.f;
+    for (int k = lane * 4; k < E; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(x + k);
+        mx = fmaxf(fmaxf(mx, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float s = mx > 0.f ? mx / 127.0f : 1.0f;
+    const float inv = 1.0f / s;
+    float ee = 0.f;
+    for (int k = lane * 4; k < E; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(x + k);
+        float qv[4] = {rintf(v.x * inv), rintf(v.y * inv), rintf(v.z * inv), rintf(v.w * inv)};
+        const float xv[4] = {v.x, v.y, v.z, v.w};
+        unsigned pk = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qv[j] = fminf(fmaxf(qv[j], -127.f), 127.f);
+            const float e = xv[j] - s * qv[j];
+            ee = fmaf(e, e, ee);
+            pk |= ((unsigned)(int)qv[j] & 0xffu) << (8 * j);
+        }
+        *reinterpret_cast<unsigned*>(out + (size_t)r * E + k) = pk;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ee += __shfl_xor(ee, o);
+    if (lane == 0) meta[r] = make_float2(s, sqrtf(ee) * 1.001f);
+}
+
+// one wave per query: t_q, ||y||, ||f_q|| and the three per-query constants of the int8 scan
+__global__ void __launch_bounds__(256) coarse_thresholds_i8_kernel(const float* thr0, const float* __restrict__ q, int E,
+                                                                   float rmax, float amax, int QA, float* qmeta) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= QA) return;
+    const float* y = q + (size_t)qi * E;
+    float mx = 0.f, ss = 0.f;
+    for (int k = lane; k < E; k += 64) { const float v = y[k]; mx = fmaxf(mx, fabsf(v)); ss = fmaf(v, v, ss); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); ss += __shfl_xor(ss, o); }
+    const float t = mx > 0.f ? mx / 127.0f : 1.0f;
+    const float inv = 1.0f / t;
+    float ff = 0.f;
+    for (int k = lane; k < E; k += 64) {
+        const float v = y[k];
+        const float p = fminf(fmaxf(rintf(v * inv), -127.f), 127.f);     // the scan's query image uses the same expression
+        const float f = v - t * p;
+        ff = fmaf(f, f, ff);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ff += __shfl_xor(ff, o);
+    if (lane == 0) {
+        const float Y = sqrtf(ss), F = sqrtf(ff) * 1.001f;
+        const float tau = thr0[qi];
+        const float margin = 1.001f * (rmax + amax) * F + 1e-4f * rmax * Y;
+        const bool bad = tau == -INFINITY || !(margin == margin) || !(Y == Y);
+        qmeta[qi] = inv;
+        qmeta[64 + qi] = 1.001f * Y * inv;
+        qmeta[128 + qi] = bad ? -INFINITY : (tau - margin) * inv;
+    }
+}
+
 struct CoarseArgs {
-    const unsigned short* dbh;   // bf16 [nrows][E]
+    const void* dbc;             // coarse copy of the matrix: bf16 [nrows][E] or int8 [nrows][E]
+    const float2* rmeta;         // int8 only: per row (scale s_r, error norm a_r >= ||x_r - s_r q_r||), padded to 32 rows
+    const float* qmeta;          // int8 only: [3][64]: 1/t_q | 1.001 ||y|| / t_q | threshold / t_q
     long long nrows;
     const float* q;              // f32 [QA][E]
     int QA;                      // 1..16*QG
@@ -502,10 +585,11 @@ constexpr int COARSE_FLUSH = 512;       // flush when more than this many are pe
 
 // PREPASS only changes the kernel's NAME (the level-2 pre-pass over S2 rows must not dilute the profiler's
 // per-name average of the main scan).
-template <int E, int QG, bool PREPASS>
-__global__ void __launch_bounds__(256) scan_coarse_bf16_kernel(CoarseArgs a) {
+template <int E, int QG, bool PREPASS, bool I8>
+__global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KS = E / 32;          // bf16 MFMA k-steps per 16-row tile
+    constexpr int KS = E / (I8 ? 64 : 32);   // MFMA k-steps per 16-row tile (16 bytes per lane and step either way)
+    constexpr int ROWB = I8 ? E : 2 * E;     // bytes per row of the coarse copy
     constexpr int SLOTS = 2 * KS;       // one step = two row tiles (32 rows): SLOTS 16-byte fragments per lane
     constexpr int NCH = SLOTS / 8;
 
@@ -515,15 +599,33 @@ __global__ void __launch_bounds__(256) scan_coarse_bf16_kernel(CoarseArgs a) {
     const int nwaves = blockDim.x >> 6;
     const int col = lane & 15, g = lane >> 4;
 
-    // bf16 query image: entry [(qg*KS + s)*64 + lane] = q[16qg + col][32s + 8g .. +7]
+    // query image: entry [(qg*KS + s)*64 + lane] = 16 bytes of query 16qg + col: bf16 k = 32s + 8g .. +7, or
+    // int8 k = 64s + 16g .. +15 (quantised exactly as coarse_thresholds_i8_kernel does)
     uint4* qimg = reinterpret_cast<uint4*>(smem);
     for (int idx = tid; idx < QG * KS * 64; idx += blockDim.x) {
         const int l = idx & 63, s_ = (idx >> 6) % KS, qg = (idx >> 6) / KS;
         const int c_ = qg * 16 + (l & 15), g_ = l >> 4;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (c_ < a.QA) {
-            const float* p = a.q + (size_t)c_ * E + 32 * s_ + 8 * g_;
-            v = make_uint4(pack2_bf16(p[0], p[1]), pack2_bf16(p[2], p[3]), pack2_bf16(p[4], p[5]), pack2_bf16(p[6], p[7]));
+            if (I8) {
+                const float* p = a.q + (size_t)c_ * E + 64 * s_ + 16 * g_;
+                const float inv = a.qmeta[c_];
+                unsigned w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned pk = 0;
+#pragma unroll
+                    for (int b_ = 0; b_ < 4; ++b_) {
+                        const float pq = fminf(fmaxf(rintf(p[4 * j + b_] * inv), -127.f), 127.f);
+                        pk |= ((unsigned)(int)pq & 0xffu) << (8 * b_);
+                    }
+                    w[j] = pk;
+                }
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            } else {
+                const float* p = a.q + (size_t)c_ * E + 32 * s_ + 8 * g_;
+                v = make_uint4(pack2_bf16(p[0], p[1]), pack2_bf16(p[2], p[3]), pack2_bf16(p[4], p[5]), pack2_bf16(p[6], p[7]));
+            }
         }
         qimg[idx] = v;
     }
@@ -533,11 +635,12 @@ __global__ void __launch_bounds__(256) scan_coarse_bf16_kernel(CoarseArgs a) {
     __syncthreads();
 
     bool active[QG];
-    float tau[QG];
+    float tau[QG], yt[QG];
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
         active[qg] = qg * 16 + col < a.QA;
-        tau[qg] = active[qg] ? a.tauc[qg * 16 + col] : INFINITY;
+        tau[qg] = active[qg] ? (I8 ? a.qmeta[128 + qg * 16 + col] : a.tauc[qg * 16 + col]) : INFINITY;
+        yt[qg] = (I8 && active[qg]) ? a.qmeta[64 + qg * 16 + col] : 0.f;
     }
     auto flush = [&]() {
         wave_lds_sync();
@@ -564,38 +667,58 @@ __global__ void __launch_bounds__(256) scan_coarse_bf16_kernel(CoarseArgs a) {
         auto frag_ptr = [&](long long st, int rt) {
             long long r = st * 32 + rt * 16 + col;
             r = r > last_row ? last_row : r;
-            return a.dbh + r * E + 8 * g;
+            return static_cast<const char*>(a.dbc) + r * ROWB + 16 * g;
+        };
+        // int8: (s_r, a_r) of this lane's accumulator rows 4g .. 4g+3 of both row tiles (rmeta is padded to 32 rows)
+        uint4 M[4] = {};
+        auto load_meta = [&](long long st, uint4* m) {
+            if (I8) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const uint4* mp = reinterpret_cast<const uint4*>(a.rmeta + st * 32 + rt * 16 + 4 * g);
+                    m[2 * rt] = mp[0];
+                    m[2 * rt + 1] = mp[1];
+                }
+            }
         };
         {
-            const unsigned short* p0 = frag_ptr(step, 0);
-            const unsigned short* p1 = frag_ptr(step, 1);
+            const char* p0 = frag_ptr(step, 0);
+            const char* p1 = frag_ptr(step, 1);
 #pragma unroll
             for (int s_ = 0; s_ < KS; ++s_) {
-                T[s_] = *reinterpret_cast<const uint4*>(p0 + 32 * s_);
-                T[KS + s_] = *reinterpret_cast<const uint4*>(p1 + 32 * s_);
+                T[s_] = *reinterpret_cast<const uint4*>(p0 + 64 * s_);
+                T[KS + s_] = *reinterpret_cast<const uint4*>(p1 + 64 * s_);
             }
+            load_meta(step, M);
         }
+        using AccT = typename std::conditional<I8, i32x4, f32x4>::type;
         while (true) {
             const long long nxt = step + tw;
             const bool has_next = nxt < nsteps;
-            const unsigned short* pn[2] = {frag_ptr(has_next ? nxt : step, 0), frag_ptr(has_next ? nxt : step, 1)};
+            const char* pn[2] = {frag_ptr(has_next ? nxt : step, 0), frag_ptr(has_next ? nxt : step, 1)};
+            uint4 MN[4] = {};
+            load_meta(has_next ? nxt : step, MN);
 
-            f32x4 acc[2][QG];
+            AccT acc[2][QG];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int qg = 0; qg < QG; ++qg) acc[rt][qg] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int qg = 0; qg < QG; ++qg) acc[rt][qg] = AccT{0, 0, 0, 0};
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int slot = 8 * c + j;
                     const int rt = slot / KS, s_ = slot % KS;
-                    const bf16x8 af = __builtin_bit_cast(bf16x8, T[slot]);
 #pragma unroll
                     for (int qg = 0; qg < QG; ++qg) {
-                        const bf16x8 bq = __builtin_bit_cast(bf16x8, qimg[(qg * KS + s_) * 64 + lane]);
-                        acc[rt][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bq, acc[rt][qg], 0, 0, 0);
+                        const uint4 bq = qimg[(qg * KS + s_) * 64 + lane];
+                        if constexpr (I8)
+                            acc[rt][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, T[slot]),
+                                                                                __builtin_bit_cast(i32x4, bq), acc[rt][qg], 0, 0, 0);
+                        else
+                            acc[rt][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, T[slot]),
+                                                                                  __builtin_bit_cast(bf16x8, bq), acc[rt][qg], 0, 0, 0);
                     }
                 }
                 // keep the refill of this chunk's registers behind its last MFMA (see scan_topk_f32_kernel)
@@ -607,11 +730,25 @@ __global__ void __launch_bounds__(256) scan_coarse_bf16_kernel(CoarseArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int slot = 8 * c + j;
-                    T[slot] = *reinterpret_cast<const uint4*>(pn[slot / KS] + 32 * (slot % KS));
+                    T[slot] = *reinterpret_cast<const uint4*>(pn[slot / KS] + 64 * (slot % KS));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
 
+            // value compared with tau[qg]: the bf16 score itself, or (int8) D * s_r + a_r * 1.001 ||y|| / t_q
+            float val[2][QG][4];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const float sr[4] = {__uint_as_float(M[2 * rt].x), __uint_as_float(M[2 * rt].z), __uint_as_float(M[2 * rt + 1].x),
+                                     __uint_as_float(M[2 * rt + 1].z)};
+                const float ar[4] = {__uint_as_float(M[2 * rt].y), __uint_as_float(M[2 * rt].w), __uint_as_float(M[2 * rt + 1].y),
+                                     __uint_as_float(M[2 * rt + 1].w)};
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        val[rt][qg][r] = I8 ? fmaf((float)acc[rt][qg][r], sr[r], ar[r] * yt[qg]) : (float)acc[rt][qg][r];
+            }
             bool any = false;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
@@ -619,7 +756,7 @@ __global__ void __launch_bounds__(256) scan_coarse_bf16_kernel(CoarseArgs a) {
                 for (int qg = 0; qg < QG; ++qg)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        any |= active[qg] && (step * 32 + rt * 16 + 4 * g + r <= last_row) && (acc[rt][qg][r] >= tau[qg]);
+                        any |= active[qg] && (step * 32 + rt * 16 + 4 * g + r <= last_row) && (val[rt][qg][r] >= tau[qg]);
             if (__ballot(any)) {
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
@@ -628,7 +765,7 @@ __global__ void __launch_bounds__(256) scan_coarse_bf16_kernel(CoarseArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const long long row = step * 32 + rt * 16 + 4 * g + r;
-                            if (active[qg] && row <= last_row && acc[rt][qg][r] >= tau[qg]) {
+                            if (active[qg] && row <= last_row && val[rt][qg][r] >= tau[qg]) {
                                 const int pos = atomicAdd(lcnt, 1);
                                 list[pos] = make_uint2((unsigned)(qg * 16 + col), (unsigned)row);
                             }
@@ -638,6 +775,8 @@ __global__ void __launch_bounds__(256) scan_coarse_bf16_kernel(CoarseArgs a) {
             }
             if (!has_next) break;
             step = nxt;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) M[i] = MN[i];
         }
     }
     // final publication, aggregated per BLOCK: one returning global atomic per (block, query) issued by
@@ -896,24 +1035,25 @@ constexpr int COARSE_Q = 64;                     // queries per coarse pass. (12
                                                  // leaves LDS for only 2 waves per CU = 2 of 4 SIMDs, and the pass turns
                                                  // MFMA-bound: 5.29 ms per 128 queries vs 2 x 2.21 ms)
 
-template <int QG, bool PREPASS>
+template <int QG, bool PREPASS, bool I8>
 int launch_coarse(const CoarseArgs& a, long long nsteps, hipStream_t st, hipEvent_t* ev) {
     // 128 queries need a 128-KiB bf16 query image: only two waves' candidate lists fit beside it
     constexpr int WAVES = QG > 4 ? 2 : 4;
-    const size_t lds = (size_t)QG * (512 / 32) * 1024 + WAVES * (COARSE_LIST * 8 + 16);
-    if (int rc = opt_in_lds((const void*)scan_coarse_bf16_kernel<512, QG, PREPASS>, lds)) return rc;
+    // the final publication reuses the head of the query image for 3 * 16 QG counters: keep >= 1 KiB
+    const size_t lds = (size_t)QG * (512 / (I8 ? 64 : 32)) * 1024 + WAVES * (COARSE_LIST * 8 + 16);
+    if (int rc = opt_in_lds((const void*)scan_coarse_kernel<512, QG, PREPASS, I8>, lds)) return rc;
     long long g_ = (nsteps + WAVES - 1) / WAVES;
     const int grid = (int)(g_ < NUM_CU ? g_ : NUM_CU);
     if (ev) (void)hipEventRecord(ev[0], st);
-    hipLaunchKernelGGL((scan_coarse_bf16_kernel<512, QG, PREPASS>), dim3(grid), dim3(WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((scan_coarse_kernel<512, QG, PREPASS, I8>), dim3(grid), dim3(WAVES * 64), lds, st, a);
     if (ev) (void)hipEventRecord(ev[1], st);
-    CLIPMI_CHECK_LAUNCH("scan_coarse_bf16_kernel");
+    CLIPMI_CHECK_LAUNCH("scan_coarse_kernel");
     return 0;
 }
 
 struct CoarseWs {
     uint2* cand_e; uint2* cand_c; unsigned* gcnt_e; unsigned* gcnt_c; float* thr0; float* tauc; unsigned* flag;
-    unsigned* last_m;
+    unsigned* last_m; float* qmeta;
 };
 
 size_t carve_coarse(const Plan& p, void* base, size_t cap, CoarseWs* w) {
@@ -927,15 +1067,20 @@ size_t carve_coarse(const Plan& p, void* base, size_t cap, CoarseWs* w) {
     x.thr0 = ar.take<float>(COARSE_Q);
     x.tauc = ar.take<float>(COARSE_Q);
     x.last_m = ar.take<unsigned>(COARSE_Q);
+    x.qmeta = ar.take<float>(3 * 64);
     if (w) *w = x;
     return ar.off + 256;
 }
 
-int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, int64_t N, int E, float rmax, const float* q_dev, int Q,
+// i8 = false: dbh_dev is the bf16 copy (rmeta, amax unused); i8 = true: dbh_dev is the int8 copy, rmeta its per-row
+// (scale, error norm) pairs padded to a multiple of 32 rows, amax >= every error norm
+int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const float2* rmeta, float amax, int64_t N, int E,
+                        float rmax, const float* q_dev, int Q,
                         int K, int64_t id_base, float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes,
                         void* stream, hipEvent_t* scan_ev) {
-    if (!db_dev || !dbh_dev || !q_dev || !out_score_dev || !out_id_dev || !ws_dev)
+    if (!db_dev || !dbh_dev || !q_dev || !out_score_dev || !out_id_dev || !ws_dev || (i8 && !rmeta))
         return set_err(CLIPMI_EINVAL, "topk_ip_coarse: NULL pointer");
+    if (i8 && !(amax >= 0.f)) return set_err(CLIPMI_EINVAL, "topk_ip_coarse_i8: amax=%g", amax);
     if (E != 512 || N < SAMPLE_MIN_N) return set_err(CLIPMI_EUNSUPPORTED, "topk_ip_coarse: needs E = 512 and N >= %d", SAMPLE_MIN_N);
     if (!(rmax > 0.f) || N >= (1ll << 32) - 1) return set_err(CLIPMI_EINVAL, "topk_ip_coarse: rmax=%g N=%lld", rmax, (long long)N);
     Plan p;
@@ -973,16 +1118,22 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, int64_t N, int 
         //  than the level-1 scan + select they replace)
         const bool two_level = S2 > S1;
         CoarseArgs c;
-        c.dbh = static_cast<const unsigned short*>(dbh_dev); c.q = qg; c.QA = qa; c.tauc = w.tauc;
+        c.dbc = dbh_dev; c.rmeta = rmeta; c.qmeta = w.qmeta; c.q = qg; c.QA = qa; c.tauc = w.tauc;
         c.cand = w.cand_c; c.gcnt = w.gcnt_c; c.cap = COARSE_CAP; c.overflow = w.flag;
         auto coarse_pass = [&](long long rows, float* thr_out, float* os, long long* oi, long long idb, hipEvent_t* ev,
                                unsigned* m_out) -> int {
             c.nrows = rows;
             const long long nsteps = (rows + 31) / 32;
             const bool pre = thr_out != nullptr;
-            int rc_ = qa <= 16 ? (pre ? launch_coarse<1, true>(c, nsteps, st, ev) : launch_coarse<1, false>(c, nsteps, st, ev))
-                    : qa <= 32 ? (pre ? launch_coarse<2, true>(c, nsteps, st, ev) : launch_coarse<2, false>(c, nsteps, st, ev))
-                               : (pre ? launch_coarse<4, true>(c, nsteps, st, ev) : launch_coarse<4, false>(c, nsteps, st, ev));
+            int rc_;
+            if (i8)
+                rc_ = qa <= 16 ? (pre ? launch_coarse<1, true, true>(c, nsteps, st, ev) : launch_coarse<1, false, true>(c, nsteps, st, ev))
+                    : qa <= 32 ? (pre ? launch_coarse<2, true, true>(c, nsteps, st, ev) : launch_coarse<2, false, true>(c, nsteps, st, ev))
+                               : (pre ? launch_coarse<4, true, true>(c, nsteps, st, ev) : launch_coarse<4, false, true>(c, nsteps, st, ev));
+            else
+                rc_ = qa <= 16 ? (pre ? launch_coarse<1, true, false>(c, nsteps, st, ev) : launch_coarse<1, false, false>(c, nsteps, st, ev))
+                    : qa <= 32 ? (pre ? launch_coarse<2, true, false>(c, nsteps, st, ev) : launch_coarse<2, false, false>(c, nsteps, st, ev))
+                               : (pre ? launch_coarse<4, true, false>(c, nsteps, st, ev) : launch_coarse<4, false, false>(c, nsteps, st, ev));
             if (rc_) return rc_;
             // ~2-3 k survivors per query = ~11 blocks of 256 pairs; a larger grid only queues idle blocks
             hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(12, qa), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
@@ -1006,14 +1157,21 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, int64_t N, int 
         }
         // level 2 (S2 rows): the coarse machinery itself, all queries at once, filtered by level 1's bound;
         // its exact re-scored K-th best is thr0
+        auto thresholds = [&](const float* thr_in) -> int {
+            if (i8)
+                hipLaunchKernelGGL(coarse_thresholds_i8_kernel, dim3((qa + 3) / 4), dim3(256), 0, st, thr_in, qg, E, rmax, amax, qa,
+                                   w.qmeta);
+            else
+                hipLaunchKernelGGL(coarse_thresholds_kernel, dim3((qa + 3) / 4), dim3(256), 0, st, thr_in, qg, E, rmax, qa, w.tauc);
+            CLIPMI_CHECK_LAUNCH("coarse_thresholds_kernel");
+            return 0;
+        };
         if (two_level) {
-            hipLaunchKernelGGL(coarse_thresholds_kernel, dim3((qa + 3) / 4), dim3(256), 0, st, w.tauc, qg, E, rmax, qa, w.tauc);
-            CLIPMI_CHECK_LAUNCH("coarse_thresholds_kernel(level 2)");
+            if (int rc = thresholds(w.tauc)) return rc;
             if (int rc = coarse_pass(S2, w.thr0, nullptr, nullptr, 0, nullptr, nullptr)) return rc;
         }
         // 2. coarse thresholds, 3. bf16 scan of all rows, 4. exact re-scoring, 5. select
-        hipLaunchKernelGGL(coarse_thresholds_kernel, dim3((qa + 3) / 4), dim3(256), 0, st, w.thr0, qg, E, rmax, qa, w.tauc);
-        CLIPMI_CHECK_LAUNCH("coarse_thresholds_kernel");
+        if (int rc = thresholds(w.thr0)) return rc;
         if (int rc = coarse_pass(N, nullptr, out_score_dev + (size_t)q0 * K, (long long*)out_id_dev + (size_t)q0 * K,
                                  (long long)id_base, scan_ev, w.last_m))
             return rc;
@@ -1045,15 +1203,52 @@ extern "C" size_t clipmi_topk_ip_coarse_workspace_bytes(int64_t N, int E, int Q,
 extern "C" int clipmi_topk_ip_coarse(const void* db_dev, const void* db_bf16_dev, int64_t N, int E, float rmax,
                                      const float* q_dev, int Q, int K, int64_t id_base, float* out_score_dev,
                                      int64_t* out_id_dev, void* ws_dev, size_t ws_bytes, void* stream) {
-    return topk_ip_coarse_impl(db_dev, db_bf16_dev, N, E, rmax, q_dev, Q, K, id_base, out_score_dev, out_id_dev, ws_dev,
-                               ws_bytes, stream, nullptr);
+    return topk_ip_coarse_impl(db_dev, db_bf16_dev, false, nullptr, 0.f, N, E, rmax, q_dev, Q, K, id_base, out_score_dev,
+                               out_id_dev, ws_dev, ws_bytes, stream, nullptr);
+}
+
+extern "C" int clipmi_quantize_rows_i8(const float* db_dev, int64_t N, int E, void* out_i8_dev, float* meta_dev, void* stream) {
+    if (!db_dev || !out_i8_dev || !meta_dev || N < 1 || E < 4 || E % 4 != 0)
+        return set_err(CLIPMI_EINVAL, "quantize_rows_i8: bad arguments (N=%lld E=%d)", (long long)N, E);
+    hipLaunchKernelGGL(quantize_rows_i8_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, as_stream(stream), db_dev,
+                       (long long)N, E, static_cast<signed char*>(out_i8_dev), reinterpret_cast<float2*>(meta_dev));
+    CLIPMI_CHECK_LAUNCH("quantize_rows_i8_kernel");
+    return 0;
+}
+
+extern "C" int clipmi_topk_ip_coarse_i8(const void* db_dev, const void* db_i8_dev, const float* meta_dev, float amax, int64_t N,
+                                        int E, float rmax, const float* q_dev, int Q, int K, int64_t id_base,
+                                        float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes, void* stream) {
+    return topk_ip_coarse_impl(db_dev, db_i8_dev, true, reinterpret_cast<const float2*>(meta_dev), amax, N, E, rmax, q_dev, Q,
+                               K, id_base, out_score_dev, out_id_dev, ws_dev, ws_bytes, stream, nullptr);
 }
 
 // Measurement hook: clipmi_topk_ip_coarse `reps` times with events around the bf16 scan kernel (Q <= 64).
+static int dbg_coarse_scan_ms(const void* db_dev, const void* db_bf16_dev, bool i8, const float2* rmeta, float amax, int64_t N,
+                              int E, float rmax, const float* q_dev, int Q, int K, float* out_score_dev,
+                              int64_t* out_id_dev, void* ws_dev, size_t ws_bytes, void* stream, int reps, float* scan_ms,
+                              long long* survivors);
+
 extern "C" int clipmi_dbg_topk_coarse_scan_ms(const void* db_dev, const void* db_bf16_dev, int64_t N, int E, float rmax,
                                               const float* q_dev, int Q, int K, float* out_score_dev, int64_t* out_id_dev,
                                               void* ws_dev, size_t ws_bytes, void* stream, int reps, float* scan_ms,
                                               long long* survivors) {
+    return dbg_coarse_scan_ms(db_dev, db_bf16_dev, false, nullptr, 0.f, N, E, rmax, q_dev, Q, K, out_score_dev, out_id_dev,
+                              ws_dev, ws_bytes, stream, reps, scan_ms, survivors);
+}
+
+extern "C" int clipmi_dbg_topk_coarse_i8_scan_ms(const void* db_dev, const void* db_i8_dev, const float* meta_dev, float amax,
+                                                 int64_t N, int E, float rmax, const float* q_dev, int Q, int K,
+                                                 float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes,
+                                                 void* stream, int reps, float* scan_ms, long long* survivors) {
+    return dbg_coarse_scan_ms(db_dev, db_i8_dev, true, reinterpret_cast<const float2*>(meta_dev), amax, N, E, rmax, q_dev, Q, K,
+                              out_score_dev, out_id_dev, ws_dev, ws_bytes, stream, reps, scan_ms, survivors);
+}
+
+static int dbg_coarse_scan_ms(const void* db_dev, const void* db_bf16_dev, bool i8, const float2* rmeta, float amax, int64_t N,
+                              int E, float rmax, const float* q_dev, int Q, int K, float* out_score_dev,
+                              int64_t* out_id_dev, void* ws_dev, size_t ws_bytes, void* stream, int reps, float* scan_ms,
+                              long long* survivors) {
     if (!scan_ms || reps < 1 || Q > COARSE_Q) return set_err(CLIPMI_EINVAL, "dbg_topk_coarse_scan_ms: bad arguments");
     hipEvent_t ev[2];
     if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess)
@@ -1061,8 +1256,8 @@ extern "C" int clipmi_dbg_topk_coarse_scan_ms(const void* db_dev, const void* db
     double total = 0.0;
     int rc = 0;
     for (int i = 0; i < reps && rc == 0; ++i) {
-        rc = topk_ip_coarse_impl(db_dev, db_bf16_dev, N, E, rmax, q_dev, Q, K, 0, out_score_dev, out_id_dev, ws_dev, ws_bytes,
-                                 stream, ev);
+        rc = topk_ip_coarse_impl(db_dev, db_bf16_dev, i8, rmeta, amax, N, E, rmax, q_dev, Q, K, 0, out_score_dev, out_id_dev,
+                                 ws_dev, ws_bytes, stream, ev);
         if (rc) break;
         if (hipEventSynchronize(ev[1]) != hipSuccess) { rc = set_err(CLIPMI_EHIP, "hipEventSynchronize"); break; }
         float ms = 0.f;

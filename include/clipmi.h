@@ -146,6 +146,19 @@ int clipmi_topk_ip_coarse(const void* db_dev, const void* db_bf16_dev, int64_t N
                           float* out_score_dev, int64_t* out_id_dev,
                           void* ws_dev, size_t ws_bytes, void* stream);
 
+/* ---- a12, int8 coarse copy: the same contract with a quarter of the f32 bytes per pass.
+ * clipmi_quantize_rows_i8 builds the copy: row r -> scale s_r = max|x_rk| / 127, q_rk = rint(x_rk / s_r) (int8
+ * [N][E]) and meta[r] = (s_r, a_r) with a_r >= ||x_r - s_r q_r||_2; `meta_dev` must have room for N rounded up to
+ * a multiple of 32 rows (+32), 2 floats each, zero-filled past N. clipmi_topk_ip_coarse_i8 scans it with
+ * v_mfma_i32_16x16x64_i8 (exact integer dot products) and keeps every row whose exact score could reach the
+ * running K-th best, by |x.y - s_r t_q D| <= a_r ||y|| + (rmax + amax) ||y - t_q p_q||; survivors are re-scored in
+ * exact f32 as above. `amax` >= every a_r, `rmax` >= every row norm. Workspace: clipmi_topk_ip_coarse_workspace_bytes. */
+int clipmi_quantize_rows_i8(const float* db_dev, int64_t N, int E, void* out_i8_dev, float* meta_dev, void* stream);
+int clipmi_topk_ip_coarse_i8(const void* db_dev, const void* db_i8_dev, const float* meta_dev, float amax,
+                             int64_t N, int E, float rmax, const float* q_dev, int Q, int K, int64_t id_base,
+                             float* out_score_dev, int64_t* out_id_dev,
+                             void* ws_dev, size_t ws_bytes, void* stream);
+
 /* ---- multi-GPU merge of per-shard partial results (no reference counterpart: the reference
  * is single-process). Inputs are R lists per query as gathered by one
  * all-gather: scores f32 [R][Q][K], ids int64 [R][Q][K] (id -1 = empty slot). Same ordering
@@ -196,6 +209,11 @@ int clipmi_dbg_topk_coarse_scan_ms(const void* db_dev, const void* db_bf16_dev, 
                                    const float* q_dev, int Q, int K, float* out_score_dev, int64_t* out_id_dev,
                                    void* ws_dev, size_t ws_bytes, void* stream, int reps, float* scan_ms,
                                    long long* survivors /* optional: rows kept by the coarse pass, summed over Q */);
+
+int clipmi_dbg_topk_coarse_i8_scan_ms(const void* db_dev, const void* db_i8_dev, const float* meta_dev, float amax,
+                                      int64_t N, int E, float rmax, const float* q_dev, int Q, int K,
+                                      float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes,
+                                      void* stream, int reps, float* scan_ms, long long* survivors);
 
 /* clipmi_encode_image `reps` times with HIP events around every launch of the GEMM whose
  * epilogue is `probe_epi` (1 = MLP c_fc + QuickGELU), on `stream`; synchronises;

@@ -153,8 +153,8 @@ def test_topk_errors(clipmi, gpu):
         idx.search(np.zeros((1, 512), np.float32), 100000)
 
 
-def _run_coarse(clipmi, gpu, db, q, K, id_base=0):
-    idx = clipmi.IndexFlatIP(512, device=gpu, coarse="bf16")
+def _run_coarse(clipmi, gpu, db, q, K, id_base=0, kind="bf16"):
+    idx = clipmi.IndexFlatIP(512, device=gpu, coarse=kind)
     idx.add(db)
     idx.id_base = id_base
     return idx.search(q, K)
@@ -202,6 +202,76 @@ def test_coarse_bf16_overflow_falls_back_to_exact(clipmi, gpu, topk_oracle):
     _assert_exact(D, I, Ds, Is, "coarse overflow fallback")
 
 
+@pytest.mark.parametrize("N,Q,K", [(65536, 1, 51), (70001, 16, 51), (100000, 33, 11), (131072, 64, 51),
+                                   (200003, 70, 51), (80000, 5, 300), (99999, 130, 21)])
+def test_coarse_int8_path_is_bit_exact(clipmi, gpu, topk_oracle, N, Q, K):
+    """int8 coarse scan (per-row scale, exact integer MFMA, Cauchy-Schwarz superset bound with each row's own
+    quantisation-error norm) + exact re-scoring returns the SAME bits as the oracle."""
+    rng = np.random.default_rng(N + Q + K + 1)
+    db = unit_rows(rng, N, 512)
+    q = unit_rows(rng, Q, 512)
+    D, I = _run_coarse(clipmi, gpu, db, q, K, id_base=7, kind="int8")
+    Ds, Is = topk_oracle.topk(db, q, K, id_base=7)
+    _assert_exact(D, I, Ds, Is, f"int8 coarse N={N} Q={Q} K={K}")
+
+
+def test_coarse_int8_hard_rows(clipmi, gpu, topk_oracle):
+    """Rows that quantise badly or oddly: row norms 0..3, one-hot rows (scale = the single component: huge error
+    bound for everything else in the row... none), rows with one dominant component (large per-row error norm),
+    an all-zero row, near-duplicates of the best row whose scores differ by far less than the int8 error, exact
+    ties, and a query with a dominant component. Results must still equal the oracle's bits."""
+    rng = np.random.default_rng(79)
+    N = 90000
+    db = unit_rows(rng, N, 512) * rng.uniform(0.0, 3.0, size=(N, 1)).astype(np.float32)
+    q = unit_rows(rng, 9, 512) * np.float32(1.7)
+    q[3, 17] = 2.5                                     # dominant query component
+    db[5] = 0.0
+    db[6] = 0.0; db[6, 17] = 1.0                       # one-hot
+    for j in range(50):                                # dominant component + small rest
+        db[2000 + j, 100 + j] = 4.0
+    base = db[np.argmax(db @ q[0])].copy()
+    for j in range(200):
+        db[1000 + 7 * j] = base * np.float32(1.0 - 1e-6 * j)
+    db[50000] = db[1000]
+    D, I = _run_coarse(clipmi, gpu, db, q, 51, kind="int8")
+    Ds, Is = topk_oracle.topk(db, q, 51)
+    _assert_exact(D, I, Ds, Is, "int8 coarse hard rows")
+
+
+def test_coarse_int8_overflow_falls_back_to_exact(clipmi, gpu, topk_oracle):
+    rng = np.random.default_rng(80)
+    N = 300000
+    v = unit_rows(rng, 1, 512)
+    db = np.repeat(v, N, axis=0)
+    db[123456] *= np.float32(1.5)
+    q = unit_rows(rng, 2, 512)
+    D, I = _run_coarse(clipmi, gpu, db, q, 20, kind="int8")
+    Ds, Is = topk_oracle.topk(db, q, 20)
+    _assert_exact(D, I, Ds, Is, "int8 coarse overflow fallback")
+
+
+def test_quantize_rows_i8_matches_numpy(clipmi, gpu):
+    """clipmi_quantize_rows_i8: scale = max|x| / 127, q = rint(x / scale) (round half to even), error norm >= the
+    true one and within 0.2 % of it."""
+    import torch
+    rng = np.random.default_rng(81)
+    x = (unit_rows(rng, 1000, 512) * rng.uniform(0.1, 3.0, size=(1000, 1))).astype(np.float32)
+    x[7] = 0.0
+    idx = clipmi.IndexFlatIP(512, device=gpu, coarse="int8")
+    idx.add(x)
+    q8, meta, amax, rmax = idx.matrix_i8()
+    torch.cuda.synchronize()
+    q8, meta = q8.cpu().numpy(), meta.cpu().numpy()
+    s = np.abs(x).max(axis=1) / np.float32(127.0)
+    s[s == 0] = 1.0
+    assert np.array_equal(meta[:1000, 0], s.astype(np.float32))
+    ref = np.clip(np.rint(x * (np.float32(1.0) / s.astype(np.float32))[:, None]), -127, 127).astype(np.int8)
+    assert np.array_equal(q8, ref)
+    err = np.linalg.norm(x.astype(np.float64) - s[:, None].astype(np.float64) * q8.astype(np.float64), axis=1)
+    assert (meta[:1000, 1] >= err).all() and (meta[:1000, 1] <= err * 1.002 + 1e-12).all()
+    assert (meta[1000:] == 0).all() and amax >= meta[:, 1].max() and rmax >= np.linalg.norm(x, axis=1).max()
+
+
 def test_full_size_10m_properties(clipmi, gpu, topk_oracle):
     """BASELINE.json's full size (10 M x 512, K = 51): size-independent properties instead of a CPU sort of
     10 M rows — (i) the coarse-then-exact path and the exact f32 scan return identical bits; (ii) every
@@ -224,6 +294,11 @@ def test_full_size_10m_properties(clipmi, gpu, topk_oracle):
     De, Ie = exact.search(q, K)
     Dc, Ic = coarse.search(q, K)
     _assert_exact(Dc, Ic, De, Ie, "coarse vs exact at 10M")
+    del coarse
+    coarse8 = clipmi.IndexFlatIP(512, device=gpu, coarse="int8"); coarse8.add(db)
+    D8, I8 = coarse8.search(q, K)
+    _assert_exact(D8, I8, De, Ie, "int8 coarse vs exact at 10M")
+    del coarse8
     assert list(Ie[3, :2]) == [17, 9_999_999] and De[3, 0] == De[3, 1]
     qh = q.cpu().numpy()
     for j in (0, 3, 31, 63):
@@ -246,7 +321,7 @@ def test_full_size_10m_properties(clipmi, gpu, topk_oracle):
     parts_s, parts_i = [], []
     for r in range(8):
         lo, hi = clipmi.shard_bounds(N, 8, r)
-        sh = clipmi.IndexFlatIP(512, device=gpu, coarse="bf16")
+        sh = clipmi.IndexFlatIP(512, device=gpu, coarse="bf16" if r % 2 else "int8")
         sh.add(db[lo:hi]); sh.id_base = lo
         s_, i_ = sh.search(q, K)
         parts_s.append(s_); parts_i.append(i_)

@@ -30,7 +30,8 @@ def main():
     def avg(d, key):
         xs = [v for k, vs in d.items() if key in k for v in vs]
         return sum(xs) / len(xs) if xs else None
-    for label, key in (("scan", "scan_topk_f32_kernel<512, false"), ("scan_coarse", "scan_coarse_bf16_kernel<512, 4, false>"),
+    for label, key in (("scan", "scan_topk_f32_kernel<512, false"), ("scan_coarse", "scan_coarse_kernel<512, 4, false, false>"),
+                       ("scan_coarse_i8", "scan_coarse_kernel<512, 4, false, true>"),
                        ("rescore", "rescore_pairs_kernel"), ("gemm_c_fc", "gemm256p_bf16_nt_kernel<1>"),
                        ("gemm_qkv", "gemm256p_bf16_nt_kernel<0>"), ("gemm_resid", "gemm256p_bf16_nt_kernel<2>"),
                        ("gemm128_c_fc", "gemm_bf16_nt_kernel<1>"), ("gemm128_resid", "gemm_bf16_nt_kernel<2>"),
