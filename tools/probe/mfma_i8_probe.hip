@@ -1,3 +1,4 @@
+// build: hipcc --offload-arch=gfx950 -O2 tools/probe/mfma_i8_probe.hip -o tools/probe/mfma_i8_probe   (run on the GPU box)
 // development probe: operand layout of v_mfma_i32_16x16x64_i8 (gfx950). D[i][j] = sum_k A[i][k] B[j][k]?
 #include <hip/hip_runtime.h>
 #include <cstdio>
