@@ -12,9 +12,11 @@ Backends:
   * `lmdb` (py-lmdb) when importable: the reference's exact environment / table names, so existing
     databases open unchanged. Commits are per BATCH, not per image (the reference fsyncs once per
     image, build-index.py:42, and once per row, :87).
-  * otherwise an append-only packed directory with the same three tables (py-lmdb and liblmdb are
-    not installed in the build image; on-disk LMDB compatibility is therefore PARITY UNPINNED here).
-An existing LMDB environment is never opened with the packed backend: that raises instead.
+  * `lmdbfile`: an existing LMDB environment (`data.mdb`) on a machine WITHOUT py-lmdb is opened READ-ONLY by
+    the own format reader in lmdbfile.py: everything query-index.py does works (it only reads); adding images
+    needs py-lmdb or `convert()` into a packed store first. Format restated from mdb.c: PARITY UNPINNED here.
+  * otherwise an append-only packed directory with the same three tables.
+`export_lmdb()` writes any store out as an LMDB environment for the reference's own tools.
 """
 import os
 import struct
@@ -62,6 +64,44 @@ class _LmdbBackend:
         self.env.close()
 
 
+class ReadOnlyStore(RuntimeError):
+    pass
+
+
+class _LmdbFileBackend:
+    """Read-only: lmdbfile.LmdbReader over an existing environment (no py-lmdb on this machine)."""
+
+    def __init__(self, path, dim):
+        from .lmdbfile import LmdbReader
+        self.path = path
+        self.r = LmdbReader(path)
+        self.dbs = {}
+        for t in ("fn_db", "skip_db", "idx_db"):
+            try:
+                self.dbs[t] = self.r.open_db(t.encode())
+            except KeyError:
+                self.dbs[t] = None                     # table never created (e.g. idx_db before the first build)
+
+    def get(self, table, key):
+        db = self.dbs[table]
+        return None if db is None else self.r.get(db, key)
+
+    def put_many(self, table, items):
+        raise ReadOnlyStore(f"{self.path} is an LMDB environment opened read-only (the `lmdb` module is not installed): "
+                            "install py-lmdb, or convert it once with clipmi.store.convert(src, dst)")
+
+    def count(self, table):
+        db = self.dbs[table]
+        return 0 if db is None else self.r.entries(db)
+
+    def items_sorted(self, table):
+        db = self.dbs[table]
+        return iter(()) if db is None else self.r.items(db)
+
+    def close(self):
+        self.r.close()
+
+
 class _PackedBackend:
     """Directory of append-only logs: <table>.log = repeated [u32 klen][u32 vlen][key][value]; the last
     record for a key wins. Loaded into dicts at open (1 M x 2 KiB vectors = 2 GiB: values of fn_db are
@@ -71,8 +111,7 @@ class _PackedBackend:
 
     def __init__(self, path, dim):
         if os.path.exists(os.path.join(path, "data.mdb")):
-            raise RuntimeError(f"{path} is an LMDB environment but the `lmdb` module is not installed; "
-                               "install py-lmdb to open existing databases")
+            raise RuntimeError(f"{path} is an LMDB environment: open it with backend 'lmdb' or 'lmdbfile'")
         os.makedirs(path, exist_ok=True)
         self.path = path
         self.index = {t: {} for t in self.TABLES}        # key -> (offset, length) of the value
@@ -136,9 +175,12 @@ class VectorStore:
     def __init__(self, path="vectors.lmdb", dim=512, backend=None):
         self.dim = dim
         if backend is None:
-            backend = "lmdb" if _have_lmdb() else "packed"
+            is_env = os.path.exists(os.path.join(path, "data.mdb"))
+            backend = "lmdb" if _have_lmdb() else ("lmdbfile" if is_env else "packed")
         self.backend_name = backend
-        self.b = _LmdbBackend(path, dim) if backend == "lmdb" else _PackedBackend(path, dim)
+        self.read_only = backend == "lmdbfile"
+        self.b = (_LmdbBackend(path, dim) if backend == "lmdb" else
+                  _LmdbFileBackend(path, dim) if backend == "lmdbfile" else _PackedBackend(path, dim))
 
     # ---- fn_db ------------------------------------------------------------------------------
     def has_vector(self, key):
@@ -178,11 +220,43 @@ class VectorStore:
         for i, (k, v) in enumerate(self.b.items_sorted("fn_db")):
             mat[i] = np.frombuffer(v, dtype="<f4")
             paths.append(k)
-        self.b.put_many("idx_db", [(str(i).encode(), p) for i, p in enumerate(paths)])
+        if self.read_only:
+            # a read-only environment keeps the idx_db its last build wrote; it must describe the same rows
+            if self.b.count("idx_db") != n or any(self.idx_get(i) != p for i, p in ((0, paths[0]), (n - 1, paths[-1])) if n):
+                raise ReadOnlyStore("idx_db of the read-only environment does not match fn_db's key order; "
+                                    "convert the store (clipmi.store.convert) and re-run the build")
+        else:
+            self.b.put_many("idx_db", [(str(i).encode(), p) for i, p in enumerate(paths)])
         return mat, paths
 
     def idx_get(self, i):
         return self.b.get("idx_db", str(int(i)).encode())                    # query-index.py:92,117-118
 
+    def export_lmdb(self, path):
+        """Write this store out as an LMDB environment (data.mdb) with the reference's three tables, for the
+        reference's own tools (lmdbfile.write_environment: one bulk transaction)."""
+        from .lmdbfile import write_environment
+        write_environment(path, {t.encode(): list(self.b.items_sorted(t)) for t in ("fn_db", "skip_db", "idx_db")},
+                          mapsize=MAP_SIZE)
+
     def close(self):
         self.b.close()
+
+
+def convert(src, dst, dim=512, dst_backend="packed"):
+    """Copy every table of the store at `src` (any backend, e.g. an LMDB environment opened read-only) into a
+    new store at `dst`."""
+    a, b = VectorStore(src, dim=dim), VectorStore(dst, dim=dim, backend=dst_backend)
+    try:
+        for t in ("fn_db", "skip_db", "idx_db"):
+            batch = []
+            for kv in a.b.items_sorted(t):
+                batch.append(kv)
+                if len(batch) >= 4096:
+                    b.b.put_many(t, batch)
+                    batch = []
+            if batch:
+                b.b.put_many(t, batch)
+    finally:
+        a.close()
+        b.close()

@@ -173,3 +173,98 @@ def test_query_repl_paging_and_similarity(clipmi, tmp_path, monkeypatch, topk_or
     assert [int(l.split()[1]) for l in res] == list(I[0][1:]) and I[0][0] == 7
     assert res[0] == f"{D[0][1]:.4f} {I[0][1]} /p/{I[0][1]:04d}.jpg"
     db.close()
+
+
+def _fake_reference_env(clipmi, path, n, rng, with_idx=True):
+    """An environment laid out like the reference's vectors.lmdb (build-index.py:22-24,51,61,87): fn_db path ->
+    2048-B vector (always on an overflow page), skip_db path -> b"1", idx_db decimal -> path."""
+    from clipmi.lmdbfile import write_environment
+    keys = sorted({f"photos/{rng.integers(0, 10 ** 9):09d}/img_{i:05d}.jpg".encode() for i in range(n)})
+    vecs = {k: rng.standard_normal(512).astype("<f4") for k in keys}
+    tables = {b"fn_db": [(k, vecs[k].tobytes()) for k in keys],
+              b"skip_db": [(b"photos/broken_%d.jpg" % i, b"1") for i in range(7)]}
+    if with_idx:
+        tables[b"idx_db"] = [(str(i).encode(), k) for i, k in enumerate(keys)]
+    write_environment(path, tables)
+    return keys, vecs
+
+
+@pytest.mark.parametrize("n", [1, 40, 3000])
+def test_lmdb_file_reader_roundtrip(clipmi, tmp_path, n):
+    """next-2: the own LMDB-format reader (used when py-lmdb is absent) against environments written from the
+    same format description: point lookups through 1-3 tree levels, overflow-page values, key-order iteration,
+    entry counts, missing keys. (PARITY UNPINNED: no file from the real library is available here.)"""
+    from clipmi.lmdbfile import LmdbReader
+    rng = np.random.default_rng(n)
+    p = str(tmp_path / "vectors.lmdb")
+    keys, vecs = _fake_reference_env(clipmi, p, n, rng)
+    r = LmdbReader(p)
+    fn, sk, ix = r.open_db(b"fn_db"), r.open_db(b"skip_db"), r.open_db(b"idx_db")
+    assert r.entries(fn) == len(keys) and r.entries(sk) == 7 and r.entries(ix) == len(keys)
+    assert (fn.depth >= 2) == (len(keys) > 100)
+    for k in (keys[0], keys[-1], keys[len(keys) // 2]):
+        assert r.get(fn, k) == vecs[k].tobytes()
+    assert r.get(fn, b"photos/none.jpg") is None and r.get(fn, b"") is None and r.get(fn, b"zzzz") is None
+    assert [k for k, _ in r.items(fn)] == keys
+    assert all(v == vecs[k].tobytes() for k, v in r.items(fn))
+    for i in (0, len(keys) - 1):
+        assert r.get(ix, str(i).encode()) == keys[i]
+    assert r.get(sk, b"photos/broken_3.jpg") == b"1"
+    with pytest.raises(KeyError):
+        r.open_db(b"nope")
+    r.close()
+
+
+def test_vector_store_opens_lmdb_env_read_only_without_pylmdb(clipmi, tmp_path):
+    """An existing vectors.lmdb on a machine without py-lmdb: VectorStore picks the read-only format reader;
+    the query side (get_vector, idx_get, assemble in key order) works; writes are refused; convert() copies it
+    into a packed store that can be extended; export_lmdb() writes a store back out as an environment."""
+    pytest.importorskip("numpy")
+    try:
+        import lmdb  # noqa: F401
+        pytest.skip("py-lmdb is installed: the lmdb backend is used instead")
+    except ImportError:
+        pass
+    rng = np.random.default_rng(5)
+    p = str(tmp_path / "vectors.lmdb")
+    keys, vecs = _fake_reference_env(clipmi, p, 300, rng)
+    st = clipmi.store.VectorStore(p, dim=512)
+    assert st.backend_name == "lmdbfile" and st.read_only and st.count() == 300
+    assert np.array_equal(st.get_vector(keys[7])[0], vecs[keys[7]])
+    assert st.idx_get(299) == keys[299] and st.is_skipped("photos/broken_0.jpg") and not st.is_skipped("x")
+    mat, paths = st.assemble()
+    assert paths == keys and np.array_equal(mat[5], vecs[keys[5]])
+    with pytest.raises(clipmi.store.ReadOnlyStore):
+        st.put_vectors(["a"], np.zeros((1, 512), np.float32))
+    st.close()
+    q = str(tmp_path / "vectors.packed")
+    clipmi.store.convert(p, q)
+    st2 = clipmi.store.VectorStore(q, dim=512)
+    assert st2.backend_name == "packed" and st2.count() == 300 and st2.idx_get(0) == keys[0]
+    st2.put_vectors(["zzz/new.jpg"], np.ones((1, 512), np.float32))
+    assert st2.count() == 301
+    back = str(tmp_path / "exported.lmdb")
+    st2.export_lmdb(back)
+    st2.close()
+    st3 = clipmi.store.VectorStore(back, dim=512)
+    assert st3.backend_name == "lmdbfile" and st3.count() == 301 and st3.has_vector("zzz/new.jpg")
+    st3.close()
+
+
+def test_lmdb_file_reader_deep_tree_small_pages(clipmi, tmp_path):
+    """512-byte pages force a 3-level tree with a few thousand keys: branch descent, separators, multi-page
+    overflow runs."""
+    from clipmi.lmdbfile import LmdbReader, write_environment
+    rng = np.random.default_rng(11)
+    keys = sorted({b"k%07d" % rng.integers(0, 10 ** 7) for _ in range(4000)})
+    vals = {k: bytes(rng.integers(0, 256, int(rng.integers(0, 1500)), dtype=np.uint8)) for k in keys}
+    p = str(tmp_path / "deep.lmdb")
+    write_environment(p, {b"t": [(k, vals[k]) for k in keys]}, psize=512)
+    r = LmdbReader(p)
+    t = r.open_db(b"t")
+    assert r.psize == 512 and t.depth >= 3 and r.entries(t) == len(keys)
+    for k in keys[::37]:
+        assert r.get(t, k) == vals[k]
+    assert r.get(t, b"k0000000x") is None and r.get(t, b"a") is None
+    assert [k for k, _ in r.items(t)] == keys
+    r.close()
