@@ -1,5 +1,6 @@
 // vit_kernels.hip — launchers for the non-GEMM tower kernels and their debug entry points.
 #include "vit_kernels.hpp"
+#include <cstdlib>
 
 namespace clipmi {
 
@@ -44,6 +45,16 @@ int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int 
         return 0;
     }
     const int nt = (L + 15) / 16;
+    // development switch for A/B runs on one box: CLIPMI_ATTN52=0 keeps ViT-B/32 on attention_kernel<4>
+    static const bool use52 = [] { const char* e = getenv("CLIPMI_ATTN52"); return !e || atoi(e) != 0; }();
+    if (L >= 49 && L <= 52 && !causal && tr && use52) {
+        // ViT-B/32: the low-register form (24 waves per CU); tr = 0 keeps the plain-read reference kernel for tests
+        const long long items = (long long)B * heads;
+        const size_t lds = 4 * 52 * 128;
+        hipLaunchKernelGGL(attention52_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, st, qkv, out, B, L, heads);
+        CLIPMI_CHECK_LAUNCH("attention52_kernel");
+        return 0;
+    }
 #define ATT(NT_)                                                                                         \
     if (nt <= NT_) {                                                                                     \
         if (causal) return tr ? launch_attn_t<NT_, true, true>(qkv, out, B, L, heads, st)                \

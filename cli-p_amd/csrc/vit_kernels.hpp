@@ -344,6 +344,138 @@ __global__ void __launch_bounds__(256) attention_kernel(const unsigned short* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// attention52_kernel: the ViT-B/32 shape (49 <= L <= 52, 4 key/query tiles, no mask) with the query tiles
+// walked in a LOOP instead of all at once. attention_kernel<4,...> keeps 16 score tiles + 16 output tiles +
+// 16 fragments live (~120 registers with the AGPRs: 4 waves per SIMD) and stages 64 V rows per wave (32 KiB per
+// workgroup: 4 workgroups per CU); its lifetime per wave is ~20 us of mostly latency, so residency is its
+// throughput (tools/attn_cliff.py: steps at every 16 waves per CU). Here per query tile: 4 score tiles, softmax,
+// 4 output tiles, store; K fragments loaded once, the next tile's Q fragments in flight during the current tile,
+// V staged once as 52 rows (6.5 KiB per wave -> 26 KiB per workgroup, six workgroups = 24 waves per CU); keys
+// >= L carry zero weight and their transposed reads are redirected to row 51 (finite filler). Same arithmetic
+// per (query, key, d) as attention_kernel: bit-identical output.
+// ---------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256, 6) attention52_kernel(const unsigned short* __restrict__ qkv,
+                                                                    unsigned short* __restrict__ out, int B, int L,
+                                                                    int heads) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = 4, ROWS = 52;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int W = heads * 64;
+    const long long item = (long long)blockIdx.x * 4 + wave;      // (b, h)
+    if (item >= (long long)B * heads) return;                       // wave-uniform; no block barriers below
+    const int b = (int)(item / heads), h = (int)(item - (long long)b * heads);
+    const unsigned short* base = qkv + (size_t)b * L * 3 * W + h * 64;
+    const size_t rs = (size_t)3 * W;
+    char* vt = smem + wave * (ROWS * 128);
+
+    // ---- stage V rows [0, 52): 8 rows x 128 B per wave-instruction, the last one half masked
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int row = i * 8 + (lane >> 3);
+        const int srcrow = row < L ? row : L - 1;                   // rows L..51: finite filler, weight 0
+        const uint4 d = *reinterpret_cast<const uint4*>(base + (size_t)srcrow * rs + 2 * W + (lane & 7) * 8);
+        if (row < ROWS) *reinterpret_cast<uint4*>(vt + row * 128 + (lane & 7) * 16) = d;
+    }
+    // ---- K fragments of all four key tiles (kept), Q fragments of tile 0
+    bf16x8 kf[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int row = t * 16 + fr;
+        row = row < L ? row : L - 1;
+        const unsigned short* pr = base + (size_t)row * rs + W + fg * 8;
+        kf[t][0] = *reinterpret_cast<const bf16x8*>(pr);
+        kf[t][1] = *reinterpret_cast<const bf16x8*>(pr + 32);
+    }
+    auto q_ptr = [&](int qt) {
+        int row = qt * 16 + fr;
+        row = row < L ? row : L - 1;
+        return base + (size_t)row * rs + fg * 8;
+    };
+    bf16x8 qn0 = *reinterpret_cast<const bf16x8*>(q_ptr(0));
+    bf16x8 qn1 = *reinterpret_cast<const bf16x8*>(q_ptr(0) + 32);
+    // transposed-read addresses of the two 32-key steps (see attention_kernel); key rows >= 52 -> row 51
+    const int k00 = 4 * fg + (fr >> 2);
+    const int krow[4] = {k00, k00 + 16, k00 + 32, (k00 + 48 < ROWS ? k00 + 48 : ROWS - 1)};
+    const char* vcol = vt + (4 * (fr & 3)) * 2;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's V tile is in LDS
+    __builtin_amdgcn_wave_barrier();
+
+#pragma unroll 1
+    for (int qt = 0; qt < NT; ++qt) {
+        const bf16x8 q0 = qn0, q1 = qn1;
+        if (qt + 1 < NT) {
+            qn0 = *reinterpret_cast<const bf16x8*>(q_ptr(qt + 1));
+            qn1 = *reinterpret_cast<const bf16x8*>(q_ptr(qt + 1) + 32);
+        }
+        f32x4 s[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], q0, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][1], q1, a, 0, 0, 0);
+            s[kt] = a;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ki = kt * 16 + 4 * fg + r;
+                float x = s[kt][r] * 0.125f;
+                if (ki >= L) x = -INFINITY;
+                s[kt][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[kt][r] - mx);             // key 0 is never masked: mx is finite
+                s[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) s[kt] *= inv;
+
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f32x4 lo = s[2 * ks], hi = s[2 * ks + 1];
+            const uint4 u = make_uint4(pack_bf16x2(lo.x, lo.y), pack_bf16x2(lo.z, lo.w), pack_bf16x2(hi.x, hi.y),
+                                       pack_bf16x2(hi.z, hi.w));
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, u);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(vcol + krow[2 * ks] * 128 + dt * 32));
+                const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(vcol + krow[2 * ks + 1] * 128 + dt * 32));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                const s16x8 t = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, t), pf, o[dt], 0, 0, 0);
+            }
+        }
+        const int qi = qt * 16 + fr;
+        if (qi < L) {
+            unsigned short* dst = out + ((size_t)b * L + qi) * W + h * 64 + 4 * fg;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<uint2*>(dst + dt * 16) = make_uint2(pack_bf16x2(o[dt].x, o[dt].y), pack_bf16x2(o[dt].z, o[dt].w));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Flash-style attention for long sequences (L > 80: ViT-B/16 L = 197, ViT-L/14 L = 257,
 // ViT-L/14@336 L = 577), head dim 64, no mask. A workgroup of WPB waves owns one (sequence, head) and
 // WPB consecutive 64-query blocks (one per wave); keys/values stream through in 64-key blocks that the

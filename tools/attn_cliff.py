@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import clipmi
 L = clipmi._lib.lib()
 dev = torch.device("cuda:0")
-for B in (256, 320, 340, 341, 342, 360, 400, 420, 426, 427, 430, 435, 512):
+for B in ([int(x) for x in sys.argv[1:]] or (256, 320, 340, 341, 342, 360, 400, 420, 426, 427, 430, 435, 512)):
     qkv = (torch.randn(B * 50, 2304, device=dev) * 1.5).to(torch.bfloat16)
     out = torch.empty(B * 50, 768, dtype=torch.bfloat16, device=dev)
     def run():
