@@ -35,7 +35,7 @@ def main():
                        ("rescore", "rescore_pairs_kernel"), ("gemm_c_fc", "gemm256p_bf16_nt_kernel<1>"),
                        ("gemm_qkv", "gemm256p_bf16_nt_kernel<0>"), ("gemm_resid", "gemm256p_bf16_nt_kernel<2>"),
                        ("gemm128_c_fc", "gemm_bf16_nt_kernel<1>"), ("gemm128_resid", "gemm_bf16_nt_kernel<2>"),
-                       ("attention", "attention_kernel"), ("layernorm", "layernorm_kernel")):
+                       ("attention", "attention"), ("layernorm", "layernorm_kernel")):
         fk, wk = avg(fetch, key), avg(write, key)
         if fk is None and wk is None:
             continue
