@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libclipmi.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 F32, BF16, U8 = 0, 1, 2
 
 # every symbol include/clipmi.h declares (tests check the .so exports all of them)
@@ -19,6 +19,7 @@ SYMBOLS = [
     "clipmi_topk_ip_workspace_bytes", "clipmi_topk_ip",
     "clipmi_topk_ip_coarse_workspace_bytes", "clipmi_topk_ip_coarse", "clipmi_dbg_topk_coarse_scan_ms",
     "clipmi_quantize_rows_i8", "clipmi_topk_ip_coarse_i8", "clipmi_dbg_topk_coarse_i8_scan_ms",
+    "clipmi_dbg_quantize_rows_fp8", "clipmi_dbg_gemm_fp8",
     "clipmi_merge_topk_workspace_bytes", "clipmi_merge_topk", "clipmi_merge_topk_packed",
     "clipmi_l2_normalize_rows", "clipmi_last_error", "clipmi_abi_version",
     "clipmi_dbg_gemm_bf16", "clipmi_dbg_layernorm", "clipmi_dbg_attention", "clipmi_dbg_topk_scan_ms",
@@ -37,7 +38,9 @@ class Tower(C.Structure):
         "off_layers", "layer_stride",
         "lo_ln1_w", "lo_ln1_b", "lo_qkv_w", "lo_qkv_b", "lo_out_w", "lo_out_b",
         "lo_ln2_w", "lo_ln2_b", "lo_fc_w", "lo_fc_b", "lo_proj_w", "lo_proj_b",
-        "off_ln_post_w", "off_ln_post_b", "off_out_proj")]
+        "off_ln_post_w", "off_ln_post_b", "off_out_proj")] + [
+        ("weight_format", C.c_int32), ("reserved0", C.c_int32)] + [(n, C.c_uint64) for n in (
+        "lo_qkv_s", "lo_out_s", "lo_fc_s", "lo_proj_s")]
 
 
 class ClipmiError(RuntimeError):
@@ -77,6 +80,10 @@ def lib():
     L.clipmi_topk_ip_coarse_workspace_bytes.argtypes = [i64, i32, i32, i32]
     L.clipmi_topk_ip_coarse.restype = i32
     L.clipmi_topk_ip_coarse.argtypes = [vp, vp, i64, i32, C.c_float, vp, i32, i32, i64, vp, vp, vp, sz, vp]
+    L.clipmi_dbg_quantize_rows_fp8.restype = i32
+    L.clipmi_dbg_quantize_rows_fp8.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.clipmi_dbg_gemm_fp8.restype = i32
+    L.clipmi_dbg_gemm_fp8.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.clipmi_quantize_rows_i8.restype = i32
     L.clipmi_quantize_rows_i8.argtypes = [vp, i64, i32, vp, vp, vp]
     L.clipmi_topk_ip_coarse_i8.restype = i32

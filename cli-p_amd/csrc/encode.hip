@@ -19,6 +19,8 @@ struct Ws {
     unsigned short* big;
     unsigned short* pooled;
     int* rowidx;
+    unsigned char* a8;        // weight_format 1: the current GEMM's A operand as e4m3 [B*L][<= 4W]
+    float* a_scale;           //                  and its row scales [B*L]
 };
 
 size_t carve(const clipmi_tower* t, int B, void* base, size_t cap, Ws* out) {
@@ -32,6 +34,10 @@ size_t carve(const clipmi_tower* t, int B, void* base, size_t cap, Ws* out) {
     w.big = ar.take<unsigned short>(rows * 4 * W);
     w.pooled = ar.take<unsigned short>((size_t)B * W);
     w.rowidx = ar.take<int>((size_t)B);
+    if (t->weight_format == 1) {
+        w.a8 = ar.take<unsigned char>(rows * 4 * W);
+        w.a_scale = ar.take<float>(rows);
+    }
     if (out) *out = w;
     return ar.off + 256;
 }
@@ -46,6 +52,10 @@ int check_tower(const clipmi_tower* t, int kind, const char* who) {
         return set_err(CLIPMI_EUNSUPPORTED,
                        "%s: width=%d heads=%d mlp=%d embed=%d (need width %% 128 == 0 <= 1024, head dim 64, embed %% 128 == 0)",
                        who, t->width, t->heads, t->mlp, t->embed);
+    if (t->weight_format != 0 && t->weight_format != 1)
+        return set_err(CLIPMI_EINVAL, "%s: weight_format %d", who, t->weight_format);
+    if (t->weight_format == 1 && t->width % 256 != 0)
+        return set_err(CLIPMI_EUNSUPPORTED, "%s: fp8 weights need width %% 256 == 0 (width %d)", who, t->width);
     if (t->tokens > 80 && kind == 1)
         return set_err(CLIPMI_EUNSUPPORTED, "%s: %d tokens (causal attention covers <= 80)", who, t->tokens);
     return 0;
@@ -56,29 +66,40 @@ const T* at(const void* blob, uint64_t off) {
     return reinterpret_cast<const T*>(static_cast<const char*>(blob) + off);
 }
 
-// the 12 (or 24) residual attention blocks shared by both towers
+// the 12 (or 24) residual attention blocks shared by both towers. weight_format 1 (BASELINE.json configs[4]): the
+// four linear layers of a block run on the FP8 matrix cores - weights are e4m3 with one scale per output channel
+// (packed by weights.py), the bf16 activation rows are quantised to e4m3 with one scale per row right before each
+// GEMM (quantize_rows_fp8_kernel), gemm256f8 applies both scales in its epilogue. LayerNorm, attention, the
+// residual stream, patch embedding and the final projection are unchanged.
 int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int causal, hipStream_t st) {
     const int W = t->width, L = t->tokens, M = B * L;
+    const bool fp8 = t->weight_format == 1;
+    auto linear = [&](const unsigned short* A, int K, uint64_t w_off, uint64_t s_off, uint64_t b_off, void* out, int N,
+                      int epi) -> int {
+        GemmArgs g{};
+        g.bias = at<float>(blob, b_off); g.out = out; g.M = M; g.N = N; g.K = K;
+        if (fp8) {
+            if (int rc = launch_quantize_rows_fp8(A, w.a8, w.a_scale, M, K, st)) return rc;
+            g.A = reinterpret_cast<const unsigned short*>(w.a8);
+            g.W = at<unsigned short>(blob, w_off);
+            g.a_scale = w.a_scale; g.w_scale = at<float>(blob, s_off);
+            return launch_gemm_fp8(g, epi, st);
+        }
+        g.A = A; g.W = at<unsigned short>(blob, w_off);
+        return launch_gemm_algo(g, epi, 0, st);
+    };
     for (int l = 0; l < t->layers; ++l) {
         const uint64_t lb = t->off_layers + (uint64_t)l * t->layer_stride;
         LnArgs ln{w.x, at<float>(blob, lb + t->lo_ln1_w), at<float>(blob, lb + t->lo_ln1_b), w.h, nullptr, 1, M, W, 1};
         if (int rc = launch_layernorm(ln, st)) return rc;
-        GemmArgs g{};
-        g.A = w.h; g.W = at<unsigned short>(blob, lb + t->lo_qkv_w); g.bias = at<float>(blob, lb + t->lo_qkv_b);
-        g.out = w.big; g.M = M; g.N = 3 * W; g.K = W;
-        if (int rc = launch_gemm_algo(g, EPI_BIAS_BF16, 0, st)) return rc;
+        if (int rc = linear(w.h, W, lb + t->lo_qkv_w, lb + t->lo_qkv_s, lb + t->lo_qkv_b, w.big, 3 * W, EPI_BIAS_BF16)) return rc;
         if (int rc = launch_attention(w.big, w.h, B, L, t->heads, causal, 1, st)) return rc;
-        g.A = w.h; g.W = at<unsigned short>(blob, lb + t->lo_out_w); g.bias = at<float>(blob, lb + t->lo_out_b);
-        g.out = w.x; g.N = W; g.K = W;
-        if (int rc = launch_gemm_algo(g, EPI_BIAS_RESID_F32, 0, st)) return rc;
+        if (int rc = linear(w.h, W, lb + t->lo_out_w, lb + t->lo_out_s, lb + t->lo_out_b, w.x, W, EPI_BIAS_RESID_F32)) return rc;
         ln.w = at<float>(blob, lb + t->lo_ln2_w); ln.b = at<float>(blob, lb + t->lo_ln2_b);
         if (int rc = launch_layernorm(ln, st)) return rc;
-        g.A = w.h; g.W = at<unsigned short>(blob, lb + t->lo_fc_w); g.bias = at<float>(blob, lb + t->lo_fc_b);
-        g.out = w.big; g.N = 4 * W; g.K = W;
-        if (int rc = launch_gemm_algo(g, EPI_BIAS_QGELU_BF16, 0, st)) return rc;
-        g.A = w.big; g.W = at<unsigned short>(blob, lb + t->lo_proj_w); g.bias = at<float>(blob, lb + t->lo_proj_b);
-        g.out = w.x; g.N = W; g.K = 4 * W;
-        if (int rc = launch_gemm_algo(g, EPI_BIAS_RESID_F32, 0, st)) return rc;
+        if (int rc = linear(w.h, W, lb + t->lo_fc_w, lb + t->lo_fc_s, lb + t->lo_fc_b, w.big, 4 * W, EPI_BIAS_QGELU_BF16)) return rc;
+        if (int rc = linear(w.big, 4 * W, lb + t->lo_proj_w, lb + t->lo_proj_s, lb + t->lo_proj_b, w.x, W, EPI_BIAS_RESID_F32))
+            return rc;
     }
     return 0;
 }

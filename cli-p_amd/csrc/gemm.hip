@@ -1,5 +1,6 @@
 // gemm.hip — instantiation and launch of the bf16 NT GEMM (see gemm.hpp).
 #include "gemm256p.hpp"
+#include "gemm256f8.hpp"
 #include <hip/hip_ext.h>
 #include <cstdlib>
 
@@ -123,6 +124,34 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st) {
     return set_err(CLIPMI_EINVAL, "gemm: unknown epilogue %d", epi);
 }
 
+template <int EPI>
+static int launch_epi256f8(const GemmArgs& g, hipStream_t st) {
+    const int grid = (g.N / 256) * ((g.M + 255) / 256);
+    static thread_local bool opted = false;
+    if (!opted) {
+        if (hipFuncSetAttribute((const void*)gemm256f8_nt_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) !=
+            hipSuccess)
+            return set_err(CLIPMI_EHIP, "hipFuncSetAttribute(gemm256f8, %d B LDS)", G256_LDS);
+        opted = true;
+    }
+    hipLaunchKernelGGL(gemm256f8_nt_kernel<EPI>, dim3(grid), dim3(512), G256_LDS, st, g);
+    CLIPMI_CHECK_LAUNCH("gemm256f8_nt_kernel");
+    return 0;
+}
+
+int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st) {
+    if (g.M < 1 || g.N % 256 != 0 || g.K % 128 != 0 || g.K < 256)
+        return set_err(CLIPMI_EINVAL, "gemm_fp8: M=%d N=%d K=%d (need N %% 256 == 0, K %% 128 == 0, K >= 256)", g.M, g.N, g.K);
+    if (!g.A || !g.W || !g.out || !g.a_scale || !g.w_scale) return set_err(CLIPMI_EINVAL, "gemm_fp8: NULL pointer");
+    switch (epi) {
+        case EPI_BIAS_BF16: return launch_epi256f8<EPI_BIAS_BF16>(g, st);
+        case EPI_BIAS_QGELU_BF16: return launch_epi256f8<EPI_BIAS_QGELU_BF16>(g, st);
+        case EPI_BIAS_RESID_F32: return launch_epi256f8<EPI_BIAS_RESID_F32>(g, st);
+        case EPI_F32: return launch_epi256f8<EPI_F32>(g, st);
+    }
+    return set_err(CLIPMI_EINVAL, "gemm_fp8: epilogue %d", epi);
+}
+
 int launch_gemm(const GemmArgs& g, int epi, hipStream_t st) {
     if (g.M < 1 || g.N < 1 || g.K < 1 || g.N % GEMM_BN != 0 || g.K % GEMM_BK != 0)
         return set_err(CLIPMI_EINVAL, "gemm: M=%d N=%d K=%d (need N %% 128 == 0, K %% 64 == 0)", g.M, g.N, g.K);
@@ -155,4 +184,17 @@ extern "C" int clipmi_dbg_gemm_bf16(const void* a_dev, const void* w_dev, const 
     if (const char* e = getenv("CLIPMI_GEMM_DBG")) g.dbg = atoi(e);
     if (g.dbg & 12) { g.pos = bias_dev; g.bias = nullptr; }     // stamps land in the caller's "bias" buffer (>= 4 KiB)
     return launch_gemm_algo(g, epi, algo, as_stream(stream));
+}
+
+extern "C" int clipmi_dbg_gemm_fp8(const void* a8_dev, const void* w8_dev, const float* a_scale_dev, const float* w_scale_dev,
+                                   const float* bias_dev, void* out_dev, int M, int N, int K, int epi, void* stream) {
+    if (epi < 0 || epi > 3) return set_err(CLIPMI_EINVAL, "dbg_gemm_fp8: epi %d", epi);
+    GemmArgs g{};
+    g.A = static_cast<const unsigned short*>(a8_dev);
+    g.W = static_cast<const unsigned short*>(w8_dev);
+    g.a_scale = a_scale_dev; g.w_scale = w_scale_dev;
+    g.bias = bias_dev;
+    g.out = out_dev;
+    g.M = M; g.N = N; g.K = K;
+    return launch_gemm_fp8(g, epi, as_stream(stream));
 }

@@ -72,6 +72,9 @@ struct GemmArgs {
     const float* pos;          // [L][N]
     int np, L;
     int dbg;                   // development experiments only (tools/gemm_persist.py); 0 in every product path
+    // FP8 path (gemm256f8.hpp): A and W point at e4m3 bytes; per-row / per-output-channel dequantisation scales
+    const float* a_scale;      // [M]
+    const float* w_scale;      // [N]
 };
 
 // Tile order shared by both GEMM kernels. (1) XCD split: hardware deals workgroups round-robin over
@@ -246,6 +249,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
 // host-side launcher (defined in gemm.hip)
 int launch_gemm(const GemmArgs& g, int epi, hipStream_t st);
 int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st);
+int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st);      // gemm256f8.hpp: e4m3 operands + scales
+int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st);
 
 struct GemmProbe {
     static constexpr int MAX = 64;

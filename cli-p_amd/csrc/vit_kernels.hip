@@ -67,6 +67,14 @@ int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int 
     return set_err(CLIPMI_EUNSUPPORTED, "attention: L=%d", L);
 }
 
+int launch_quantize_rows_fp8(const unsigned short* in, unsigned char* out, float* scale, int M, int K, hipStream_t st) {
+    if (M < 1) return 0;
+    if (K < 8 || K % 8 != 0 || !in || !out || !scale) return set_err(CLIPMI_EINVAL, "quantize_rows_fp8: K=%d", K);
+    hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, in, out, scale, M, K);
+    CLIPMI_CHECK_LAUNCH("quantize_rows_fp8_kernel");
+    return 0;
+}
+
 int launch_patchify(const PatchArgs& a, hipStream_t st) {
     const long long total = (long long)a.B * a.np * (a.patch_k / 8);
     hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
@@ -91,4 +99,10 @@ extern "C" int clipmi_dbg_attention(const void* qkv_dev, void* out_dev, int B, i
     if (!qkv_dev || !out_dev) return set_err(CLIPMI_EINVAL, "dbg_attention: NULL pointer");
     return launch_attention(static_cast<const unsigned short*>(qkv_dev), static_cast<unsigned short*>(out_dev), B, L,
                             heads, causal & 1, (causal & 2) ? 0 : 1, as_stream(stream));
+}
+
+extern "C" int clipmi_dbg_quantize_rows_fp8(const void* in_bf16_dev, void* out_fp8_dev, float* scale_dev, int M, int K,
+                                            void* stream) {
+    return launch_quantize_rows_fp8(static_cast<const unsigned short*>(in_bf16_dev), static_cast<unsigned char*>(out_fp8_dev),
+                                    scale_dev, M, K, as_stream(stream));
 }

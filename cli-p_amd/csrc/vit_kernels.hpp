@@ -344,6 +344,49 @@ __global__ void __launch_bounds__(256) attention_kernel(const unsigned short* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// quantize_rows_fp8_kernel: bf16 [M][K] -> OCP e4m3 [M][K] + f32 scale [M] (the A operand of gemm256f8).
+// One wave per row: scale = max|x| / 448 (1 for an all-zero row), q = RNE(x * (1 / scale)) by v_cvt_pk_fp8_f32;
+// dequantised value = scale * q. K % 8 == 0.
+// ---------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256) quantize_rows_fp8_kernel(const unsigned short* __restrict__ in,
+                                                                       unsigned char* __restrict__ out,
+                                                                       float* __restrict__ scale, int M, int K) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const unsigned short* x = in + (size_t)r * K;
+    float mx = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const uint4 v = *reinterpret_cast<const uint4*>(x + k);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            mx = fmaxf(mx, fmaxf(fabsf(__uint_as_float(w[j] << 16)), fabsf(__uint_as_float(w[j] & 0xffff0000u))));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float s = mx > 0.f ? mx / 448.0f : 1.0f;
+    const float inv = 1.0f / s;
+    for (int k = lane * 8; k < K; k += 512) {
+        const uint4 v = *reinterpret_cast<const uint4*>(x + k);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[2 * j] = __uint_as_float(w[j] << 16) * inv;
+            f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u) * inv;
+        }
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+        *reinterpret_cast<uint2*>(out + (size_t)r * K + k) = make_uint2((unsigned)lo, (unsigned)hi);
+    }
+    if (lane == 0) scale[r] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
 // attention52_kernel: the ViT-B/32 shape (49 <= L <= 52, 4 key/query tiles, no mask) with the query tiles
 // walked in a LOOP instead of all at once. attention_kernel<4,...> keeps 16 score tiles + 16 output tiles +
 // 16 fragments live (~120 registers with the AGPRs: 4 waves per SIMD) and stages 64 V rows per wave (32 KiB per
@@ -650,5 +693,6 @@ int launch_layernorm(const LnArgs& a, hipStream_t st);
 int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int L, int heads, int causal, int tr,
                      hipStream_t st);
 int launch_patchify(const PatchArgs& a, hipStream_t st);
+int launch_quantize_rows_fp8(const unsigned short* in, unsigned char* out, float* scale, int M, int K, hipStream_t st);
 
 }  // namespace clipmi

@@ -33,10 +33,14 @@ class CLIP:
     """Both towers resident in HBM as packed blobs; encode_* enqueue the HIP kernel sequences on
     torch's current stream and return device tensors (f32 [B, E])."""
 
-    def __init__(self, state_dict, device="cuda:0"):
+    def __init__(self, state_dict, device="cuda:0", vision_weights="bf16"):
+        """vision_weights="fp8": the image tower's linear layers run on the FP8 matrix cores (e4m3 weights with
+        per-channel scales, activations quantised per row on the fly; BASELINE.json configs[4]). Lower accuracy
+        than bf16 (tests state the measured tolerance); the text tower and the search are unchanged."""
         self.device = torch.device(device)
         self.dims = weights.infer_dims(state_dict)
-        self.vision, self._vblob = weights.pack_vision(state_dict, self.device)
+        self.vision_weights = vision_weights
+        self.vision, self._vblob = weights.pack_vision(state_dict, self.device, weight_format=vision_weights)
         self.text, self._tblob = weights.pack_text(state_dict, self.device)
         self.visual = _Visual(self.dims["res"])
         self.context_length = self.dims["ctx"]

@@ -193,7 +193,21 @@ class _Blob:
         return buf.to(device), total
 
 
-def _pack_layers(tw, blob, sd, prefix, width, layers):
+FP8_MAX = 448.0          # largest finite OCP e4m3 value
+
+
+def quantize_fp8_rows(w):
+    """f32 [N][K] -> (uint8 [N][K] OCP e4m3 bit patterns, f32 [N] scales): scale_n = max|w_n| / 448 (1 for a zero
+    row), value = RNE(w * (1 / scale)). The same rule the device applies to activation rows
+    (quantize_rows_fp8_kernel) and the oracle emulates."""
+    w = w.detach().to("cpu", torch.float32).contiguous()
+    amax = w.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / FP8_MAX, torch.ones_like(amax))
+    q = (w * (1.0 / scale)[:, None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), scale
+
+
+def _pack_layers(tw, blob, sd, prefix, width, layers, fp8=False):
     bf, f32 = torch.bfloat16, torch.float32
     first = None
     stride = None
@@ -203,10 +217,22 @@ def _pack_layers(tw, blob, sd, prefix, width, layers):
              ("lo_ln2_w", "ln_2.weight", f32), ("lo_ln2_b", "ln_2.bias", f32),
              ("lo_fc_w", "mlp.c_fc.weight", bf), ("lo_fc_b", "mlp.c_fc.bias", f32),
              ("lo_proj_w", "mlp.c_proj.weight", bf), ("lo_proj_b", "mlp.c_proj.bias", f32)]
+    scale_field = {"lo_qkv_w": "lo_qkv_s", "lo_out_w": "lo_out_s", "lo_fc_w": "lo_fc_s", "lo_proj_w": "lo_proj_s"}
     for i in range(layers):
         base = None
         for field, key, dt in names:
-            off = blob.put(sd[f"{prefix}.resblocks.{i}.{key}"], dt)
+            t = sd[f"{prefix}.resblocks.{i}.{key}"]
+            if fp8 and field in scale_field:
+                # the weights as the bf16 path stores them, then e4m3 + one scale per output channel
+                q, sc = quantize_fp8_rows(t.to(torch.bfloat16).float())
+                off = blob.put(q, torch.uint8)
+                soff = blob.put(sc, f32)
+                if i == 0:
+                    setattr(tw, scale_field[field], soff - (base if base is not None else off))
+                else:
+                    assert soff - base == getattr(tw, scale_field[field])
+            else:
+                off = blob.put(t, dt)
             if base is None:
                 base = off
             if i == 0:
@@ -223,8 +249,12 @@ def _pack_layers(tw, blob, sd, prefix, width, layers):
     tw.layer_stride = stride if stride is not None else 0
 
 
-def pack_vision(sd, device):
-    """OpenAI-named state-dict -> (Tower descriptor, uint8 device blob) for the vision tower."""
+def pack_vision(sd, device, weight_format="bf16"):
+    """OpenAI-named state-dict -> (Tower descriptor, uint8 device blob) for the vision tower.
+    weight_format="fp8": the four linear layers of every block as OCP e4m3 + per-output-channel scales
+    (BASELINE.json configs[4]); everything else as in the bf16 layout."""
+    if weight_format not in ("bf16", "fp8"):
+        raise ValueError("weight_format must be 'bf16' or 'fp8'")
     d = infer_dims(sd)
     W, P = d["v_width"], d["patch"]
     if W % 64 or (4 * W) % 128:
@@ -245,7 +275,8 @@ def pack_vision(sd, device):
     tw.off_pos = blob.put(sd["visual.positional_embedding"], f32)
     tw.off_ln_pre_w = blob.put(sd["visual.ln_pre.weight"], f32)
     tw.off_ln_pre_b = blob.put(sd["visual.ln_pre.bias"], f32)
-    _pack_layers(tw, blob, sd, "visual.transformer", W, d["v_layers"])
+    tw.weight_format = 1 if weight_format == "fp8" else 0
+    _pack_layers(tw, blob, sd, "visual.transformer", W, d["v_layers"], fp8=weight_format == "fp8")
     tw.off_ln_post_w = blob.put(sd["visual.ln_post.weight"], f32)
     tw.off_ln_post_b = blob.put(sd["visual.ln_post.bias"], f32)
     tw.off_out_proj = blob.put(sd["visual.proj"].t(), bf)          # [E][W]

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CLIPMI_ABI_VERSION 1
+#define CLIPMI_ABI_VERSION 2
 
 enum {
     CLIPMI_OK = 0,
@@ -90,6 +90,13 @@ typedef struct clipmi_tower {
     /* vision: ln_post + visual.proj stored TRANSPOSED as bf16 [E][W];
        text: ln_final + text_projection stored TRANSPOSED as bf16 [E][W] */
     uint64_t off_ln_post_w, off_ln_post_b, off_out_proj;
+
+    /* ABI 2. weight_format 0: the four linear layers of every block are bf16 (above). weight_format 1
+       (BASELINE.json configs[4], FP8 matrix cores): lo_qkv_w / lo_out_w / lo_fc_w / lo_proj_w point at OCP e4m3
+       bytes [out_features][in_features] and lo_*_s at f32 [out_features] per-output-channel scales
+       (weight = scale * e4m3 value); activations are quantised per row on the fly. Needs width % 256 == 0. */
+    int32_t weight_format, reserved0;
+    uint64_t lo_qkv_s, lo_out_s, lo_fc_s, lo_proj_s;
 } clipmi_tower;
 
 /* ---- a3/a4: model.encode_image(image) and the row L2-normalise that follows it ----------
@@ -214,6 +221,12 @@ int clipmi_dbg_topk_coarse_i8_scan_ms(const void* db_dev, const void* db_i8_dev,
                                       int64_t N, int E, float rmax, const float* q_dev, int Q, int K,
                                       float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes,
                                       void* stream, int reps, float* scan_ms, long long* survivors);
+
+/* the FP8 path's two kernels alone: bf16 [M][K] -> e4m3 [M][K] + f32 row scales; C = a_scale w_scale (A8 W8^T) + epilogue
+ * `epi` (0 bias -> bf16, 1 bias + QuickGELU -> bf16, 2 bias + residual into f32 out, 3 f32) */
+int clipmi_dbg_quantize_rows_fp8(const void* in_bf16_dev, void* out_fp8_dev, float* scale_dev, int M, int K, void* stream);
+int clipmi_dbg_gemm_fp8(const void* a8_dev, const void* w8_dev, const float* a_scale_dev, const float* w_scale_dev,
+                        const float* bias_dev, void* out_dev, int M, int N, int K, int epi, void* stream);
 
 /* clipmi_encode_image `reps` times with HIP events around every launch of the GEMM whose
  * epilogue is `probe_epi` (1 = MLP c_fc + QuickGELU), on `stream`; synchronises;

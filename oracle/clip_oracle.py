@@ -57,13 +57,44 @@ class act_round:
         _ACT_ROUND = self.prev
 
 
+_FP8_LINEAR = False   # test knob: the four linear layers of every block on e4m3 operands (BASELINE.json configs[4])
+FP8_MAX = 448.0
+
+
+def _fp8_rows(t):
+    """Per-row e4m3 quantise/dequantise: scale = max|row| / 448 (1 for a zero row), q = RNE(t * (1 / scale)) -
+    the rule of quantize_rows_fp8_kernel (activations) and weights.quantize_fp8_rows (weights)."""
+    amax = t.abs().amax(dim=-1, keepdim=True)
+    scale = torch.where(amax > 0, amax / FP8_MAX, torch.ones_like(amax))
+    return (t * (1.0 / scale)).to(torch.float8_e4m3fn).to(t.dtype) * scale
+
+
+class linear_fp8:
+    """Context manager: emulate the FP8 linear layers (products of e4m3 values are exact in f32, so an f32 matmul of
+    the dequantised operands is what the FP8 matrix cores compute, up to summation order)."""
+
+    def __enter__(self):
+        global _FP8_LINEAR
+        self.prev, _FP8_LINEAR = _FP8_LINEAR, True
+
+    def __exit__(self, *a):
+        global _FP8_LINEAR
+        _FP8_LINEAR = self.prev
+
+
+def _linear(x, w, b):
+    if _FP8_LINEAR:
+        return _fp8_rows(_r(x)) @ _fp8_rows(w).t() + b
+    return _r(x) @ w.t() + b
+
+
 def _attention(x, sd, p, heads, mask):
     """nn.MultiheadAttention(width, heads) self-attention as ResidualAttentionBlock.attention
     calls it (need_weights=False, attn_mask=mask); x is [B, L, W] here (upstream uses [L, B, W];
     the arithmetic is per (batch, head) and identical)."""
     B, L, W = x.shape
     hd = W // heads
-    qkv = _r(_r(x) @ sd[p + ".attn.in_proj_weight"].t() + sd[p + ".attn.in_proj_bias"])
+    qkv = _r(_linear(x, sd[p + ".attn.in_proj_weight"], sd[p + ".attn.in_proj_bias"]))
     q, k, v = qkv.split(W, dim=-1)
     q = q.reshape(B, L, heads, hd).transpose(1, 2)
     k = k.reshape(B, L, heads, hd).transpose(1, 2)
@@ -73,14 +104,14 @@ def _attention(x, sd, p, heads, mask):
         s = s + mask
     a = _r(torch.softmax(s, dim=-1)) @ v
     a = _r(a.transpose(1, 2).reshape(B, L, W))
-    return a @ sd[p + ".attn.out_proj.weight"].t() + sd[p + ".attn.out_proj.bias"]
+    return _linear(a, sd[p + ".attn.out_proj.weight"], sd[p + ".attn.out_proj.bias"])
 
 
 def _resblock(x, sd, p, heads, mask):
     # upstream ResidualAttentionBlock.forward: x + attention(ln_1(x)); x + mlp(ln_2(x))
     x = x + _attention(_ln(x, sd, p + ".ln_1"), sd, p, heads, mask)
-    h = _r(_ln(x, sd, p + ".ln_2")) @ sd[p + ".mlp.c_fc.weight"].t() + sd[p + ".mlp.c_fc.bias"]
-    h = _r(quick_gelu(h)) @ sd[p + ".mlp.c_proj.weight"].t() + sd[p + ".mlp.c_proj.bias"]
+    h = _linear(_ln(x, sd, p + ".ln_2"), sd[p + ".mlp.c_fc.weight"], sd[p + ".mlp.c_fc.bias"])
+    h = _linear(quick_gelu(h), sd[p + ".mlp.c_proj.weight"], sd[p + ".mlp.c_proj.bias"])
     return x + h
 
 

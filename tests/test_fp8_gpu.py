@@ -1,0 +1,143 @@
+"""-m gpu tests of the FP8 path (BASELINE.json configs[4]: "fp8 ViT-B/32 weights on CDNA4 fp8 MFMA"):
+row quantisation, the FP8 GEMM with its scaled epilogues, and encode_image with e4m3 weights, each against
+the torch emulation of the same rule (per-row / per-output-channel scale = max|.| / 448, RNE to OCP e4m3,
+f32 accumulation of exact products).
+
+Stated tolerance for embeddings: e4m3 keeps 3 mantissa bits, so this path is far coarser than bf16. The HIP
+result's deviation from the fp32 oracle must be within 3x the deviation the oracle shows when ITS linear layers
+are put on e4m3 operands (measured in the test), and the row-wise cosine to the fp32 oracle must be >= 0.99."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, GOLD)
+sys.path.insert(0, ROOT)
+import clip_case  # noqa: E402
+from oracle import clip_oracle  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16)
+
+
+def _quant_rows(t):
+    """torch restatement of the quantisation rule -> (uint8 e4m3 bytes, f32 scales)."""
+    t = t.float()
+    amax = t.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    q = (t * (1.0 / scale)[:, None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), scale
+
+
+def test_quantize_rows_fp8_matches_torch(clipmi, gpu):
+    L = clipmi._lib.lib()
+    g = torch.Generator(device="cpu"); g.manual_seed(3)
+    M, K = 777, 768
+    x = _bf16(torch.randn(M, K, generator=g) * torch.rand(M, 1, generator=g) * 5)
+    x[5] = 0
+    x[6, 3] = 1e-30                                     # tiny row: scale far below 1
+    x[7] = _bf16(torch.full((K,), 448.0))
+    xd = x.to(gpu)
+    out = torch.zeros(M, K, dtype=torch.uint8, device=gpu)
+    sc = torch.zeros(M, dtype=torch.float32, device=gpu)
+    clipmi._lib.check(L.clipmi_dbg_quantize_rows_fp8(xd.data_ptr(), out.data_ptr(), sc.data_ptr(), M, K, None), "q")
+    torch.cuda.synchronize()
+    q_ref, s_ref = _quant_rows(x)
+    assert torch.equal(sc.cpu(), s_ref)
+    got = out.cpu()
+    same = got == q_ref
+    # +0 / -0 of e4m3 are the only representational freedom
+    assert (same | (((got & 0x7f) == 0) & ((q_ref & 0x7f) == 0))).all(), f"{(~same).sum().item()} bytes differ"
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (1, 256, 256), (300, 512, 384), (2500, 2304, 768), (2501, 768, 3072),
+                                   (2500, 3072, 768)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm_fp8_epilogues(clipmi, gpu, M, N, K, epi):
+    """C = a_scale w_scale (A8 W8^T) + epilogue against an f32 matmul of the dequantised operands (products of
+    e4m3 values are exact in f32: only the summation order differs); twice for determinism."""
+    L = clipmi._lib.lib()
+    g = torch.Generator(device="cpu"); g.manual_seed(M + N + K + epi)
+    a = _bf16(torch.randn(M, K, generator=g) * (0.2 + 3 * torch.rand(M, 1, generator=g)))
+    w = _bf16(torch.randn(N, K, generator=g) * K ** -0.5 * (0.5 + torch.rand(N, 1, generator=g)))
+    bias = torch.randn(N, generator=g)
+    a8, sa = _quant_rows(a)
+    w8, sw = _quant_rows(w)
+    ad = a8.view(torch.float8_e4m3fn).float() * sa[:, None]
+    wd = w8.view(torch.float8_e4m3fn).float() * sw[:, None]
+    ref = (ad.to(gpu).double() @ wd.to(gpu).double().t()).float() + bias.to(gpu)
+    res = torch.randn(M, N, generator=g).to(gpu) if epi == 2 else None
+    a8d, w8d, sad, swd, biasd = a8.to(gpu), w8.to(gpu), sa.to(gpu), sw.to(gpu), bias.to(gpu)
+    if epi == 1:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    if epi == 2:
+        ref = ref + res
+    outs = []
+    for _ in range(2):
+        if epi in (0, 1):
+            out = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device=gpu)
+        else:
+            out = torch.full((M + 1, N), float("nan"), dtype=torch.float32, device=gpu)
+            if epi == 2:
+                out[:M] = res
+        rc = L.clipmi_dbg_gemm_fp8(a8d.data_ptr(), w8d.data_ptr(), sad.data_ptr(), swd.data_ptr(), biasd.data_ptr(),
+                                   out.data_ptr(), M, N, K, epi, None)
+        clipmi._lib.check(rc, "gemm_fp8")
+        torch.cuda.synchronize()
+        assert torch.isnan(out[M]).all(), "wrote past row M"
+        outs.append(out[:M].float())
+    scale = ref.abs().max().item()
+    err = (outs[0] - ref).abs().max().item()
+    tol = 6e-5 * scale + (2.0 ** -8) * scale * (epi in (0, 1))     # f32 accumulation of up to 3072 terms + scaling
+    assert torch.isfinite(outs[0]).all() and err <= tol, f"M={M} N={N} K={K} epi={epi}: err {err} tol {tol}"
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_gemm_fp8_rejects(clipmi, gpu):
+    L = clipmi._lib.lib()
+    x = torch.zeros(1 << 20, dtype=torch.uint8, device=gpu)
+    f = torch.zeros(4096, dtype=torch.float32, device=gpu)
+    args = (x.data_ptr(), x.data_ptr(), f.data_ptr(), f.data_ptr(), None, x.data_ptr())
+    assert L.clipmi_dbg_gemm_fp8(*args, 256, 128, 256, 0, None) == 1      # N % 256
+    assert L.clipmi_dbg_gemm_fp8(*args, 256, 256, 192, 0, None) == 1      # K % 128
+    assert L.clipmi_dbg_gemm_fp8(*args, 256, 256, 128, 0, None) == 1      # K >= 256
+
+
+@pytest.mark.parametrize("name", ["vitb32_seed0", "vitb32_outlier"])
+def test_encode_image_fp8_weights_matches_emulation(clipmi, gpu, name):
+    sd = clip_case.state_dict(name)
+    images, _ = clip_case.inputs(name)
+    model = clipmi.CLIP(sd, device=gpu, vision_weights="fp8")
+    assert model.vision.weight_format == 1
+    got = model.encode_image(images).cpu()
+    sdr = clipmi.weights.bf16_round_state_dict(sd)
+    ref = clip_oracle.encode_image(sdr, images)
+    with clip_oracle.act_round(torch.bfloat16), clip_oracle.linear_fp8():
+        emu = clip_oracle.encode_image(sdr, images)
+    noise = (emu - ref).abs().max().item()
+    err = (got - ref).abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(got.double(), ref.double(), dim=-1).min().item()
+    cos_emu = torch.nn.functional.cosine_similarity(got.double(), emu.double(), dim=-1).min().item()
+    print(f"{name}: fp8 image err {err:.4g} (e4m3-emulation noise {noise:.4g}), cosine to fp32 oracle {cos:.5f}, "
+          f"to the emulation {cos_emu:.5f}")
+    assert torch.isfinite(got).all()
+    assert err <= 3 * noise + 1e-3, f"err {err} vs measured e4m3 noise {noise}"
+    assert cos >= 0.99
+    # the bf16 tower on the same weights is the closer one
+    got16 = clipmi.CLIP(sd, device=gpu).encode_image(images).cpu()
+    assert (got16 - ref).abs().max().item() < err
+
+
+def test_fp8_needs_width_multiple_of_256(clipmi, gpu):
+    sd = clip_case.state_dict("toy_seed0")              # width 128
+    model = clipmi.CLIP(sd, device=gpu, vision_weights="fp8")
+    images, _ = clip_case.inputs("toy_seed0")
+    with pytest.raises(clipmi.ClipmiError, match="256"):
+        model.encode_image(images)
