@@ -124,30 +124,33 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st) {
     return set_err(CLIPMI_EINVAL, "gemm: unknown epilogue %d", epi);
 }
 
-template <int EPI>
+template <int EPI, bool MX>
 static int launch_epi256f8(const GemmArgs& g, hipStream_t st) {
     const int grid = (g.N / 256) * ((g.M + 255) / 256);
     static thread_local bool opted = false;
     if (!opted) {
-        if (hipFuncSetAttribute((const void*)gemm256f8_nt_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS) !=
-            hipSuccess)
+        if (hipFuncSetAttribute((const void*)gemm256f8_nt_kernel<EPI, MX>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G256_LDS) != hipSuccess)
             return set_err(CLIPMI_EHIP, "hipFuncSetAttribute(gemm256f8, %d B LDS)", G256_LDS);
         opted = true;
     }
-    hipLaunchKernelGGL(gemm256f8_nt_kernel<EPI>, dim3(grid), dim3(512), G256_LDS, st, g);
+    hipLaunchKernelGGL((gemm256f8_nt_kernel<EPI, MX>), dim3(grid), dim3(512), G256_LDS, st, g);
     CLIPMI_CHECK_LAUNCH("gemm256f8_nt_kernel");
     return 0;
 }
 
-int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st) {
+// mx: 1 = the block-scaled MFMA form with unit scales (twice the rate), 0 = plain FP8 MFMA (f32 accumulation)
+int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st, int mx) {
     if (g.M < 1 || g.N % 256 != 0 || g.K % 128 != 0 || g.K < 256)
         return set_err(CLIPMI_EINVAL, "gemm_fp8: M=%d N=%d K=%d (need N %% 256 == 0, K %% 128 == 0, K >= 256)", g.M, g.N, g.K);
     if (!g.A || !g.W || !g.out || !g.a_scale || !g.w_scale) return set_err(CLIPMI_EINVAL, "gemm_fp8: NULL pointer");
     switch (epi) {
-        case EPI_BIAS_BF16: return launch_epi256f8<EPI_BIAS_BF16>(g, st);
-        case EPI_BIAS_QGELU_BF16: return launch_epi256f8<EPI_BIAS_QGELU_BF16>(g, st);
-        case EPI_BIAS_RESID_F32: return launch_epi256f8<EPI_BIAS_RESID_F32>(g, st);
-        case EPI_F32: return launch_epi256f8<EPI_F32>(g, st);
+        case EPI_BIAS_BF16: return mx ? launch_epi256f8<EPI_BIAS_BF16, true>(g, st) : launch_epi256f8<EPI_BIAS_BF16, false>(g, st);
+        case EPI_BIAS_QGELU_BF16:
+            return mx ? launch_epi256f8<EPI_BIAS_QGELU_BF16, true>(g, st) : launch_epi256f8<EPI_BIAS_QGELU_BF16, false>(g, st);
+        case EPI_BIAS_RESID_F32:
+            return mx ? launch_epi256f8<EPI_BIAS_RESID_F32, true>(g, st) : launch_epi256f8<EPI_BIAS_RESID_F32, false>(g, st);
+        case EPI_F32: return mx ? launch_epi256f8<EPI_F32, true>(g, st) : launch_epi256f8<EPI_F32, false>(g, st);
     }
     return set_err(CLIPMI_EINVAL, "gemm_fp8: epilogue %d", epi);
 }
@@ -188,6 +191,8 @@ extern "C" int clipmi_dbg_gemm_bf16(const void* a_dev, const void* w_dev, const 
 
 extern "C" int clipmi_dbg_gemm_fp8(const void* a8_dev, const void* w8_dev, const float* a_scale_dev, const float* w_scale_dev,
                                    const float* bias_dev, void* out_dev, int M, int N, int K, int epi, void* stream) {
+    const int mx = (epi >> 8) & 1 ? 0 : 1;        // test hook: bit 8 selects the plain (non-scaled) FP8 MFMA form
+    epi &= 0xff;
     if (epi < 0 || epi > 3) return set_err(CLIPMI_EINVAL, "dbg_gemm_fp8: epi %d", epi);
     GemmArgs g{};
     g.A = static_cast<const unsigned short*>(a8_dev);
@@ -196,5 +201,5 @@ extern "C" int clipmi_dbg_gemm_fp8(const void* a8_dev, const void* w8_dev, const
     g.bias = bias_dev;
     g.out = out_dev;
     g.M = M; g.N = N; g.K = K;
-    return launch_gemm_fp8(g, epi, as_stream(stream));
+    return launch_gemm_fp8(g, epi, as_stream(stream), mx);
 }

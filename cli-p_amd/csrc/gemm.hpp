@@ -249,8 +249,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
 // host-side launcher (defined in gemm.hip)
 int launch_gemm(const GemmArgs& g, int epi, hipStream_t st);
 int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st);
-int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st);      // gemm256f8.hpp: e4m3 operands + scales
-int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st);
+int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st, int mx = 1);      // gemm256f8.hpp: e4m3 operands + scales
 
 struct GemmProbe {
     static constexpr int MAX = 64;

@@ -18,8 +18,9 @@
 namespace clipmi {
 
 typedef long i64x2v __attribute__((ext_vector_type(2)));
+typedef int i32x8v __attribute__((ext_vector_type(8)));
 
-template <int EPI>
+template <int EPI, bool MX>
 __global__ void __launch_bounds__(512, 2) gemm256f8_nt_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -91,19 +92,36 @@ __global__ void __launch_bounds__(512, 2) gemm256f8_nt_kernel(GemmArgs g) {
         dst[t_][0] = *reinterpret_cast<const i64x2v*>((base) + (half) * G256_HALF + offB + t_ * 2048 + c0); \
         dst[t_][1] = *reinterpret_cast<const i64x2v*>((base) + (half) * G256_HALF + offB + t_ * 2048 + c1); \
     }
-    // MFMA slot: 16 MFMAs of quadrant (A half a, B half b); D = Wfrag x Afrag (C^T tile, see gemm.hpp)
+    // MFMA slot of quadrant (A half a, B half b); D = Wfrag x Afrag (C^T tile, see gemm.hpp).
+    //   MX = false: 32 x v_mfma_f32_16x16x32_fp8_fp8 (low and high 8 bytes of each fragment pair; f32 accumulation of
+    //               exact products; the bf16 MFMA rate)
+    //   MX = true:  8 x v_mfma_scale_f32_16x16x128_f8f6f4 with UNIT block scales (e8m0 127 = 2^0): one instruction takes
+    //               both 16-byte fragments of a lane (32 of the 128 k), twice the k per cycle. Probed on hardware
+    //               (tools/probe/mfma_mx_probe.hip): the same products, summed with ~2^-15 relative error per
+    //               instruction (a narrower adder than the f32 chain), far below e4m3's own 2^-4.
 #define G256_MFMA(a, bfr, b)                                                                         \
     do {                                                                                             \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
         __builtin_amdgcn_sched_barrier(0);                                                           \
         __builtin_amdgcn_s_setprio(1);                                                               \
-        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                          \
+        if constexpr (MX) {                                                                          \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
-                _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                     \
-                    {                                                                                \
+                _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                   \
+                    const i64x2v b0_ = bfr[j_][0], b1_ = bfr[j_][1], a0_ = af[i_][0], a1_ = af[i_][1]; \
+                    typedef long i64x4v_ __attribute__((ext_vector_type(4)));                        \
+                    const i64x4v_ bw_ = {b0_.x, b0_.y, b1_.x, b1_.y}, aw_ = {a0_.x, a0_.y, a1_.x, a1_.y}; \
+                    acc[a][i_][b][j_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(            \
+                        __builtin_bit_cast(i32x8v, bw_), __builtin_bit_cast(i32x8v, aw_), acc[a][i_][b][j_], 0, 0, 0, \
+                        0x7f7f7f7f, 0, 0x7f7f7f7f);                                                  \
+                }                                                                                    \
+        } else {                                                                                     \
+            _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                      \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                     \
+                    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                               \
                         acc[a][i_][b][j_] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bfr[j_][ks_].x, af[i_][ks_].x, acc[a][i_][b][j_], 0, 0, 0); \
                         acc[a][i_][b][j_] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bfr[j_][ks_].y, af[i_][ks_].y, acc[a][i_][b][j_], 0, 0, 0); \
                     }                                                                                \
+        }                                                                                            \
         __builtin_amdgcn_s_setprio(0);                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                           \
         __builtin_amdgcn_s_barrier();                                                                \
