@@ -74,12 +74,14 @@ const T* at(const void* blob, uint64_t off) {
 int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int causal, hipStream_t st) {
     const int W = t->width, L = t->tokens, M = B * L;
     const bool fp8 = t->weight_format == 1;
+    // A == nullptr: the A operand is already in w.a8 / w.a_scale (LayerNorm wrote it as e4m3)
     auto linear = [&](const unsigned short* A, int K, uint64_t w_off, uint64_t s_off, uint64_t b_off, void* out, int N,
                       int epi) -> int {
         GemmArgs g{};
         g.bias = at<float>(blob, b_off); g.out = out; g.M = M; g.N = N; g.K = K;
         if (fp8) {
-            if (int rc = launch_quantize_rows_fp8(A, w.a8, w.a_scale, M, K, st)) return rc;
+            if (A)
+                if (int rc = launch_quantize_rows_fp8(A, w.a8, w.a_scale, M, K, st)) return rc;
             g.A = reinterpret_cast<const unsigned short*>(w.a8);
             g.W = at<unsigned short>(blob, w_off);
             g.a_scale = w.a_scale; g.w_scale = at<float>(blob, s_off);
@@ -91,13 +93,14 @@ int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int 
     for (int l = 0; l < t->layers; ++l) {
         const uint64_t lb = t->off_layers + (uint64_t)l * t->layer_stride;
         LnArgs ln{w.x, at<float>(blob, lb + t->lo_ln1_w), at<float>(blob, lb + t->lo_ln1_b), w.h, nullptr, 1, M, W, 1};
+        if (fp8) { ln.out8 = w.a8; ln.scale8 = w.a_scale; }       // LayerNorm output straight to e4m3 + row scale
         if (int rc = launch_layernorm(ln, st)) return rc;
-        if (int rc = linear(w.h, W, lb + t->lo_qkv_w, lb + t->lo_qkv_s, lb + t->lo_qkv_b, w.big, 3 * W, EPI_BIAS_BF16)) return rc;
+        if (int rc = linear(fp8 ? nullptr : w.h, W, lb + t->lo_qkv_w, lb + t->lo_qkv_s, lb + t->lo_qkv_b, w.big, 3 * W, EPI_BIAS_BF16)) return rc;
         if (int rc = launch_attention(w.big, w.h, B, L, t->heads, causal, 1, st)) return rc;
         if (int rc = linear(w.h, W, lb + t->lo_out_w, lb + t->lo_out_s, lb + t->lo_out_b, w.x, W, EPI_BIAS_RESID_F32)) return rc;
         ln.w = at<float>(blob, lb + t->lo_ln2_w); ln.b = at<float>(blob, lb + t->lo_ln2_b);
         if (int rc = launch_layernorm(ln, st)) return rc;
-        if (int rc = linear(w.h, W, lb + t->lo_fc_w, lb + t->lo_fc_s, lb + t->lo_fc_b, w.big, 4 * W, EPI_BIAS_QGELU_BF16)) return rc;
+        if (int rc = linear(fp8 ? nullptr : w.h, W, lb + t->lo_fc_w, lb + t->lo_fc_s, lb + t->lo_fc_b, w.big, 4 * W, EPI_BIAS_QGELU_BF16)) return rc;
         if (int rc = linear(w.big, 4 * W, lb + t->lo_proj_w, lb + t->lo_proj_s, lb + t->lo_proj_b, w.x, W, EPI_BIAS_RESID_F32))
             return rc;
     }

@@ -134,6 +134,10 @@ struct LnArgs {
     const int* rowidx;    // optional gather
     long long row_step;   // source row stride in ROWS when rowidx == nullptr (1 = dense, L = CLS rows)
     int M, W, out_bf16;
+    // FP8 path: when out8 is set, the row goes out as OCP e4m3 + one f32 scale instead of bf16 - exactly what
+    // quantize_rows_fp8_kernel would make of the bf16 row (the values are rounded to bf16 first)
+    unsigned char* out8;
+    float* scale8;
 };
 
 static __global__ void __launch_bounds__(256) layernorm_kernel(LnArgs a) {
@@ -166,6 +170,38 @@ static __global__ void __launch_bounds__(256) layernorm_kernel(LnArgs a) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
     const float rstd = rsqrtf(q / (float)a.W + 1e-5f);
+    if (a.out8) {
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = i * 256 + lane * 4;
+            if (c < a.W) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(a.w + c);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(a.b + c);
+                const f32x4 y = (v[i] - mean) * rstd * g + bb;
+                const unsigned lo = pack_bf16x2(y.x, y.y), hi = pack_bf16x2(y.z, y.w);     // the bf16 row, kept in v[i]
+                v[i] = f32x4{__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
+                             __uint_as_float(hi & 0xffff0000u)};
+                mx = fmaxf(fmaxf(mx, fabsf(v[i].x)), fmaxf(fabsf(v[i].y), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float sc = mx > 0.f ? mx / 448.0f : 1.0f;
+        const float inv = 1.0f / sc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = i * 256 + lane * 4;
+            if (c < a.W) {
+                int pk = 0;
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].x * inv, v[i].y * inv, pk, false);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].z * inv, v[i].w * inv, pk, true);
+                *reinterpret_cast<unsigned*>(a.out8 + (size_t)r * a.W + c) = (unsigned)pk;
+            }
+        }
+        if (lane == 0) a.scale8[r] = sc;
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = i * 256 + lane * 4;
