@@ -51,6 +51,7 @@ def parse():
                     help="coarse copy scanned before the exact f32 re-scoring (results are identical either way)")
     ap.add_argument("--k", type=int, default=50, help="results per query (K = k + 1 is searched)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the FP8 (configs[4]) encode measurement")
     return ap.parse_args()
 
 
@@ -190,6 +191,24 @@ def main():
     img_per_s = world * B * a.steps / dt_enc
     assert torch.isfinite(enc_out[0]).all()
 
+    # BASELINE.json configs[4] beside the headline (never `value`: reduced precision): the same step with the
+    # block linear layers on the FP8 matrix cores (e4m3 weights, activations quantised per row on the fly)
+    fp8_info = None
+    if not a.no_fp8:
+        ref16 = enc_out[0].clone()
+        model8 = clipmi.CLIP(sd, device=dev, vision_weights="fp8")
+
+        def enc8_step():
+            enc_out[0] = model8.encode_image(images, normalize=True)
+        steps8 = max(3, a.steps // 2)
+        dt8 = timed(enc8_step, steps8, 2, dist, world)
+        cos = torch.nn.functional.cosine_similarity(enc_out[0].double(), ref16.double(), dim=-1)
+        fp8_info = {"metric": "images/sec ViT-B/32 encode, FP8 (e4m3) linear layers", "value": world * B * steps8 / dt8,
+                    "unit": "images/s", "ms_per_step": dt8 / steps8 * 1e3, "steps": steps8, "dtype": "fp8 e4m3 x e4m3 -> f32",
+                    "min_cosine_to_bf16_path": float(cos.min()),
+                    "note": "BASELINE.json configs[4] parity case; not the headline (configs[1] is bf16)"}
+        del model8
+
     # dominant encode kernel (MLP c_fc GEMM + bias + QuickGELU, 12 launches per step), timed IN SITU:
     # HIP events recorded by the library around each of its launches on the launch stream
     M, N, Kd = B * 50, 3072, 768
@@ -310,6 +329,8 @@ def main():
                                 "coarse_survivors_per_query": (survivors.value / Qp) if survivors.value >= 0 else None,
                                 "whole_call_gbs_per_gpu": scan_bytes * ((Q + Qp - 1) // Qp) * a.steps / dt_s / 1e9}},
     }
+    if fp8_info is not None:
+        out["encode_fp8"] = fp8_info
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_encode(sd)
         out["search"]["cpu_baseline"] = cpu_baseline_search(a.rows, Q, K)

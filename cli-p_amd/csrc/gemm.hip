@@ -58,25 +58,25 @@ static int persist_mode() {
     return mode;
 }
 
-template <int EPI>
+template <int EPI, bool FP8 = false>
 static int launch_epi256p(const GemmArgs& g, hipStream_t st) {
     const int tiles = (g.N / 256) * ((g.M + 255) / 256);
     const int grid = tiles < NUM_CU ? tiles : NUM_CU;
-    const int lds = G256_LDS + g.N * 4 + ((g.dbg & 12) ? 2048 : 0);
+    const int lds = G256_LDS + g.N * 4 * (FP8 ? 2 : 1) + (FP8 ? 1024 : 0) + ((g.dbg & 12) ? 2048 : 0);
     static thread_local int opted = 0;
     if (opted < lds) {
-        if (hipFuncSetAttribute((const void*)gemm256p_bf16_nt_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)gemm256p_bf16_nt_kernel<EPI, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 G256_LDS + G256P_MAX_N * 4) != hipSuccess)
             return set_err(CLIPMI_EHIP, "hipFuncSetAttribute(gemm256p, %d B LDS)", G256_LDS + G256P_MAX_N * 4);
         opted = G256_LDS + G256P_MAX_N * 4;
     }
     GemmProbe& p = gemm_probe();
     if (p.active && p.epi == EPI && p.n < GemmProbe::MAX) {
-        hipExtLaunchKernelGGL(gemm256p_bf16_nt_kernel<EPI>, dim3(grid), dim3(512), lds, st, p.ev[2 * p.n],
+        hipExtLaunchKernelGGL((gemm256p_bf16_nt_kernel<EPI, FP8>), dim3(grid), dim3(512), lds, st, p.ev[2 * p.n],
                               p.ev[2 * p.n + 1], 0, g);
         ++p.n;
     } else {
-        hipLaunchKernelGGL(gemm256p_bf16_nt_kernel<EPI>, dim3(grid), dim3(512), lds, st, g);
+        hipLaunchKernelGGL((gemm256p_bf16_nt_kernel<EPI, FP8>), dim3(grid), dim3(512), lds, st, g);
     }
     CLIPMI_CHECK_LAUNCH("gemm256p_bf16_nt_kernel");
     return 0;
@@ -144,6 +144,13 @@ int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st, int mx) {
     if (g.M < 1 || g.N % 256 != 0 || g.K % 128 != 0 || g.K < 256)
         return set_err(CLIPMI_EINVAL, "gemm_fp8: M=%d N=%d K=%d (need N %% 256 == 0, K %% 128 == 0, K >= 256)", g.M, g.N, g.K);
     if (!g.A || !g.W || !g.out || !g.a_scale || !g.w_scale) return set_err(CLIPMI_EINVAL, "gemm_fp8: NULL pointer");
+    // more than one round of tiles: the persistent role-split kernel on FP8 operands (mx = 2 keeps gemm256f8 for tests)
+    const long long tiles = (long long)(g.N / 256) * ((g.M + 255) / 256);
+    if (mx == 1 && tiles > NUM_CU && g.K % 256 == 0 && g.N <= 3840 && persist_mode() != 0) {
+        if (epi == EPI_BIAS_BF16) return launch_epi256p<EPI_BIAS_BF16, true>(g, st);
+        if (epi == EPI_BIAS_QGELU_BF16) return launch_epi256p<EPI_BIAS_QGELU_BF16, true>(g, st);
+        // (the residual epilogue stays on gemm256f8: its persistent FP8 form does not fit 256 registers)
+    }
     switch (epi) {
         case EPI_BIAS_BF16: return mx ? launch_epi256f8<EPI_BIAS_BF16, true>(g, st) : launch_epi256f8<EPI_BIAS_BF16, false>(g, st);
         case EPI_BIAS_QGELU_BF16:
@@ -191,7 +198,8 @@ extern "C" int clipmi_dbg_gemm_bf16(const void* a_dev, const void* w_dev, const 
 
 extern "C" int clipmi_dbg_gemm_fp8(const void* a8_dev, const void* w8_dev, const float* a_scale_dev, const float* w_scale_dev,
                                    const float* bias_dev, void* out_dev, int M, int N, int K, int epi, void* stream) {
-    const int mx = (epi >> 8) & 1 ? 0 : 1;        // test hook: bit 8 selects the plain (non-scaled) FP8 MFMA form
+    // test hook: bit 8 selects the plain (non-scaled) FP8 MFMA form, bit 9 keeps the MX form on the non-persistent kernel
+    const int mx = (epi >> 8) & 1 ? 0 : ((epi >> 9) & 1 ? 2 : 1);
     epi &= 0xff;
     if (epi < 0 || epi > 3) return set_err(CLIPMI_EINVAL, "dbg_gemm_fp8: epi %d", epi);
     GemmArgs g{};

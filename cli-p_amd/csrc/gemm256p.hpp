@@ -23,7 +23,7 @@
 // buffer 1 (dead after the last K-tile; buffer 0 holds the next tile's K-tile 0 in flight) in two passes
 // of 128 rows x 512 B.
 #pragma once
-#include "gemm256.hpp"
+#include "gemm256f8.hpp"
 
 #ifndef CLIPMI_GEMM_STAMPS
 #define CLIPMI_GEMM_STAMPS 0      // 1: in-kernel time stamps (tools/gp_stamps.py); costs a few % of the K-loop
@@ -33,7 +33,10 @@ namespace clipmi {
 
 constexpr int G256P_MAX_N = 8192;
 
-template <int EPI>
+// FP8 = true: e4m3 operands + scales as gemm256f8 (MX form: one unit-scale v_mfma_scale_f32_16x16x128_f8f6f4 per
+// accumulator tile and K-tile of 128 bytes); w_scale[N] sits in LDS beside the bias row, the tile's 256 a_scale
+// values arrive by one LDS-DMA instruction under the last K-tile.
+template <int EPI, bool FP8 = false>
 __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_RESID_F32, "store-only epilogues");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -45,7 +48,9 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     const int fr = lane & 15, fg = lane >> 4;
 
     const int ntn = g.N >> 8, mtiles = (g.M + 255) >> 8, ntiles = ntn * mtiles;
-    const int K = g.K, nk = K >> 6;
+    const int K = g.K;
+    const unsigned KB = FP8 ? (unsigned)K : 2u * (unsigned)K;      // bytes per operand row
+    const int nk = (int)(KB >> 7);
     const int stride = gridDim.x;
     int v = blockIdx.x;
 
@@ -55,7 +60,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     // row M-1 (their products are never stored); W needs no clamp (N % 256 == 0).
     const int srow = lane >> 3, spos = lane & 7;
     const unsigned lane_chunk = (unsigned)(spos ^ srow) * 16u;          // row & 7 == srow for every piece
-    const unsigned wvoff = (unsigned)(wn * 32 + srow) * (unsigned)K * 2u + lane_chunk;
+    const unsigned wvoff = (unsigned)(wn * 32 + srow) * KB + lane_chunk;
     unsigned avoff[2][4];                // [A half][piece], bytes from the tile's first A row
     auto tile_origin = [&](int vv, int& mm, int& nn) {
         int bm, bn;
@@ -66,19 +71,24 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     __amdgpu_buffer_rsrc_t rsA, rsW;
     auto set_tile = [&](int mm, int nn) {
         const int last = g.M - 1 - mm;                                  // >= 0: last valid local row
+        // recompute the lane's eight row indices here (mbcnt = lane id without a live register): hoisted out of
+        // the tile loop they, or `lane`, get spilled, and a scratch reload costs every wave a vmcnt(0)
+        int sr_;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(sr_));
+        sr_ >>= 3;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                int lr = h * 128 + wn * 32 + i * 8 + srow;
+                int lr = h * 128 + wn * 32 + i * 8 + sr_;
                 lr = lr < last ? lr : last;
-                avoff[h][i] = (unsigned)lr * (unsigned)K * 2u + lane_chunk;
+                avoff[h][i] = (unsigned)lr * KB + lane_chunk;
             }
-        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)mm * K), 0, 0x7fffffff, 0x00020000);
-        rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(g.W + (size_t)nn * K), 0, 0x7fffffff, 0x00020000);
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(g.A) + (size_t)mm * KB), 0, 0x7fffffff, 0x00020000);
+        rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(g.W) + (size_t)nn * KB), 0, 0x7fffffff, 0x00020000);
     };
     const int dma_off = wn * 32 * 128;
-    const unsigned piece_stride = 8u * (unsigned)K * 2u, half_stride = 128u * (unsigned)K * 2u;
+    const unsigned piece_stride = 8u * KB, half_stride = 128u * KB;
     // issue half-tile H (0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi) of K-tile kt of the current descriptors into `buf`
 #define P_ISSUE(H, kt, buf)                                                                                           \
     do {                                                                                                              \
@@ -131,28 +141,44 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     const int offB = 2 * G256_HALF + (wn * 32 + fr) * 128;
 
     f32x4 acc[2][4][2][2];     // [A half][mt][B half][nt]
-    bf16x8 af[4][2];
-    bf16x8 bl[2][2], bh[2][2];
+    i64x2v af[4][2];           // bf16: 16-byte fragments [mt][ks]
+    i64x2v bl[2][2], bh[2][2];
+    typedef long i64x4v __attribute__((ext_vector_type(4)));
+    i64x4v af8[4], bl8[2], bh8[2];   // FP8: both fragments of a lane as ONE 32-byte operand (8 consecutive registers)
 
 #define P_READ_A(base, half)                                                                         \
     _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                               \
-        af[t_][0] = *reinterpret_cast<const bf16x8*>((base) + (half) * G256_HALF + offA + t_ * 2048 + c0); \
-        af[t_][1] = *reinterpret_cast<const bf16x8*>((base) + (half) * G256_HALF + offA + t_ * 2048 + c1); \
+        const i64x2v lo_ = *reinterpret_cast<const i64x2v*>((base) + (half) * G256_HALF + offA + t_ * 2048 + c0); \
+        const i64x2v hi_ = *reinterpret_cast<const i64x2v*>((base) + (half) * G256_HALF + offA + t_ * 2048 + c1); \
+        if constexpr (FP8) af8[t_] = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3);                  \
+        else { af[t_][0] = lo_; af[t_][1] = hi_; }                                                   \
     }
 #define P_READ_B(dst, base, half)                                                                    \
     _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {                                               \
-        dst[t_][0] = *reinterpret_cast<const bf16x8*>((base) + (half) * G256_HALF + offB + t_ * 2048 + c0); \
-        dst[t_][1] = *reinterpret_cast<const bf16x8*>((base) + (half) * G256_HALF + offB + t_ * 2048 + c1); \
+        const i64x2v lo_ = *reinterpret_cast<const i64x2v*>((base) + (half) * G256_HALF + offB + t_ * 2048 + c0); \
+        const i64x2v hi_ = *reinterpret_cast<const i64x2v*>((base) + (half) * G256_HALF + offB + t_ * 2048 + c1); \
+        if constexpr (FP8) dst##8[t_] = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3);               \
+        else { dst[t_][0] = lo_; dst[t_][1] = hi_; }                                                 \
     }
 #define P_MFMA(a, bfr, b)                                                                            \
     do {                                                                                             \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
         __builtin_amdgcn_sched_barrier(0);                                                           \
         __builtin_amdgcn_s_setprio(1);                                                               \
-        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                          \
+        if constexpr (FP8) {                                                                         \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
-                _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                     \
-                    acc[a][i_][b][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j_][ks_], af[i_][ks_], acc[a][i_][b][j_], 0, 0, 0); \
+                _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                   \
+                    acc[a][i_][b][j_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(            \
+                        __builtin_bit_cast(i32x8v, bfr##8[j_]), __builtin_bit_cast(i32x8v, af8[i_]), acc[a][i_][b][j_], 0, 0, 0, \
+                        0x7f7f7f7f, 0, 0x7f7f7f7f);                                                  \
+                }                                                                                    \
+        } else {                                                                                     \
+            _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                      \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                     \
+                    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                 \
+                        acc[a][i_][b][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                 \
+                            __builtin_bit_cast(bf16x8, bfr[j_][ks_]), __builtin_bit_cast(bf16x8, af[i_][ks_]), acc[a][i_][b][j_], 0, 0, 0); \
+        }                                                                                            \
         __builtin_amdgcn_s_setprio(0);                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                           \
         __builtin_amdgcn_s_barrier();                                                                \
@@ -219,6 +245,12 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     P_ISSUE(1, 0, 0);
     float* sbias = reinterpret_cast<float*>(smem + G256_LDS);
     for (int i = tid; i < g.N; i += 512) sbias[i] = g.bias ? g.bias[i] : 0.f;
+    float* sws = sbias + g.N;                          // FP8: per-output-channel weight scales [N]
+    float* sas = sws + g.N;                            // FP8: the current tile's 256 activation-row scales
+    if (FP8)
+        for (int i = tid; i < g.N; i += 512) sws[i] = g.w_scale[i];
+    __amdgpu_buffer_rsrc_t rsS;
+    if (FP8) rsS = __builtin_amdgcn_make_buffer_rsrc((void*)g.a_scale, 0, (unsigned)g.M * 4u, 0x00020000);
     // (the compiler's wait for these loads also retires the loaders' DMA above; harmless, once per launch.
     //  The tile-start barrier below publishes sbias: every wave reaches it after its ds_write + lgkmcnt(0).)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -228,7 +260,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     unsigned short* const outp = static_cast<unsigned short*>(g.out);
 
     // development stamps (dbg & 4): [wave][tile][stamp] 100 MHz wall-clock ticks in LDS, dumped at the end
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + G256_LDS + g.N * 4);
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + G256_LDS + g.N * 4 * (FP8 ? 2 : 1) + (FP8 ? 1024 : 0));
     int tile_i = 0;
     unsigned long long kst[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define P_STAMP(k)                                                                                   \
@@ -267,6 +299,13 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
             if (last_kt) {
                 ktn = 0;
                 if (has_next) set_tile(nm0, nn0);      // the current offsets are dead: K-tile nk-1 is issued
+                if (FP8 && wave == 0) {                // a_scale[m0 .. m0+255] -> sas (rows past M read as 0: never stored);
+                    // older than this K-tile's prefetch: retired by its P3 wait
+                    unsigned lo_;
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo_));
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) char*)sas, 16,
+                                                             (unsigned)m0 * 4u + lo_ * 16u, 0, 0, 0);
+                }
             }
             P_KTILE(cur, 1, ktn, nb, 8, 8, 8);
         }
@@ -284,6 +323,40 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
                 bz[b][nt] = *reinterpret_cast<const f32x4*>(sbias + n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg);
+        // FP8: sc[a][mt][b][nt] multiplies the accumulator: w_scale of the lane's 4 columns x a_scale of its row
+        f32x4 wsv[2][2];
+        float asv[2][4];
+        if constexpr (FP8) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    wsv[b][nt] = *reinterpret_cast<const f32x4*>(sws + n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg);
+            // asm reads: a compiler-visible read of an LDS-DMA destination is preceded by vmcnt(0)
+            const unsigned sa_ = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sas + (wm * 64 + fr) * 4;
+            asm volatile(
+                "ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:64\n\tds_read_b32 %2, %8 offset:128\n\tds_read_b32 %3, %8 offset:192\n\t"
+                "ds_read_b32 %4, %8 offset:512\n\tds_read_b32 %5, %8 offset:576\n\tds_read_b32 %6, %8 offset:640\n\t"
+                "ds_read_b32 %7, %8 offset:704\n\ts_waitcnt lgkmcnt(0)"
+                : "=&v"(asv[0][0]), "=&v"(asv[0][1]), "=&v"(asv[0][2]), "=&v"(asv[0][3]), "=&v"(asv[1][0]), "=&v"(asv[1][1]),
+                  "=&v"(asv[1][2]), "=&v"(asv[1][3])
+                : "v"(sa_)
+                : "memory");
+        }
+        // bias (and the FP8 scales) are folded into the accumulators in place, before the staging passes: the
+        // per-column / per-row factors are dead by the time the passes need registers for their LDS traffic
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        if constexpr (FP8) acc[a][mt][b][nt] = acc[a][mt][b][nt] * (wsv[b][nt] * asv[a][mt]) + bz[b][nt];
+                        else acc[a][mt][b][nt] = acc[a][mt][b][nt] + bz[b][nt];
+                    }
+#define P_SCALED(accv, a_, mt_, b_, nt_) (accv)
         if constexpr (EPI == EPI_BIAS_RESID_F32) {
             // Residual stream update out[m][n] = (acc + bias) + out[m][n] (the add order of gemm256: bit-identical).
             // Eight sub-passes sp of 32 tile rows ((sp>>2)*128 + (sp&1)*64 + ((sp>>1)&1)*32 ..+31: the rows the
@@ -314,7 +387,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                 if (wm == h) {
 #define P_STAGE32(mt, b, nt)                                                                         \
     do {                                                                                             \
-        const f32x4 x_ = acc[sp >> 2][((sp >> 1) & 1) * 2 + (mt)][b][nt] + bz[b][nt];                \
+        const f32x4 x_ = P_SCALED(acc[sp >> 2][((sp >> 1) & 1) * 2 + (mt)][b][nt], sp >> 2, ((sp >> 1) & 1) * 2 + (mt), b, nt); \
         asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(stage_addr[nt]), "v"(x_), "n"((mt) * 16384 + (b) * 512) : "memory"); \
     } while (0)
 #define P_STAGE32_MT(mt) P_STAGE32(mt, 0, 0); P_STAGE32(mt, 0, 1); P_STAGE32(mt, 1, 0); P_STAGE32(mt, 1, 1)
@@ -392,7 +465,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                 // two lane addresses (nt = 0, 1) + immediates mt*8192 + b*256
     #define P_STAGE(mt, b, nt)                                                                           \
         do {                                                                                             \
-            f32x4 x_ = acc[a][mt][b][nt] + bz[b][nt];                                                    \
+            f32x4 x_ = P_SCALED(acc[a][mt][b][nt], a, mt, b, nt);                                        \
             if (EPI == EPI_BIAS_QGELU_BF16) x_ = quick_gelu4(x_);                                        \
             const uint2 pk_ = make_uint2(pack_bf16x2(x_.x, x_.y), pack_bf16x2(x_.z, x_.w));              \
             asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(stage_addr[nt]), "v"(pk_), "n"((mt) * 8192 + (b) * 256) : "memory"); \
@@ -452,6 +525,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.pos)) + (blockIdx.x ? 256 : 0);
         if (tid < 256) dst[tid] = stamps[tid];
     }
+#undef P_SCALED
 #undef P_STAMP
 #undef P_ISSUE
 #undef P_WAIT

@@ -144,3 +144,35 @@ def test_fp8_needs_width_multiple_of_256(clipmi, gpu):
     images, _ = clip_case.inputs("toy_seed0")
     with pytest.raises(clipmi.ClipmiError, match="256"):
         model.encode_image(images)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(21750, 2304, 768, 0), (21750, 3072, 768, 1), (21750, 768, 3072, 2), (43500, 768, 768, 2),
+                                       (33000, 1024, 1024, 0), (70001, 256, 256, 1)])
+def test_gemm_fp8_persistent_matches_plain_launch(clipmi, gpu, M, N, K, epi):
+    """More than 256 tiles: the persistent role-split kernel on FP8 operands (loader / storer waves, w_scale in LDS,
+    the tile's a_scale by LDS-DMA) performs the same MFMA sequence per element as gemm256f8<MX>: bit-identical,
+    including the residual epilogue and M-edge tiles; twice for determinism."""
+    L = clipmi._lib.lib()
+    g = torch.Generator(device="cpu"); g.manual_seed(M + N + K + epi)
+    a = _bf16(torch.randn(M, K, generator=g) * (0.2 + 3 * torch.rand(M, 1, generator=g)))
+    w = _bf16(torch.randn(N, K, generator=g) * K ** -0.5 * (0.5 + torch.rand(N, 1, generator=g)))
+    a8, sa = _quant_rows(a)
+    w8, sw = _quant_rows(w)
+    a8d, w8d, sad, swd = a8.to(gpu), w8.to(gpu), sa.to(gpu), sw.to(gpu)
+    biasd = torch.randn(N, generator=g).to(gpu)
+    res = torch.randn(M, N, generator=g).to(gpu) if epi == 2 else None
+    outs = []
+    for flags in (2 << 8, 0, 0):                        # bit 9: MX form on the non-persistent kernel; 0: default
+        if epi == 2:
+            out = torch.full((M + 1, N), float("nan"), dtype=torch.float32, device=gpu)
+            out[:M] = res
+        else:
+            out = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device=gpu)
+        rc = L.clipmi_dbg_gemm_fp8(a8d.data_ptr(), w8d.data_ptr(), sad.data_ptr(), swd.data_ptr(), biasd.data_ptr(),
+                                   out.data_ptr(), M, N, K, epi | flags, None)
+        clipmi._lib.check(rc, "gemm_fp8")
+        torch.cuda.synchronize()
+        assert torch.isnan(out[M]).all(), "wrote past row M"
+        outs.append(out[:M])
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
