@@ -146,7 +146,7 @@ def make_transform(n_px):
 
 
 def available_models():
-    return [k for k in weights.ARCHS if k != "toy"]
+    return [k for k in weights.ARCHS if not k.startswith("toy")]
 
 
 def load(name, device="cuda" if torch.cuda.is_available() else "cpu", jit=False, seed=None):

@@ -27,6 +27,9 @@ ARCHS = {
     # 101 tokens (> 80: flash-style attention path)
     "toy-l14": dict(v_width=128, v_layers=2, patch=14, res=140,
                     t_width=128, t_layers=2, ctx=16, vocab=512, embed=128),
+    # width 256 (the smallest the FP8 path accepts), 101 tokens (flash attention), 3 layers
+    "toy-256": dict(v_width=256, v_layers=3, patch=14, res=140,
+                    t_width=128, t_layers=2, ctx=16, vocab=512, embed=128),
     # 2-layer toy used by kernel-level tests (SURVEY.md §8c fixture (i))
     "toy": dict(v_width=128, v_layers=2, patch=32, res=64,
                 t_width=128, t_layers=2, ctx=16, vocab=512, embed=128),

@@ -176,3 +176,24 @@ def test_gemm_fp8_persistent_matches_plain_launch(clipmi, gpu, M, N, K, epi):
         outs.append(out[:M])
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
+@pytest.mark.parametrize("B", [3, 700])
+def test_encode_image_fp8_other_geometry(clipmi, gpu, B):
+    """Width 256, 101 tokens (flash attention), 14-pixel patches: the FP8 linear layers at the smallest supported
+    width, through the non-persistent kernel (B = 3) and the persistent one (B = 700: 277 row tiles x 3 column
+    tiles > 256 workgroups for qkv / c_fc); same measured-tolerance rule."""
+    sd = clipmi.weights.random_state_dict("toy-256", seed=5)
+    g = torch.Generator(device="cpu"); g.manual_seed(B)
+    images = torch.randn(B, 3, 140, 140, generator=g)
+    n = min(B, 6)
+    got = clipmi.CLIP(sd, device=gpu, vision_weights="fp8").encode_image(images).cpu()[:n]
+    sdr = clipmi.weights.bf16_round_state_dict(sd)
+    ref = clip_oracle.encode_image(sdr, images[:n])
+    with clip_oracle.act_round(torch.bfloat16), clip_oracle.linear_fp8():
+        emu = clip_oracle.encode_image(sdr, images[:n])
+    noise = (emu - ref).abs().max().item()
+    err = (got - ref).abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(got.double(), ref.double(), dim=-1).min().item()
+    print(f"toy-256 B={B}: fp8 err {err:.4g} (emulation noise {noise:.4g}), cosine {cos:.5f}")
+    assert torch.isfinite(got).all() and err <= 3 * noise + 1e-3 and cos >= 0.99
