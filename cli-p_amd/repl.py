@@ -157,6 +157,10 @@ def main():
     db = vstore.VectorStore("vectors.lmdb", dim=model.embed_dim)
     index = read_index("images.index", device=device)
     index.nprobe = 32
+    # large libraries: scan a coarse copy first (identical results; CLIPMI_COARSE = int8 | bf16 | none)
+    coarse = os.environ.get("CLIPMI_COARSE", "int8")
+    if coarse in ("int8", "bf16") and index.d == 512 and index.ntotal >= 65536:
+        index.coarse = coarse
     try:
         repl(model, index, db)
     except (EOFError, KeyboardInterrupt):
