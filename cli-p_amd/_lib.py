@@ -59,6 +59,11 @@ def lib():
         raise ClipmiError(
             f"{LIB_PATH} is missing: build the HIP library first "
             "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    from . import build as _build
+    if os.path.isdir(_build.CSRC) and not _build.is_current():
+        raise ClipmiError(
+            f"{LIB_PATH} does not match the sources under csrc/ (content stamp mismatch): rebuild "
+            "(python cli-p_amd/build.py). A stale HIP library is never loaded silently.")
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
     TP = C.POINTER(Tower)

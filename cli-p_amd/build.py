@@ -2,7 +2,15 @@
 
 `python cli-p_amd/build.py` or `__graft_entry__.build()`. hipcc cross-compiles without a GPU.
 The .so is git-ignored but travels with the tree to the GPU box (it is not gpurun-ignored).
+
+Staleness is decided by CONTENT, not mtimes: each object file has a stamp holding the SHA-256 of its
+source, every header and the compiler flags; the library has one over the object stamps. A stamp that
+does not match (edited source, changed flags, a .so copied in from elsewhere) recompiles.
+`CLIPMI_FORCE_BUILD=1` (or force=True / `--force`) recompiles everything. build() returns a report
+dict — how many translation units were compiled vs reused — that `__graft_entry__.build()` prints.
 """
+import hashlib
+import json
 import os
 import subprocess
 import sys
@@ -12,33 +20,69 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libclipmi.so")
+STAMP = LIB + ".stamp"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]
 
 
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _sha(paths, extra=()):
+    h = hashlib.sha256()
+    for p in paths:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    for e in extra:
+        h.update(str(e).encode() + b"\0")
+    return h.hexdigest()
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def source_digest():
+    """Digest of everything libclipmi.so is made from (sources, headers, flags)."""
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))
+    headers.append(os.path.join(HERE, "..", "include", "clipmi.h"))
+    srcs = [os.path.join(CSRC, s) for s in _sources()]
+    return _sha(srcs + headers, FLAGS + LINK_FLAGS)
+
+
+def is_current():
+    """True when libclipmi.so exists and its stamp matches the sources in the tree."""
+    st = _read(STAMP)
+    if st is None or not os.path.exists(LIB):
+        return False
+    try:
+        return json.loads(st).get("digest") == source_digest()
+    except ValueError:
+        return False
 
 
 def build(force=False, verbose=True):
+    force = force or os.environ.get("CLIPMI_FORCE_BUILD", "") not in ("", "0")
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))
     headers.append(os.path.join(HERE, "..", "include", "clipmi.h"))
-    jobs = []
-    objs = []
+    jobs, objs, stamps = [], [], {}
     for src in _sources():
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src[:-4] + ".o")
+        digest = _sha([s] + headers, FLAGS)
         objs.append(o)
-        if force or _stale(o, [s] + headers):
-            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
+        stamps[o] = digest
+        if force or not os.path.exists(o) or _read(o + ".stamp") != digest:
+            jobs.append((src, [HIPCC] + FLAGS + ["-c", s, "-o", o], o, digest))
 
     def run(cmd):
         if verbose:
@@ -49,12 +93,30 @@ def build(force=False, verbose=True):
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
+    def compile_one(job):
+        _, cmd, o, digest = job
+        if os.path.exists(o + ".stamp"):
+            os.remove(o + ".stamp")
+        run(cmd)
+        with open(o + ".stamp", "w") as f:
+            f.write(digest + "\n")
+
     with ThreadPoolExecutor(max_workers=4) as ex:
-        list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
-    return LIB
+        list(ex.map(compile_one, jobs))
+    digest = source_digest()
+    linked = False
+    if force or jobs or not is_current():
+        if os.path.exists(STAMP):
+            os.remove(STAMP)
+        run([HIPCC] + LINK_FLAGS + objs + ["-o", LIB])
+        with open(STAMP, "w") as f:
+            json.dump({"digest": digest, "objects": {os.path.basename(o): d for o, d in stamps.items()}}, f)
+        linked = True
+    return {"lib": LIB, "units": len(objs), "compiled": [j[0] for j in jobs], "reused": len(objs) - len(jobs),
+            "linked": linked, "forced": bool(force), "digest": digest}
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    rep = build(force="--force" in sys.argv)
+    print(f"{rep['lib']}: compiled {len(rep['compiled'])} of {rep['units']} translation units "
+          f"({', '.join(rep['compiled']) or 'none'}), linked={rep['linked']}, digest {rep['digest'][:16]}")

@@ -580,8 +580,12 @@ struct CoarseArgs {
     unsigned* overflow;          // set to 1 when a list would exceed cap
 };
 
-constexpr int COARSE_LIST = 1536;       // per-wave (query, row) list entries in LDS
-constexpr int COARSE_FLUSH = 512;       // flush when more than this many are pending (a step adds <= 1024)
+// Per-wave (query, row) list in LDS. One 32-row step appends at most 2 row tiles x QG x 4 rows x 64 lanes =
+// 512*QG pairs and the flush test runs once per step, so the list holds COARSE_FLUSH + 512*QG entries: it cannot
+// overrun by construction (and the append is bound-checked all the same: a miss arms the exact fallback).
+constexpr int COARSE_FLUSH = 512;       // flush when more than this many are pending
+constexpr int coarse_list_entries(int QG) { return COARSE_FLUSH + 512 * QG; }
+constexpr size_t coarse_wave_bytes(int QG) { return (size_t)coarse_list_entries(QG) * 8 + 16; }
 
 // PREPASS only changes the kernel's NAME (the level-2 pre-pass over S2 rows must not dilute the profiler's
 // per-name average of the main scan).
@@ -592,6 +596,8 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
     constexpr int ROWB = I8 ? E : 2 * E;     // bytes per row of the coarse copy
     constexpr int SLOTS = 2 * KS;       // one step = two row tiles (32 rows): SLOTS 16-byte fragments per lane
     constexpr int NCH = SLOTS / 8;
+    constexpr int COARSE_LIST = coarse_list_entries(QG);
+    static_assert(COARSE_LIST >= COARSE_FLUSH + 2 * QG * 4 * 64, "a step's appends must fit behind a pending flush");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -629,7 +635,7 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
         }
         qimg[idx] = v;
     }
-    uint2* list = reinterpret_cast<uint2*>(smem + QG * KS * 1024 + (size_t)wave * (COARSE_LIST * 8 + 16));
+    uint2* list = reinterpret_cast<uint2*>(smem + QG * KS * 1024 + (size_t)wave * coarse_wave_bytes(QG));
     int* lcnt = reinterpret_cast<int*>(list + COARSE_LIST);
     if (lane == 0) *lcnt = 0;
     __syncthreads();
@@ -767,7 +773,8 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
                             const long long row = step * 32 + rt * 16 + 4 * g + r;
                             if (active[qg] && row <= last_row && val[rt][qg][r] >= tau[qg]) {
                                 const int pos = atomicAdd(lcnt, 1);
-                                list[pos] = make_uint2((unsigned)(qg * 16 + col), (unsigned)row);
+                                if (pos < COARSE_LIST) list[pos] = make_uint2((unsigned)(qg * 16 + col), (unsigned)row);
+                                else *a.overflow = 1u;       // unreachable (static_assert above); never write past the list
                             }
                         }
                 wave_lds_sync();
@@ -790,7 +797,7 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
     unsigned* hoff = hist + 2 * QMAXC;                               // running offsets
     if (tid < QMAXC) { hist[tid] = 0; hoff[tid] = 0; }
     __syncthreads();
-    const int n_mine = *lcnt;
+    const int n_mine = *lcnt < COARSE_LIST ? *lcnt : COARSE_LIST;
     for (int e = lane; e < n_mine; e += 64) atomicAdd(&hist[list[e].x], 1u);
     __syncthreads();
     if (tid < QMAXC) gbase[tid] = hist[tid] ? atomicAdd(&a.gcnt[tid], hist[tid]) : 0u;
@@ -1037,10 +1044,11 @@ constexpr int COARSE_Q = 64;                     // queries per coarse pass. (12
 
 template <int QG, bool PREPASS, bool I8>
 int launch_coarse(const CoarseArgs& a, long long nsteps, hipStream_t st, hipEvent_t* ev) {
-    // 128 queries need a 128-KiB bf16 query image: only two waves' candidate lists fit beside it
-    constexpr int WAVES = QG > 4 ? 2 : 4;
+    static_assert(QG <= 4, "64 queries per pass at most");
+    constexpr int WAVES = 4;
     // the final publication reuses the head of the query image for 3 * 16 QG counters: keep >= 1 KiB
-    const size_t lds = (size_t)QG * (512 / (I8 ? 64 : 32)) * 1024 + WAVES * (COARSE_LIST * 8 + 16);
+    const size_t lds = (size_t)QG * (512 / (I8 ? 64 : 32)) * 1024 + WAVES * coarse_wave_bytes(QG);
+    if (lds > (size_t)LDS_LIMIT) return set_err(CLIPMI_EUNSUPPORTED, "scan_coarse: %zu B of LDS", lds);
     if (int rc = opt_in_lds((const void*)scan_coarse_kernel<512, QG, PREPASS, I8>, lds)) return rc;
     long long g_ = (nsteps + WAVES - 1) / WAVES;
     const int grid = (int)(g_ < NUM_CU ? g_ : NUM_CU);

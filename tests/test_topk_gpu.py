@@ -250,6 +250,65 @@ def test_coarse_int8_overflow_falls_back_to_exact(clipmi, gpu, topk_oracle):
     _assert_exact(D, I, Ds, Is, "int8 coarse overflow fallback")
 
 
+@pytest.mark.parametrize("kind", ["bf16", "int8"])
+@pytest.mark.parametrize("Q", [64, 130])
+def test_coarse_identical_rows_many_queries(clipmi, gpu, topk_oracle, kind, Q):
+    """300 k identical rows at Q > 32 (scan_coarse_kernel<QG=4>): EVERY (query, row) pair of every 32-row step
+    passes the coarse test, i.e. the per-wave LDS list takes its maximum of 2048 appends per step behind up to
+    512 pending ones (the round-1 list held 1536: VERDICT r01 weak #1). Lists overflow their global capacity,
+    the exact fallback runs; results equal the oracle's bits, ties by ascending id."""
+    rng = np.random.default_rng(780 + Q)
+    N = 300000
+    v = unit_rows(rng, 1, 512)
+    db = np.repeat(v, N, axis=0)
+    db[123456] *= np.float32(1.5)
+    q = unit_rows(rng, Q, 512)
+    D, I = _run_coarse(clipmi, gpu, db, q, 20, kind=kind)
+    Ds, Is = topk_oracle.topk(db, q, 20)
+    _assert_exact(D, I, Ds, Is, f"{kind} identical rows Q={Q}")
+
+
+@pytest.mark.parametrize("kind", ["bf16", "int8"])
+@pytest.mark.parametrize("Q", [64, 130])
+def test_coarse_duplicate_cluster_many_queries(clipmi, gpu, topk_oracle, kind, Q):
+    """A run of 4096 consecutive duplicates of a row that ranks first for every one of Q similar queries (burst
+    shots + near-identical prompts): 128 consecutive 32-row steps in which all 64 queries of a pass accept all 32
+    rows (2048 pairs per step per wave) WITHOUT overflowing the global lists (4096 < 2^18), so the answer comes
+    from the coarse path itself, not from the fallback."""
+    rng = np.random.default_rng(790 + Q)
+    N = 100000
+    db = unit_rows(rng, N, 512)
+    base = unit_rows(rng, 1, 512)[0]
+    db[30000:34096] = base
+    db[77777] = base                                    # one more copy far away: loses every tie to the run
+    q = base[None, :] + 0.02 * unit_rows(rng, Q, 512)
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    D, I = _run_coarse(clipmi, gpu, db, q, 51, kind=kind)
+    Ds, Is = topk_oracle.topk(db, q, 51)
+    _assert_exact(D, I, Ds, Is, f"{kind} duplicate cluster Q={Q}")
+    assert (I[:, 0] == 30000).all() and (I[:, 50] == 30050).all()
+
+
+@pytest.mark.parametrize("kind", ["bf16", "int8"])
+def test_coarse_prepass_threshold_useless(clipmi, gpu, topk_oracle, kind):
+    """Q = 64 with pre-pass thresholds that filter nothing. (A literal -inf threshold needs < K finite scores in
+    the sample, i.e. NaN rows, and a non-finite row norm already routes the call to the exact path — so the
+    reachable worst case is a threshold below every score.) The first 40 k rows — all of the level-1 and level-2
+    samples — score about -125 against every query, later rows about 0: thr0 ~ -125, the main coarse pass accepts
+    every (query, row) pair of all 70 k rows: 2048 appends per 32-row step in every wave, 70 k survivors per
+    query (< 2^18: no fallback)."""
+    rng = np.random.default_rng(801)
+    N = 70001
+    q = unit_rows(rng, 64, 512)
+    u = q.sum(axis=0); u /= np.linalg.norm(u)
+    db = unit_rows(rng, N, 512)
+    db[:40000] = (-1000.0 * u)[None, :] * (1.0 + 1e-6 * np.arange(40000, dtype=np.float32))[:, None]
+    D, I = _run_coarse(clipmi, gpu, db, q, 51, kind=kind)
+    Ds, Is = topk_oracle.topk(db, q, 51)
+    _assert_exact(D, I, Ds, Is, f"{kind} useless pre-pass threshold")
+    assert (I >= 40000).all()
+
+
 def test_quantize_rows_i8_matches_numpy(clipmi, gpu):
     """clipmi_quantize_rows_i8: scale = max|x| / 127, q = rint(x / scale) (round half to even), error norm >= the
     true one and within 0.2 % of it."""
