@@ -84,7 +84,13 @@ class IndexFlatIP:
 
     def add(self, x):
         """Append rows (numpy f32 [n,d] as in build-index.py:99,107, or a torch tensor)."""
-        t = torch.as_tensor(x) if not isinstance(x, torch.Tensor) else x
+        if not isinstance(x, torch.Tensor):
+            x = np.asarray(x)
+            if not x.flags.writeable:
+                x = x.copy()                # torch warns on (and may alias) read-only buffers, e.g. np.frombuffer views
+            t = torch.as_tensor(x)
+        else:
+            t = x
         if t.dim() != 2 or t.shape[1] != self.d:
             raise ValueError(f"add: expected [n,{self.d}], got {tuple(t.shape)}")
         t = t.to(device=self.device, dtype=torch.float32).contiguous()
@@ -200,7 +206,7 @@ class IndexFlatIP:
 
     def search(self, x, K):
         """D, I = index.search(features, K) (query-index.py:111): numpy in, numpy out."""
-        q = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)) if not isinstance(x, torch.Tensor) else x
+        q = torch.from_numpy(np.array(x, dtype=np.float32, order="C")) if not isinstance(x, torch.Tensor) else x
         if q.dim() != 2 or q.shape[1] != self.d:
             raise ValueError(f"search: expected [Q,{self.d}], got {tuple(q.shape)}")
         s, i = self.search_device(q, int(K))
@@ -287,7 +293,7 @@ class ShardedFlatIP:
         return torch.from_numpy(ms), torch.from_numpy(mi)
 
     def search(self, x, K):
-        q = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)) if not isinstance(x, torch.Tensor) else x
+        q = torch.from_numpy(np.array(x, dtype=np.float32, order="C")) if not isinstance(x, torch.Tensor) else x
         s, i = self.search_device(q, int(K))
         return s.cpu().numpy(), i.cpu().numpy()
 
@@ -391,35 +397,61 @@ def _read_faiss_ivfflat(f, path):
     return d, mat
 
 
-def read_index(path, device="cuda:0"):
+def read_index(path, device="cuda:0", rows=None, coarse=None):
     """faiss.read_index stand-in (query-index.py:29): reads both formats write_index produces and the
     IndexIVFFlat file the reference's build-index.py writes (rows come back in id order and are searched
-    exactly; `nprobe` is accepted and ignored)."""
+    exactly; `nprobe` is accepted and ignored).
+    rows=(lo, hi): load only that contiguous row range (one rank's shard) — the flat formats
+    seek straight to it; the returned index has `id_base = lo` and `n_file` = the file's row count."""
     with open(path, "rb") as f:
         head = f.read(8)
-        if head[:4] == FAISS_FOURCC_FLAT_IP:
-            f.seek(4)
-            d, n, metric = _read_faiss_header(f)
-            if metric != METRIC_INNER_PRODUCT:
-                raise ValueError(f"{path}: faiss flat index with metric {metric}; only inner product is supported")
-            (count,) = struct.unpack("<Q", f.read(8))
-            if count != n * d:
-                raise ValueError(f"{path}: vector count {count} != ntotal*d {n * d}")
-            data = np.fromfile(f, dtype="<f4", count=n * d)
+        if head[:4] == FAISS_FOURCC_FLAT_IP or head == MAGIC:
+            if head == MAGIC:
+                ver, d, n = struct.unpack("<IIQ", f.read(16))
+                if ver != 1:
+                    raise ValueError(f"{path}: unsupported version {ver}")
+            else:
+                f.seek(4)
+                d, n, metric = _read_faiss_header(f)
+                if metric != METRIC_INNER_PRODUCT:
+                    raise ValueError(f"{path}: faiss flat index with metric {metric}; only inner product is supported")
+                (count,) = struct.unpack("<Q", f.read(8))
+                if count != n * d:
+                    raise ValueError(f"{path}: vector count {count} != ntotal*d {n * d}")
+            lo, hi = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
+            if not (0 <= lo <= hi <= n):
+                raise ValueError(f"{path}: rows {rows} outside 0..{n}")
+            f.seek((lo * d) * 4, 1)
+            data = np.fromfile(f, dtype="<f4", count=(hi - lo) * d)
         elif head[:4] == b"IwFl":
             f.seek(4)
             d, mat = _read_faiss_ivfflat(f, path)
-            n, data = mat.shape[0], mat.reshape(-1)
-        elif head == MAGIC:
-            ver, d, n = struct.unpack("<IIQ", f.read(16))
-            if ver != 1:
-                raise ValueError(f"{path}: unsupported version {ver}")
-            data = np.fromfile(f, dtype="<f4", count=n * d)
+            n = mat.shape[0]
+            lo, hi = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
+            if not (0 <= lo <= hi <= n):
+                raise ValueError(f"{path}: rows {rows} outside 0..{n}")
+            data = np.ascontiguousarray(mat[lo:hi]).reshape(-1)
         else:
             raise ValueError(f"{path}: not a clipmi, faiss IndexFlatIP or faiss IndexIVFFlat file")
-    if data.size != n * d:
-        raise ValueError(f"{path}: truncated ({data.size} of {n * d} floats)")
-    idx = IndexFlatIP(d, device=device)
-    if n:
-        idx.add(data.reshape(n, d))
+    if data.size != (hi - lo) * d:
+        raise ValueError(f"{path}: truncated ({data.size} of {(hi - lo) * d} floats)")
+    idx = IndexFlatIP(d, device=device, coarse=coarse)
+    if hi > lo:
+        idx.add(data.reshape(hi - lo, d))
+    idx.id_base = lo
+    idx.n_file = n
     return idx
+
+
+def index_rows(path):
+    """(ntotal, d) of an index file without loading its rows (flat formats: header only)."""
+    with open(path, "rb") as f:
+        head = f.read(8)
+        if head == MAGIC:
+            _, d, n = struct.unpack("<IIQ", f.read(16))
+            return n, d
+        if head[:4] in (FAISS_FOURCC_FLAT_IP, b"IwFl"):
+            f.seek(4)
+            d, n, _ = _read_faiss_header(f)
+            return n, d
+    raise ValueError(f"{path}: not a clipmi, faiss IndexFlatIP or faiss IndexIVFFlat file")

@@ -7,6 +7,14 @@ skipped, :36-44; a failing file prints '#' and is recorded, :55-61; Ctrl-C still
 :63-64). What differs: images are encoded in batches by the HIP kernels, the store commits once per
 batch, and the index is an exact flat inner-product matrix instead of a trained IVF file.
 
+Multi-GPU (the reference is single-device, build-index.py:17): launched as
+`python -m torch.distributed.run --nproc-per-node N build-index.py DIR/ ...`, rank 0 owns the store. Per
+directory it lists the files still to encode, SORTS them and broadcasts the list; every rank takes the
+contiguous slice `shard_bounds(len(todo), world, rank)` and encodes it on its own GPU — images are
+independent, so the encode path has no collective. After every round of one batch per rank, the ranks'
+(keys, vectors, failures) are gathered to rank 0 over gloo (host-side ingest I/O, not the data path) and
+committed in rank order; rank 0 alone assembles the matrix and writes `images.index`.
+
 Weights: $CLIPMI_WEIGHTS (a local ViT-B-32.pt / state-dict), or CLIPMI_RANDOM_WEIGHTS=<seed> for a
 synthetic model. Knobs: CLIPMI_BATCH (default 435 = whole rounds of GEMM tiles on 256 CUs),
 CLIPMI_WORKERS (decode threads, default 8).
@@ -14,8 +22,9 @@ CLIPMI_WORKERS (decode threads, default 8).
 import os
 
 from . import pipeline, store as vstore
-from .index import IndexFlatIP, write_index
+from .index import IndexFlatIP, shard_bounds, write_index
 from .model import load
+from .ranks import Ranks
 
 EXTS = (".jpg", ".jpeg", ".png")
 
@@ -33,16 +42,39 @@ def candidates(base_path, db):
     return todo
 
 
-def encode_directories(dirs, model, db, batch, workers):
+def encode_directories(dirs, model, db, batch, workers, ranks=None):
+    """ranks=None or world 1: the single-GPU loop. Otherwise `db` is only used on rank 0 (others pass None)."""
+    if ranks is None or ranks.world == 1:
+        for base_path in dirs:
+            print(f"CLIPing {base_path}...")
+            todo = candidates(base_path, db)
+            for ok, feats, bad in pipeline.encode_files(model, todo, batch=batch, workers=workers):
+                if ok:
+                    db.put_vectors(ok, feats)
+                db.mark_skipped(bad)
+                print("." * len(ok) + "#" * len(bad), end="", flush=True)
+            print(flush=True)
+        return
     for base_path in dirs:
-        print(f"CLIPing {base_path}...")
-        todo = candidates(base_path, db)
-        for ok, feats, bad in pipeline.encode_files(model, todo, batch=batch, workers=workers):
-            if ok:
-                db.put_vectors(ok, feats)
-            db.mark_skipped(bad)
-            print("." * len(ok) + "#" * len(bad), end="", flush=True)
-        print(flush=True)
+        if ranks.leader:
+            print(f"CLIPing {base_path}...")
+        # the same sorted list on every rank (rank 0 is the only one that can see what is already stored)
+        todo = ranks.bcast(sorted(candidates(base_path, db)) if ranks.leader else None)
+        lo, hi = shard_bounds(len(todo), ranks.world, ranks.rank)
+        mine = pipeline.encode_files(model, todo[lo:hi], batch=batch, workers=workers)
+        # every rank walks the same number of rounds: the largest slice decides (slices differ by <= 1 file)
+        rounds = (shard_bounds(len(todo), ranks.world, 0)[1] + batch - 1) // batch
+        for _ in range(rounds):
+            got = next(mine, ([], None, []))
+            parts = ranks.gather(got)
+            if ranks.leader:
+                for ok, feats, bad in parts:           # rank order = sorted-list order: deterministic commits
+                    if ok:
+                        db.put_vectors(ok, feats)
+                    db.mark_skipped(bad)
+                    print("." * len(ok) + "#" * len(bad), end="", flush=True)
+        if ranks.leader:
+            print(flush=True)
 
 
 def finalise(db, device, out="images.index"):
@@ -60,16 +92,18 @@ def finalise(db, device, out="images.index"):
 
 
 def main(argv):
-    device = "cuda:0"
+    ranks = Ranks("cuda").init()
+    device = str(ranks.device)
     model, _ = load(os.environ.get("CLIPMI_WEIGHTS", "ViT-B/32"), device=device, jit=False)
     model.eval()
-    db = vstore.VectorStore("vectors.lmdb", dim=model.embed_dim)
+    db = vstore.VectorStore("vectors.lmdb", dim=model.embed_dim) if ranks.leader else None
     try:
         encode_directories(argv, model, db, int(os.environ.get("CLIPMI_BATCH", "435")),
-                           int(os.environ.get("CLIPMI_WORKERS", "8")))
+                           int(os.environ.get("CLIPMI_WORKERS", "8")), ranks)
     except KeyboardInterrupt:
         print("Interrupted!")
-    finalise(db, device)
-    print("Done!")
-    db.close()
-
+    if ranks.leader:
+        finalise(db, device)
+        print("Done!")
+        db.close()
+    ranks.close()

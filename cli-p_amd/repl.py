@@ -5,6 +5,13 @@ line = more results; result lines "score id path"; the best hit is dropped and K
 query-index.py:111,115-116). Text is encoded by the HIP text tower and searched EXACTLY over the flat
 matrix; `p NUM` is accepted and has no effect. Images are shown only if OpenCV is installed.
 
+Multi-GPU (the reference is single-process, query-index.py:20): launched as
+`python -m torch.distributed.run --nproc-per-node N query-index.py`, every rank loads rows
+`shard_bounds(ntotal, world, rank)` of images.index into its own GPU. Rank 0 owns the terminal, the store and
+the text tower and runs the unchanged prompt loop over a `LeaderIndex`: each search first broadcasts
+(features, K) to the followers (a 2-KB host object over gloo), then all ranks run `ShardedFlatIP.search` —
+per-shard exact top-K, ONE all-gather (RCCL), the same merge everywhere. Followers sit in `follow()`.
+
 Weights as for the indexer; the BPE merge table comes from $CLIPMI_BPE_PATH.
 """
 import os
@@ -14,8 +21,9 @@ import time
 import numpy as np
 
 from . import store as vstore, tokenizer
-from .index import read_index
+from .index import ShardedFlatIP, index_rows, read_index, shard_bounds
 from .model import load
+from .ranks import Ranks
 
 HELP = ("Enter a search query and you will receive a list of best matching\nimages. The first number is the "
         "difference score, the second the\nimage ID followed by the filename.\n\nPress q to stop viewing image "
@@ -150,21 +158,71 @@ def repl(model, index, db, inp=input, out=print):
         viewer.close()
 
 
+class LeaderIndex:
+    """What rank 0's prompt loop sees as `index` when the rows are sharded over the ranks: `.search` tells the
+    followers what to search for, then takes part in the collective search itself."""
+
+    def __init__(self, sharded, ranks):
+        self.sharded, self.ranks = sharded, ranks
+        self.nprobe = 1                      # accepted and ignored, as on the flat index
+
+    def search(self, features, K):
+        f = np.ascontiguousarray(features, dtype=np.float32)
+        self.ranks.bcast(("search", f, int(K)))
+        return self.sharded.search(f, int(K))
+
+    def quit(self):
+        self.ranks.bcast(("quit", None, 0))
+
+
+def follow(sharded, ranks):
+    """Ranks > 0: wait for rank 0's next search, join it, until told to quit."""
+    while True:
+        what, f, K = ranks.bcast(None)
+        if what == "quit":
+            return
+        sharded.search(f, K)
+
+
+def open_sharded(path, ranks, coarse=None, local_search=None):
+    """This rank's shard of the index file + the all-gather merge around it. `local_search(q, K, lo)` replaces the
+    GPU search on the CPU/gloo path (tests of the host logic; the product path has no CPU search)."""
+    n, d = index_rows(path)
+    lo, hi = shard_bounds(n, ranks.world, ranks.rank)
+    if local_search is not None:
+        return ShardedFlatIP(None, n, group=ranks.data, local_search=local_search)
+    local = read_index(path, device=str(ranks.device), rows=(lo, hi))
+    if coarse in ("int8", "bf16") and local.d == 512 and local.ntotal >= 65536:
+        local.coarse = coarse
+    return ShardedFlatIP(local, n, group=ranks.data)
+
+
 def main():
-    device = "cuda:0"
+    ranks = Ranks("cuda").init()
+    device = str(ranks.device)
+    # large libraries: scan a coarse copy first (identical results; CLIPMI_COARSE = int8 | bf16 | none)
+    coarse = os.environ.get("CLIPMI_COARSE", "int8")
+    if ranks.world > 1:
+        sharded = open_sharded("images.index", ranks, coarse=coarse)
+        if not ranks.leader:
+            follow(sharded, ranks)
+            ranks.close()
+            sys.exit(0)
+        index = LeaderIndex(sharded, ranks)
+    else:
+        index = read_index("images.index", device=device)
+        if coarse in ("int8", "bf16") and index.d == 512 and index.ntotal >= 65536:
+            index.coarse = coarse
     model, _ = load(os.environ.get("CLIPMI_WEIGHTS", "ViT-B/32"), device=device, jit=False)
     model.eval()
     db = vstore.VectorStore("vectors.lmdb", dim=model.embed_dim)
-    index = read_index("images.index", device=device)
     index.nprobe = 32
-    # large libraries: scan a coarse copy first (identical results; CLIPMI_COARSE = int8 | bf16 | none)
-    coarse = os.environ.get("CLIPMI_COARSE", "int8")
-    if coarse in ("int8", "bf16") and index.d == 512 and index.ntotal >= 65536:
-        index.coarse = coarse
     try:
         repl(model, index, db)
     except (EOFError, KeyboardInterrupt):
         print("Interrupted.")
+    if ranks.world > 1:
+        index.quit()
+        ranks.close()
     db.close()
     sys.exit(0)
-

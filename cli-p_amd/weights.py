@@ -105,9 +105,9 @@ def load_state_dict(path):
         try:
             sd = torch.jit.load(path, map_location="cpu").state_dict()
         except RuntimeError:
-            sd = torch.load(path, map_location="cpu")
-            if hasattr(sd, "state_dict"):
-                sd = sd.state_dict()
+            # a pickled state-dict: tensors and plain containers only (weights_only refuses to unpickle
+            # arbitrary objects from a user-supplied path)
+            sd = torch.load(path, map_location="cpu", weights_only=True)
             if "state_dict" in sd:
                 sd = sd["state_dict"]
     sd = {k: v.float() for k, v in sd.items() if torch.is_tensor(v)}

@@ -15,6 +15,10 @@ CASES = {
     "vitb32_seed0": ("ViT-B/32", 0, False),
     "vitb32_outlier": ("ViT-B/32", 1, True),
     "toy_seed0": ("toy", 0, False),
+    # round 2: the geometry paths that had no independent golden — 14-px patches (K = 588 padded to 640) with
+    # 101 tokens (flash attention), and ViT-B/16 (16-px patches, 197 tokens)
+    "toyl14_seed3": ("toy-l14", 3, False),
+    "vitb16_seed2": ("ViT-B/16", 2, False),
 }
 
 

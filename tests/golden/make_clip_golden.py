@@ -70,7 +70,10 @@ def hf_models(sd):
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    only = sys.argv[1:]                      # optional: regenerate just these cases
     for name in clip_case.CASES:
+        if only and name not in only:
+            continue
         sd = clip_case.state_dict(name)
         images, ids = clip_case.inputs(name)
         vm, tm = hf_models(sd)

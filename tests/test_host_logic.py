@@ -139,3 +139,143 @@ def test_sharded_search_gloo_world2(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").read_text() == "1" and (tmp_path / "ok1").read_text() == "1"
+
+
+def test_read_index_row_ranges(clipmi, tmp_path):
+    """One rank's shard straight from the file (seek, no full load): both flat formats, id_base = lo."""
+    rng = np.random.default_rng(3)
+    x = unit_rows(rng, 101, 512)
+    idx = clipmi.IndexFlatIP(512, device="cpu")
+    idx.add(x)
+    for fmt in ("clipmi", "faiss"):
+        p = str(tmp_path / f"i.{fmt}")
+        clipmi.write_index(idx, p, format=fmt)
+        assert clipmi.index.index_rows(p) == (101, 512)
+        for r in range(3):
+            lo, hi = clipmi.shard_bounds(101, 3, r)
+            part = clipmi.read_index(p, device="cpu", rows=(lo, hi))
+            assert part.id_base == lo and part.n_file == 101 and np.array_equal(part.matrix().numpy(), x[lo:hi])
+        with pytest.raises(ValueError):
+            clipmi.read_index(p, device="cpu", rows=(50, 102))
+
+
+class _FakeModel:
+    """CPU stand-in for the encoder in tests of the build-side HOST logic (file sharding, store commits):
+    features are a fixed function of the decoded pixels, so they do not depend on batch composition or rank."""
+
+    class _V:
+        input_resolution = 32
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.visual = self._V()
+        self.embed_dim = 512
+
+    def encode_image(self, x, normalize=False):
+        f = x.float().reshape(x.shape[0], -1)[:, :512] + 1.0
+        return f / f.norm(dim=-1, keepdim=True) if normalize else f
+
+
+def _make_photo_dir(d, n):
+    from PIL import Image
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(17)
+    for i in range(n):
+        Image.fromarray(rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)).save(os.path.join(d, f"img_{i:05d}.png"))
+    open(os.path.join(d, "broken.jpg"), "wb").write(b"not a jpeg")
+    open(os.path.join(d, "notes.txt"), "w").write("ignored")
+
+
+def _indexer_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import clipmi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.chdir(tmp)
+    ranks = clipmi.ranks.Ranks("cpu", rank=rank, world=world, local=rank).init()
+    db = clipmi.store.VectorStore(os.path.join(tmp, "sharded.store"), dim=512, backend="packed") if ranks.leader else None
+    clipmi.indexer.encode_directories([os.path.join(tmp, "lib") + "/"], _FakeModel(), db, 4, 2, ranks)
+    if ranks.leader:
+        clipmi.indexer.finalise(db, "cpu", out=os.path.join(tmp, "sharded.index"))
+        db.close()
+    ranks.close()
+
+
+def test_sharded_build_gloo_world2(clipmi, tmp_path, capsys):
+    """SURVEY.md §8e build side: the sorted file list is split contiguously over 2 ranks, each encodes its slice,
+    rank 0 ingests every round's results. The store and index must equal the single-process build's, byte for byte."""
+    import torch.multiprocessing as mp
+    tmp = str(tmp_path)
+    _make_photo_dir(os.path.join(tmp, "lib"), 23)
+    db1 = clipmi.store.VectorStore(os.path.join(tmp, "single.store"), dim=512, backend="packed")
+    clipmi.indexer.encode_directories([os.path.join(tmp, "lib") + "/"], _FakeModel(), db1, 4, 2)
+    clipmi.indexer.finalise(db1, "cpu", out=os.path.join(tmp, "single.index"))
+    mp.spawn(_indexer_worker, args=(2, 29500 + (os.getpid() + 7) % 2000, tmp), nprocs=2, join=True)
+    db2 = clipmi.store.VectorStore(os.path.join(tmp, "sharded.store"), dim=512, backend="packed")
+    assert db1.count() == db2.count() == 23
+    for t in ("fn_db", "skip_db", "idx_db"):
+        assert list(db1.b.items_sorted(t)) == list(db2.b.items_sorted(t)), t
+    assert db2.is_skipped(os.path.join(tmp, "lib") + "/broken.jpg")
+    assert open(os.path.join(tmp, "single.index"), "rb").read() == open(os.path.join(tmp, "sharded.index"), "rb").read()
+    # a second sharded run finds nothing left to do (resume semantics, build-index.py:36-44)
+    assert clipmi.indexer.candidates(os.path.join(tmp, "lib") + "/", db2) == []
+    db1.close(); db2.close()
+
+
+def _repl_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import clipmi
+    from conftest import TopkOracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    ranks = clipmi.ranks.Ranks("cpu", rank=rank, world=world, local=rank).init()
+    path = os.path.join(tmp, "images.index")
+    n, d = clipmi.index.index_rows(path)
+    lo, hi = clipmi.shard_bounds(n, world, rank)
+    rows = clipmi.read_index(path, device="cpu", rows=(lo, hi)).matrix().numpy()
+    orc = TopkOracle()
+    sharded = clipmi.repl.open_sharded(path, ranks, local_search=lambda q, k, base: orc.topk(rows, np.asarray(q), k, id_base=base))
+    if not ranks.leader:
+        clipmi.repl.follow(sharded, ranks)
+    else:
+        db = clipmi.store.VectorStore(os.path.join(tmp, "vectors.store"), dim=512, backend="packed")
+        index = clipmi.repl.LeaderIndex(sharded, ranks)
+        script = iter(["c 7", "i 5", "", "p 40", "i 999999", "i 2001", "q"])
+        lines = []
+        clipmi.repl.repl(None, index, db, inp=lambda p: next(script), out=lines.append)
+        index.quit()
+        db.close()
+        open(os.path.join(tmp, "repl.out"), "w").write("\n".join(lines))
+    ranks.close()
+
+
+def test_sharded_query_repl_gloo_world2(clipmi, tmp_path, topk_oracle):
+    """SURVEY.md §8e query side: rank 0 runs the prompt loop, both ranks search their row shard of images.index,
+    one all-gather + merge; printed results equal the single-process exact answer."""
+    import torch.multiprocessing as mp
+    tmp = str(tmp_path)
+    rng = np.random.default_rng(31)
+    N = 3001
+    x = unit_rows(rng, N, 512)
+    x[2999] = x[5]                                           # a duplicate in the other shard
+    keys = [f"/lib/img_{i:05d}.jpg" for i in range(N)]
+    db = clipmi.store.VectorStore(os.path.join(tmp, "vectors.store"), dim=512, backend="packed")
+    db.put_vectors(keys, x)
+    db.assemble()
+    db.close()
+    idx = clipmi.IndexFlatIP(512, device="cpu")
+    idx.add(x)
+    clipmi.write_index(idx, os.path.join(tmp, "images.index"))
+    mp.spawn(_repl_worker, args=(2, 29500 + (os.getpid() + 13) % 2000, tmp), nprocs=2, join=True)
+    lines = open(os.path.join(tmp, "repl.out")).read().splitlines()
+    res = [l for l in lines if l.count(" ") == 2 and l.split()[1].isdigit() and "/lib/img_" in l]
+    # "c 7" -> K = 7 + 0 + 1 per query; the empty line pages only after a TEXT query (query-index.py:100-103)
+    D, I = topk_oracle.topk(x, x[5:6], 8)
+    D2, I2 = topk_oracle.topk(x, x[2001:2002], 8)
+    want = [(f"{D[0][j]:.4f}", int(I[0][j])) for j in range(1, 8)] + [(f"{D2[0][j]:.4f}", int(I2[0][j])) for j in range(1, 8)]
+    got = [(l.split()[0], int(l.split()[1])) for l in res]
+    assert got == want
+    assert I[0][0] == 5 and I[0][1] == 2999                   # the cross-shard duplicate ranks right behind the query row
+    assert "Not found." in lines and "Set to probe 40 subsets." in lines
+    assert all(l.split()[2] == f"/lib/img_{int(l.split()[1]):05d}.jpg" for l in res)

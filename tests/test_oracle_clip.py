@@ -78,3 +78,45 @@ def test_hf_named_checkpoint_maps_onto_openai_names(tmp_path):
     want_t = want_t if torch.is_tensor(want_t) else want_t.pooler_output
     assert (clip_oracle.encode_image(sd, images) - want_i).abs().max() < 1e-4
     assert (clip_oracle.encode_text(sd, ids) - want_t).abs().max() < 1e-4
+
+
+def _module_tree(sd):
+    """nn.Module hierarchy whose state_dict() has exactly the given dotted names (what the upstream TorchScript
+    archive ViT-B-32.pt exposes through torch.jit.load(...).state_dict())."""
+    root = torch.nn.Module()
+    for k, v in sd.items():
+        m = root
+        parts = k.split(".")
+        for p_ in parts[:-1]:
+            if not hasattr(m, p_):
+                m.add_module(p_, torch.nn.Module())
+            m = getattr(m, p_)
+        m.register_parameter(parts[-1], torch.nn.Parameter(v.clone(), requires_grad=False))
+    return root
+
+
+def test_torchscript_archive_and_pickle_loaders(tmp_path):
+    """weights.load_state_dict's TorchScript branch (the format of the reference's ViT-B-32.pt, build-index.py:18):
+    a seeded toy model saved with torch.jit.save comes back name for name, bit for bit; the pickled state-dict
+    branch loads with weights_only (no arbitrary unpickling) and refuses a pickle that carries other objects."""
+    import clipmi
+    sd = clip_case.state_dict("toy_seed0")
+    arch = str(tmp_path / "toy.pt")
+    torch.jit.save(torch.jit.script(_module_tree(sd)), arch)
+    back = clipmi.weights.load_state_dict(arch)
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k].float()) for k in sd)
+    assert clipmi.weights.infer_dims(back) == clipmi.weights.infer_dims(sd)
+    images, ids = clip_case.inputs("toy_seed0")
+    assert torch.equal(clip_oracle.encode_image(back, images), clip_oracle.encode_image(sd, images))
+    pk = str(tmp_path / "toy_sd.pt")
+    torch.save({"state_dict": sd}, pk)
+    back2 = clipmi.weights.load_state_dict(pk)
+    assert all(torch.equal(back2[k], sd[k].float()) for k in sd)
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    bad = str(tmp_path / "evil.pt")
+    torch.save({"visual.conv1.weight": sd["visual.conv1.weight"], "x": Evil()}, bad)
+    with pytest.raises(Exception):
+        clipmi.weights.load_state_dict(bad)
