@@ -3,7 +3,11 @@
 flat inner-product top-50 search, on synthetic data, one process per GPU.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 is accepted both ways: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or as plain `python bench.py --gpus N`,
+in which case this process — before it has touched a GPU — starts that launcher as a CHILD process, relays
+its output (rank 0's JSON line) and exits with its code.
 
 A "step" is one pass of the hot path over one batch: encode a batch of B synthetic 224x224 uint8
 images on every rank (weak: per-GPU work fixed), then — timed in its own bracket — one search
@@ -11,14 +15,23 @@ batch of Q queries for the best K = 50 + 1 (query-index.py:111: k + offset + 1) 
 f32 matrix split contiguously over the ranks (strong: total rows fixed), with ONE all-gather of the
 per-rank partial lists and the K-way merge. Rank 0 prints ONE JSON line.
 
-`value` is images/s (BASELINE.json's first metric); the second metric (queries/s) and its own
-roofline and CPU baseline are in the "search" object of the same line.
+`value` is images/s (BASELINE.json's first metric, configs[1]); the second metric (queries/s) and its own
+roofline and CPU baseline are in the "search" object of the same line. Further objects in the same line:
+  encode_sustained      the same encode step for >= 1 M images (configs[1] says "encode 1M images": ~11 s)
+  encode_fp8            configs[4] encode half (FP8 linear layers)
+  encode_vitl14_336     configs[3]: ViT-L/14@336px, own MFMA roofline
+  search_shard_12p5m    configs[4] search half: one rank's 12.5 M-row share of a 100 M x 512 DB (+ the
+                        all-gather merge when N > 1: at N = 8 this IS the 100 M-row sharded search)
+  cpu_baseline          configs[0] as SURVEY.md §8(d) specifies it (256 JPEGs, B = 1; B = 32 beside it;
+                        flat-IP top-11 over the 256 x 512 result for 16 image-id + 16 text queries)
 """
 import argparse
 import ctypes as C
 import io
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +43,7 @@ sys.path.insert(0, ROOT)
 import clipmi  # noqa: E402
 
 FLOP_PER_IMAGE = 8_817_623_040          # ViT-B/32, L = 50, 2 FLOP per MAC
+FLOP_PER_IMAGE_L14_336 = 381.92e9       # ViT-L/14@336px
 PEAK_BF16_TFLOPS = 2500.0               # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0                   # MI355X HBM3E spec
 
@@ -50,9 +64,37 @@ def parse():
     ap.add_argument("--coarse", choices=["int8", "bf16"], default="int8",
                     help="coarse copy scanned before the exact f32 re-scoring (results are identical either way)")
     ap.add_argument("--k", type=int, default=50, help="results per query (K = k + 1 is searched)")
+    ap.add_argument("--sustained-images", type=int, default=1_000_000, help="images of the encode_sustained leg (0 = skip)")
+    ap.add_argument("--shard-rows", type=int, default=12_500_000, help="rows per rank of the search_shard leg (0 = skip)")
+    ap.add_argument("--l14-batch", type=int, default=266, help="images per step of the ViT-L/14@336px leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp8", action="store_true", help="skip the FP8 (configs[4]) encode measurement")
-    return ap.parse_args()
+    ap.add_argument("--quick", action="store_true",
+                    help="headline encode + search only: no sustained / fp8 / ViT-L / shard legs, no CPU baseline "
+                         "(profiling passes and tests)")
+    a = ap.parse_args()
+    if a.quick:
+        a.sustained_images = a.shard_rows = a.l14_batch = 0
+        a.no_cpu_baseline = a.no_fp8 = True
+    return a
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks as a child `torch.distributed.run` BEFORE this
+    process touches the GPU (never re-exec a process that has initialised it), relay, exit with its code."""
+    have = torch.cuda.device_count()            # does not initialise the GPU on this image
+    if have < a.gpus:
+        print(json.dumps({"error": f"--gpus {a.gpus} but only {have} GPU(s) visible", "n_gpus": a.gpus, "value": None}),
+              flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def bracket(dist, world):
@@ -78,61 +120,111 @@ def timed(fn, steps, warmup, dist, world):
 
 
 def pmc_traffic(key):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json,
-    written by tools/pmc_traffic.py from FETCH_SIZE/WRITE_SIZE with the gfx950 corrections)."""
-    best = None
+    """(HBM bytes per launch, provenance) from the NEWEST committed rocprofv3 --pmc summary
+    (profiles/*_pmc_traffic.json, written by tools/pmc_traffic.py from FETCH_SIZE / WRITE_SIZE with the gfx950
+    corrections). A summary taken with another build of libclipmi.so is refused (traffic = null): the file
+    records the source digest of the library it profiled."""
     pdir = os.path.join(ROOT, "profiles")
-    if os.path.isdir(pdir):
-        for f in sorted(os.listdir(pdir)):
-            if f.endswith("_pmc_traffic.json"):
-                try:
-                    d = json.load(open(os.path.join(pdir, f)))
-                    if key in d:
-                        best = d[key]
-                except Exception:
-                    pass
-    return best
+    files = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_traffic.json")) if os.path.isdir(pdir) else []
+    if not files:
+        return None, "no profiles/*_pmc_traffic.json"
+    f = files[-1]
+    try:
+        d = json.load(open(os.path.join(pdir, f)))
+    except Exception as e:
+        return None, f"{f}: unreadable ({e})"
+    cur = clipmi.build.source_digest()
+    if d.get("lib_digest") != cur:
+        return None, f"{f}: taken with library digest {str(d.get('lib_digest'))[:12]}, this build is {cur[:12]} — stale, not reported"
+    if key not in d:
+        return None, f"{f}: no entry {key}"
+    return d[key], f"profiles/{f}"
 
 
-def cpu_baseline_encode(sd):
-    """Reference semantics on the host cores: JPEG decode + transform + fp32
-    encode at B = 1 per image (build-index.py:47-50) through oracle/clip_oracle.py ("port")."""
+def make_jpegs(n):
     from PIL import Image
-    from oracle import clip_oracle
     rng = np.random.default_rng(0)
-    n = 48
     blobs = []
     for _ in range(n):
         buf = io.BytesIO()
         Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)).save(buf, format="JPEG", quality=95)
         blobs.append(buf.getvalue())
+    return blobs
+
+
+def cpu_baseline_cfg1(sd):
+    """BASELINE.json configs[0] on the host cores, as SURVEY.md §8(d) lays it out: 256 synthetic 224x224 JPEGs
+    (rng 0, quality 95) -> decode + transform + fp32 encode at B = 1 per image (reference semantics,
+    build-index.py:47-50) + normalise, through oracle/clip_oracle.py ("port": clip / faiss are not installable
+    here); the same at B = 32 as a courtesy; then exact flat-IP top-10(+1) over the 256 x 512 result for 16
+    image-id queries (query-index.py:86-99) and 16 synthetic token rows through the text tower (:107-111)."""
+    from PIL import Image
+    from oracle import clip_oracle
+    n = 256
+    blobs = make_jpegs(n)
     tf = clipmi.make_transform(224)
 
-    def run(items):
+    def run_b1(items):
+        rows = []
         t0 = time.perf_counter()
         for b in items:
             x = tf(Image.open(io.BytesIO(b))).unsqueeze(0)
             f = clip_oracle.encode_image(sd, x)
-            f = f / f.norm(dim=-1, keepdim=True)
-        return time.perf_counter() - t0
+            rows.append((f / f.norm(dim=-1, keepdim=True)).numpy().astype("float32"))
+        return time.perf_counter() - t0, rows
 
     # B = 1 matmuls do not scale to every host core: try torch's default thread count (what the
-    # reference would get) and a moderate one, keep the faster, and say which was used
+    # reference would get) and moderate ones, keep the fastest, and say which was used
     default_threads = torch.get_num_threads()
     best_threads, best_rate = default_threads, 0.0
     for nt in sorted({default_threads, min(default_threads, 16), min(default_threads, 32)}):
         torch.set_num_threads(nt)
-        run(blobs[:2])
-        rate = 6 / run(blobs[:6])
+        run_b1(blobs[:2])
+        rate = 6 / run_b1(blobs[:6])[0]
         if rate > best_rate:
             best_threads, best_rate = nt, rate
     torch.set_num_threads(best_threads)
-    dt = run(blobs)
+    dt1, rows = run_b1(blobs)
+    mat = np.concatenate(rows, axis=0)                                   # [256, 512] = the index
+    t0 = time.perf_counter()
+    for lo in range(0, n, 32):
+        x = torch.stack([tf(Image.open(io.BytesIO(b))) for b in blobs[lo:lo + 32]])
+        f = clip_oracle.encode_image(sd, x)
+        f = f / f.norm(dim=-1, keepdim=True)
+    dt32 = time.perf_counter() - t0
+    # query side: K = 10 + 1
+    rng = np.random.default_rng(3)
+    ids = np.zeros((16, 77), dtype=np.int64)
+    for r in range(16):
+        eot = int(rng.integers(4, 30))
+        ids[r, 0] = 49406
+        ids[r, 1:eot] = rng.integers(1, 49406, eot - 1)
+        ids[r, eot] = 49407
+    t0 = time.perf_counter()
+    tq = []
+    for r in range(16):
+        f = clip_oracle.encode_text(sd, torch.from_numpy(ids[r:r + 1])).numpy().astype("float32")
+        nrm = np.linalg.norm(f)
+        tq.append(f if nrm < 1e-9 else f / nrm)
+    dt_text = time.perf_counter() - t0
+    queries = [mat[i:i + 1] for i in range(16)] + tq
+    t0 = time.perf_counter()
+    for q in queries:                                                    # Q = 1 per call, as the REPL does
+        s = (mat @ q.T)[:, 0]
+        top = np.lexsort((np.arange(n), -s))[:11]
+        _ = s[top]
+    dt_search = time.perf_counter() - t0
     torch.set_num_threads(default_threads)
-    return {"value": n / dt, "unit": "images/s", "cores": best_threads, "kind": "port",
-            "sample": f"{n} synthetic 224x224 JPEGs (quality 95): Pillow decode + transform + oracle fp32 "
-                      f"encode at B=1 per image (reference semantics), torch {torch.__version__} CPU, "
-                      f"{best_threads} threads (fastest of default {default_threads} / 32 / 16)"}
+    return {"value": n / dt1, "unit": "images/s", "cores": best_threads, "kind": "port",
+            "sample": f"configs[0]: {n} synthetic 224x224 JPEGs (rng 0, quality 95): Pillow decode + transform + oracle "
+                      f"fp32 encode at B=1 per image (reference semantics) + normalise, torch {torch.__version__} CPU, "
+                      f"{best_threads} threads (fastest of default {default_threads} / 32 / 16), {dt1:.1f} s",
+            "images_per_s_b32": n / dt32,
+            "search_top11_over_256_rows": {"queries": 32, "queries_per_s": 32 / dt_search,
+                                           "text_encode_ms_per_query": dt_text / 16 * 1e3,
+                                           "what": "16 image-id + 16 text queries, numpy f32 dot + exact (score desc, id asc) "
+                                                   "top-11 per query; text tower through the fp32 oracle"},
+            "host_cpus": os.cpu_count()}
 
 
 def cpu_baseline_search(rows_total, Q, K):
@@ -159,13 +251,108 @@ def cpu_baseline_search(rows_total, Q, K):
                       f"to {rows_total} rows"}
 
 
+def unit_rows_device(n, dev, seed):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    db = torch.empty((n, 512), dtype=torch.float32, device=dev)
+    chunk = 1 << 20
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        blk = torch.randn((e - s, 512), generator=g, device=dev)
+        db[s:e] = blk / blk.norm(dim=1, keepdim=True)
+    return db
+
+
+def scan_probe(L, idx, q, Qp, K, dev, kind):
+    """The dominant search kernel alone: HIP events recorded by the library around it on the launch stream.
+    -> (ms, survivors per query or None, algorithmic bytes, kernel name, traffic key)"""
+    db = idx.matrix()
+    n_local = db.shape[0]
+    os_ = torch.empty((64, K), dtype=torch.float32, device=dev)
+    oi_ = torch.empty((64, K), dtype=torch.int64, device=dev)
+    scan_ms = C.c_float(0)
+    survivors = C.c_longlong(-1)
+    qg = 1 if Qp <= 16 else 2 if Qp <= 32 else 4
+    if kind == "int8":
+        db8, meta, amax, rmax = idx.matrix_i8()
+        ws = torch.empty(L.clipmi_topk_ip_coarse_workspace_bytes(n_local, 512, Qp, K), dtype=torch.uint8, device=dev)
+        clipmi._lib.check(L.clipmi_dbg_topk_coarse_i8_scan_ms(db.data_ptr(), db8.data_ptr(), meta.data_ptr(), amax, n_local, 512,
+                                                              rmax, q.data_ptr(), Qp, K, os_.data_ptr(), oi_.data_ptr(),
+                                                              ws.data_ptr(), ws.numel(), clipmi._lib.stream_ptr(dev), 10,
+                                                              C.byref(scan_ms), C.byref(survivors)), "coarse_i8_scan_ms")
+        return (scan_ms.value, survivors.value / Qp, n_local * (512 + 8),     # int8 row + its (scale, error norm) pair
+                f"scan_coarse_kernel<512,{qg},false,true>", "scan_coarse_i8_bytes_per_launch")
+    if kind == "bf16":
+        dbh, rmax = idx.matrix_bf16()
+        ws = torch.empty(L.clipmi_topk_ip_coarse_workspace_bytes(n_local, 512, Qp, K), dtype=torch.uint8, device=dev)
+        clipmi._lib.check(L.clipmi_dbg_topk_coarse_scan_ms(db.data_ptr(), dbh.data_ptr(), n_local, 512, rmax, q.data_ptr(), Qp,
+                                                           K, os_.data_ptr(), oi_.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                           clipmi._lib.stream_ptr(dev), 10, C.byref(scan_ms),
+                                                           C.byref(survivors)), "coarse_scan_ms")
+        return (scan_ms.value, survivors.value / Qp, n_local * 512 * 2,
+                f"scan_coarse_kernel<512,{qg},false,false>", "scan_coarse_bytes_per_launch")
+    ws = torch.empty(L.clipmi_topk_ip_workspace_bytes(n_local, 512, Qp, K), dtype=torch.uint8, device=dev)
+    clipmi._lib.check(L.clipmi_dbg_topk_scan_ms(db.data_ptr(), n_local, 512, q.data_ptr(), Qp, K, os_.data_ptr(),
+                                                oi_.data_ptr(), ws.data_ptr(), ws.numel(), clipmi._lib.stream_ptr(dev),
+                                                10, C.byref(scan_ms)), "scan_ms")
+    return (scan_ms.value, None, n_local * 512 * 4, f"scan_topk_f32_kernel<512,false,{2 if Qp > 16 else 1}>",
+            "scan_bytes_per_launch")
+
+
+def search_leg(L, a, dev, dist, world, rank, rows_total, n_local, seed, steps, warmup):
+    """One search measurement: this rank's `n_local` rows of a `rows_total`-row index, Q queries, K = k + 1."""
+    K, Q = a.k + 1, a.queries
+    db = unit_rows_device(n_local, dev, seed + rank)          # every shard its own rows (no cross-shard duplicates)
+    idx = clipmi.IndexFlatIP(512, device=dev, coarse=None if a.exact_only else a.coarse)
+    idx.add(db)
+    coarse = idx.uses_coarse()
+    kind = (a.coarse if coarse else "f32")
+    if coarse:                   # the coarse copy + row-norm bounds are part of the index, built once
+        idx.matrix_i8() if kind == "int8" else idx.matrix_bf16()
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(2)
+    q = torch.randn((Q, 512), generator=gq, device=dev)
+    q = q / q.norm(dim=1, keepdim=True)
+    searcher = clipmi.ShardedFlatIP(idx, rows_total) if world > 1 else idx
+    res = [None]
+
+    def search_step():
+        res[0] = searcher.search_device(q, K)
+    dt_s = timed(search_step, steps, warmup, dist, world)
+    assert (res[0][1][:, 0] >= 0).all()
+    Qp = min(Q, 64 if coarse else 32)            # queries of ONE pass
+    scan_ms, surv, scan_bytes, scan_name, traffic_key = scan_probe(L, idx, q, Qp, K, dev, kind)
+    scan_gbs = scan_bytes / (scan_ms * 1e-3) / 1e9
+    passes = (Q + Qp - 1) // Qp
+    traffic, tsrc = pmc_traffic(traffic_key)
+    out = {"value": Q * steps / dt_s, "unit": "queries/s", "ms_per_step": dt_s / steps * 1e3, "steps": steps,
+           "dtype": ("int8 coarse scan (i32 MFMA) + f32 exact re-scoring" if kind == "int8" else
+                     "bf16 coarse scan + f32 exact re-scoring" if kind == "bf16" else "f32"),
+           "path": ("coarse-then-exact (clipmi_topk_ip_coarse_i8)" if kind == "int8" else
+                    "coarse-then-exact (clipmi_topk_ip_coarse)" if kind == "bf16" else "exact scan (clipmi_topk_ip)"),
+           "queries_per_batch": Q, "K": K, "rows_per_gpu": n_local, "rows_total": rows_total,
+           "roofline": {"bound": "hbm", "kernel": scan_name, "achieved": scan_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": scan_gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": tsrc,
+                        "kernel_ms": scan_ms, "algorithmic_bytes_per_launch": scan_bytes,
+                        "coarse_survivors_per_query": surv,
+                        "whole_call_gbs_per_gpu": scan_bytes * passes * steps / dt_s / 1e9,
+                        "whole_call_frac": scan_bytes * passes * steps / dt_s / 1e9 / PEAK_HBM_GBS}}
+    del searcher, idx, db
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse()
+    # (CLIPMI_BENCH_FORCE_SPAWN=1 takes the self-spawning path with one rank too: the test of that path on a 1-GPU box)
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("CLIPMI_BENCH_FORCE_SPAWN") == "1"):
+        sys.exit(spawn_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        print(json.dumps({"error": f"--gpus {a.gpus} but WORLD_SIZE={world}", "n_gpus": a.gpus, "value": None}), flush=True)
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
@@ -190,6 +377,16 @@ def main():
     dt_enc = timed(enc_step, a.steps, a.warmup, dist, world)
     img_per_s = world * B * a.steps / dt_enc
     assert torch.isfinite(enc_out[0]).all()
+
+    # configs[1] reads "encode 1M images": the same step repeated until >= 1 M images per GPU have gone through
+    # (about 11 s of sustained bf16 MFMA load: the clock the chip holds under it is part of the answer)
+    sustained = None
+    if a.sustained_images > 0:
+        steps_s = (a.sustained_images + B - 1) // B
+        dt_sus = timed(enc_step, steps_s, 1, dist, world)
+        sustained = {"value": world * B * steps_s / dt_sus, "unit": "images/s", "images_per_gpu": B * steps_s,
+                     "steps": steps_s, "seconds": dt_sus, "ms_per_step": dt_sus / steps_s * 1e3,
+                     "whole_step_frac": FLOP_PER_IMAGE * B * steps_s / dt_sus / 1e12 / PEAK_BF16_TFLOPS}
 
     # BASELINE.json configs[4] beside the headline (never `value`: reduced precision): the same step with the
     # block linear layers on the FP8 matrix cores (e4m3 weights, activations quantised per row on the fly)
@@ -222,75 +419,48 @@ def main():
                       "encode_image_probe")
     gemm_ms = kms.value
     gemm_tflops = 2.0 * M * N * Kd / (gemm_ms * 1e-3) / 1e12
-    del ews, eout
+    del ews, eout, model, images
+    torch.cuda.empty_cache()
+
+    # ---------------- configs[3]: ViT-L/14@336px (24 layers, width 1024, 577 tokens, 768-D) -----------------------
+    l14 = None
+    if a.l14_batch > 0:
+        sdl = clipmi.weights.random_state_dict("ViT-L/14@336px", seed=0)
+        ml = clipmi.CLIP(sdl, device=dev)
+        del sdl
+        Bl = a.l14_batch
+        gi = torch.Generator(device=dev)
+        gi.manual_seed(77 + rank)
+        imgs_l = torch.randint(0, 256, (Bl, 3, 336, 336), generator=gi, device=dev, dtype=torch.uint8)
+        lo_ = [None]
+
+        def l14_step():
+            lo_[0] = ml.encode_image(imgs_l, normalize=True)
+        steps_l = max(3, a.steps // 4)
+        dt_l = timed(l14_step, steps_l, 1, dist, world)
+        assert torch.isfinite(lo_[0]).all()
+        tf_l = FLOP_PER_IMAGE_L14_336 * Bl * steps_l / dt_l / 1e12
+        l14 = {"metric": "images/sec ViT-L/14@336px encode (BASELINE.json configs[3])", "value": world * Bl * steps_l / dt_l,
+               "unit": "images/s", "ms_per_step": dt_l / steps_l * 1e3, "steps": steps_l, "images_per_gpu_per_step": Bl,
+               "dtype": "bf16", "flop_per_image": FLOP_PER_IMAGE_L14_336,
+               "roofline": {"bound": "mfma", "kernel": "whole step (24 layers; GEMMs gemm256p/gemm256, flash attention)",
+                            "achieved": tf_l, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf_l / PEAK_BF16_TFLOPS,
+                            "traffic": None}}
+        del ml, imgs_l
+        torch.cuda.empty_cache()
 
     # ---------------- search: 10M x 512 f32 split over the ranks, Q queries, K = k + 1 -----------
-    K = a.k + 1
-    Q = a.queries
     lo, hi = clipmi.shard_bounds(a.rows, world, rank)
-    n_local = hi - lo
-    gd = torch.Generator(device=dev)
-    gd.manual_seed(1000 + rank)  # every shard its own rows (no cross-shard duplicates)
-    db = torch.empty((n_local, 512), dtype=torch.float32, device=dev)
-    chunk = 1 << 20
-    for s in range(0, n_local, chunk):
-        e = min(n_local, s + chunk)
-        blk = torch.randn((e - s, 512), generator=gd, device=dev)
-        db[s:e] = blk / blk.norm(dim=1, keepdim=True)
-    idx = clipmi.IndexFlatIP(512, device=dev, coarse=None if a.exact_only else a.coarse)
-    idx.add(db)
-    coarse = idx.uses_coarse()
-    i8 = coarse and a.coarse == "int8"
-    if coarse:                   # the coarse copy + row-norm bounds are part of the index, built once
-        idx.matrix_i8() if i8 else idx.matrix_bf16()
-    gq = torch.Generator(device=dev)
-    gq.manual_seed(2)
-    q = torch.randn((Q, 512), generator=gq, device=dev)
-    q = q / q.norm(dim=1, keepdim=True)
-    searcher = clipmi.ShardedFlatIP(idx, a.rows) if world > 1 else idx
-    res = [None]
-
-    def search_step():
-        res[0] = searcher.search_device(q, K)
-    dt_s = timed(search_step, a.steps, a.warmup, dist, world)
-    qps = Q * a.steps / dt_s
-    assert (res[0][1][:, 0] >= 0).all()
-
-    # dominant search kernel alone, HIP events recorded by the library around it on the launch stream
-    Qp = min(Q, 64 if coarse else 32)            # queries of ONE pass
-    os_ = torch.empty((64, K), dtype=torch.float32, device=dev)
-    oi_ = torch.empty((64, K), dtype=torch.int64, device=dev)
-    scan_ms = C.c_float(0)
-    survivors = C.c_longlong(-1)
-    if i8:
-        db8, meta, amax, rmax = idx.matrix_i8()
-        ws = torch.empty(L.clipmi_topk_ip_coarse_workspace_bytes(n_local, 512, Qp, K), dtype=torch.uint8, device=dev)
-        clipmi._lib.check(L.clipmi_dbg_topk_coarse_i8_scan_ms(db.data_ptr(), db8.data_ptr(), meta.data_ptr(), amax, n_local, 512,
-                                                              rmax, q.data_ptr(), Qp, K, os_.data_ptr(), oi_.data_ptr(),
-                                                              ws.data_ptr(), ws.numel(), clipmi._lib.stream_ptr(dev), 10,
-                                                              C.byref(scan_ms), C.byref(survivors)), "coarse_i8_scan_ms")
-        scan_bytes = n_local * (512 + 8)         # int8 row + its (scale, error norm) pair
-        scan_name = f"scan_coarse_kernel<512,{1 if Qp <= 16 else 2 if Qp <= 32 else 4},false,true>"
-        traffic_key = "scan_coarse_i8_bytes_per_launch"
-    elif coarse:
-        dbh, rmax = idx.matrix_bf16()
-        ws = torch.empty(L.clipmi_topk_ip_coarse_workspace_bytes(n_local, 512, Qp, K), dtype=torch.uint8, device=dev)
-        clipmi._lib.check(L.clipmi_dbg_topk_coarse_scan_ms(db.data_ptr(), dbh.data_ptr(), n_local, 512, rmax, q.data_ptr(), Qp,
-                                                           K, os_.data_ptr(), oi_.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                           clipmi._lib.stream_ptr(dev), 10, C.byref(scan_ms),
-                                                           C.byref(survivors)), "coarse_scan_ms")
-        scan_bytes = n_local * 512 * 2
-        scan_name = f"scan_coarse_kernel<512,{1 if Qp <= 16 else 2 if Qp <= 32 else 4},false,false>"
-        traffic_key = "scan_coarse_bytes_per_launch"
-    else:
-        ws = torch.empty(L.clipmi_topk_ip_workspace_bytes(n_local, 512, Qp, K), dtype=torch.uint8, device=dev)
-        clipmi._lib.check(L.clipmi_dbg_topk_scan_ms(db.data_ptr(), n_local, 512, q.data_ptr(), Qp, K, os_.data_ptr(),
-                                                    oi_.data_ptr(), ws.data_ptr(), ws.numel(), clipmi._lib.stream_ptr(dev),
-                                                    10, C.byref(scan_ms)), "scan_ms")
-        scan_bytes = n_local * 512 * 4
-        scan_name = f"scan_topk_f32_kernel<512,false,{2 if Qp > 16 else 1}>"
-        traffic_key = "scan_bytes_per_launch"
-    scan_gbs = scan_bytes / (scan_ms.value * 1e-3) / 1e9
+    search = search_leg(L, a, dev, dist, world, rank, a.rows, hi - lo, 1000, a.steps, a.warmup)
+    search["metric"] = f"queries/sec top-{a.k} over {a.rows}x512 flat IP (exact results, f32 scores)"
+    search["scaling"] = "strong"
+    # configs[4] search half: 12.5 M rows on every rank (weak): at N = 8 a 100 M x 512 DB
+    shard = None
+    if a.shard_rows > 0:
+        shard = search_leg(L, a, dev, dist, world, rank, a.shard_rows * world, a.shard_rows, 5000, max(5, a.steps // 2), 2)
+        shard["metric"] = (f"queries/sec top-{a.k} over {a.shard_rows * world}x512 flat IP, {a.shard_rows} rows per GPU "
+                           f"(BASELINE.json configs[4] search half)")
+        shard["scaling"] = "weak"
 
     if rank != 0:
         if world > 1:
@@ -298,41 +468,37 @@ def main():
             dist.destroy_process_group()
         return
 
+    traffic, tsrc = pmc_traffic("gemm_c_fc_bytes_per_launch")
+    K, Q = a.k + 1, a.queries
     out = {
         "metric": "images/sec ViT-B/32 encode", "value": img_per_s, "unit": "images/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_enc / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"ViT-B/32 bf16 encode of synthetic 224x224 uint8 images (random-init weights, "
-                               f"L=50, 12 layers), {B} images per GPU per step, fused normalise, inputs resident "
-                               f"in HBM; then exact-result flat-IP top-{K} (k={a.k}+1, query-index.py:111) over "
-                               f"{a.rows} x 512 f32 split over {world} GPU(s), Q={Q} per batch",
+        "config": {"workload": f"BASELINE.json configs[1]: ViT-B/32 bf16 encode of synthetic 224x224 uint8 images "
+                               f"(random-init weights, L=50, 12 layers), {B} images per GPU per step, fused normalise, "
+                               f"inputs resident in HBM; then exact-result flat-IP top-{K} (k={a.k}+1, "
+                               f"query-index.py:111) over {a.rows} x 512 f32 split over {world} GPU(s), Q={Q} per batch",
                    "images_per_gpu_per_step": B, "index_rows_total": a.rows, "queries_per_batch": Q, "K": K},
-        "roofline": {"bound": "mfma", "kernel": ("gemm256p_bf16_nt_kernel<1>" if (N // 256) * ((M + 255) // 256) > 256
+        "roofline": {"bound": "mfma", "kernel": ("gemm256p_bf16_nt_kernel<1,false>" if (N // 256) * ((M + 255) // 256) > 256
                                                  else "gemm256_bf16_nt_kernel<1>") +
                                                 f" (MLP c_fc + bias + QuickGELU, M={M} N={N} K={Kd})",
                      "achieved": gemm_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": gemm_tflops / PEAK_BF16_TFLOPS, "traffic": pmc_traffic("gemm_c_fc_bytes_per_launch"),
+                     "frac": gemm_tflops / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
                      "kernel_ms": gemm_ms, "launches_timed": nl.value,
                      "whole_step_tflops_per_gpu": FLOP_PER_IMAGE * B * a.steps / dt_enc / 1e12,
                      "whole_step_frac": FLOP_PER_IMAGE * B * a.steps / dt_enc / 1e12 / PEAK_BF16_TFLOPS},
-        "search": {"metric": f"queries/sec top-{a.k} over {a.rows}x512 flat IP (exact results, f32 scores)", "value": qps,
-                   "unit": "queries/s", "ms_per_step": dt_s / a.steps * 1e3, "scaling": "strong",
-                   "dtype": ("int8 coarse scan (i32 MFMA) + f32 exact re-scoring" if i8 else
-                             "bf16 coarse scan + f32 exact re-scoring" if coarse else "f32"),
-                   "path": ("coarse-then-exact (clipmi_topk_ip_coarse_i8)" if i8 else
-                            "coarse-then-exact (clipmi_topk_ip_coarse)" if coarse else "exact scan (clipmi_topk_ip)"),
-                   "queries_per_batch": Q, "rows_per_gpu": n_local,
-                   "roofline": {"bound": "hbm", "kernel": scan_name,
-                                "achieved": scan_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                "frac": scan_gbs / PEAK_HBM_GBS, "traffic": pmc_traffic(traffic_key),
-                                "kernel_ms": scan_ms.value, "algorithmic_bytes_per_launch": scan_bytes,
-                                "coarse_survivors_per_query": (survivors.value / Qp) if survivors.value >= 0 else None,
-                                "whole_call_gbs_per_gpu": scan_bytes * ((Q + Qp - 1) // Qp) * a.steps / dt_s / 1e9}},
+        "search": search,
     }
+    if sustained is not None:
+        out["encode_sustained"] = sustained
     if fp8_info is not None:
         out["encode_fp8"] = fp8_info
+    if l14 is not None:
+        out["encode_vitl14_336"] = l14
+    if shard is not None:
+        out["search_shard_12p5m"] = shard
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_encode(sd)
+        out["cpu_baseline"] = cpu_baseline_cfg1(sd)
         out["search"]["cpu_baseline"] = cpu_baseline_search(a.rows, Q, K)
     else:
         out["cpu_baseline"] = None

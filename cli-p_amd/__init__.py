@@ -9,6 +9,7 @@ reached through ctypes; torch is used for device memory, streams and torch.distr
 The directory name carries a hyphen, so import it with importlib.import_module("cli-p_amd")
 or through the `clipmi` shim module at the repo root.
 """
+from . import build
 from . import _lib
 from ._lib import ClipmiError
 from .index import (IndexFlatIP, IndexIVFFlat, ShardedFlatIP, METRIC_INNER_PRODUCT, read_index, write_index,

@@ -92,19 +92,47 @@ def test_sharded_search_rccl_single_rank(tmp_path):
     assert (tmp_path / "ok").read_text() == "1"
 
 
-def test_bench_contract_under_torchrun_one_rank(tmp_path):
-    """bench.py launched the way the driver launches N>1 (torch.distributed.run), with one rank and a
-    small index: one JSON line with the contract's keys."""
+BENCH_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "search")
+
+
+def _check_bench_line(stdout):
     import json
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
-           "--warmup", "1", "--rows", "200000", "--batch", "64", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    line = [l for l in stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "search"):
+    for k in BENCH_KEYS:
         assert k in d
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["search"]["value"] > 0
     assert d["roofline"]["bound"] == "mfma" and d["search"]["roofline"]["bound"] == "hbm"
+    return d
+
+
+def test_bench_contract_under_torchrun_one_rank(tmp_path):
+    """bench.py launched the way the driver launches N>1 (torch.distributed.run), with one rank and a
+    small index: one JSON line with the contract's keys; the small configs[3]/configs[4] legs are in the line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
+           "--warmup", "1", "--rows", "200000", "--batch", "64", "--no-cpu-baseline", "--no-fp8", "--sustained-images", "256",
+           "--shard-rows", "150000", "--l14-batch", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _check_bench_line(r.stdout)
+    assert d["encode_sustained"]["images_per_gpu"] >= 256 and d["search_shard_12p5m"]["rows_per_gpu"] == 150000
+    assert d["search_shard_12p5m"]["value"] > 0 and d["search_shard_12p5m"]["roofline"]["bound"] == "hbm"
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` with no launcher in the environment must start the ranks itself (a child
+    torch.distributed.run, before the parent touches the GPU) and relay rank 0's line. One GPU per box here, so the
+    path is taken with N = 1 through CLIPMI_BENCH_FORCE_SPAWN=1."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["CLIPMI_BENCH_FORCE_SPAWN"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--rows", "200000",
+           "--batch", "64", "--quick"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    _check_bench_line(r.stdout)
+    # asking for more GPUs than the box has is a JSON error record and a non-zero exit, not a traceback
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--quick"], capture_output=True,
+                       text=True, timeout=120, cwd=ROOT, env=env)
+    assert r.returncode != 0 and '"error"' in r.stdout
