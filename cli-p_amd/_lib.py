@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libclipmi.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 F32, BF16, U8 = 0, 1, 2
 
 # every symbol include/clipmi.h declares (tests check the .so exports all of them)
@@ -24,6 +24,7 @@ SYMBOLS = [
     "clipmi_l2_normalize_rows", "clipmi_last_error", "clipmi_abi_version",
     "clipmi_dbg_gemm_bf16", "clipmi_dbg_layernorm", "clipmi_dbg_attention", "clipmi_dbg_topk_scan_ms",
     "clipmi_dbg_encode_image_probe_ms",
+    "clipmi_dbg_cast_stats", "clipmi_dbg_gemm_ln", "clipmi_dbg_gemm_resid_ln",
 ]
 
 
@@ -39,8 +40,8 @@ class Tower(C.Structure):
         "lo_ln1_w", "lo_ln1_b", "lo_qkv_w", "lo_qkv_b", "lo_out_w", "lo_out_b",
         "lo_ln2_w", "lo_ln2_b", "lo_fc_w", "lo_fc_b", "lo_proj_w", "lo_proj_b",
         "off_ln_post_w", "off_ln_post_b", "off_out_proj")] + [
-        ("weight_format", C.c_int32), ("reserved0", C.c_int32)] + [(n, C.c_uint64) for n in (
-        "lo_qkv_s", "lo_out_s", "lo_fc_s", "lo_proj_s")]
+        ("weight_format", C.c_int32), ("ln_fold", C.c_int32)] + [(n, C.c_uint64) for n in (
+        "lo_qkv_s", "lo_out_s", "lo_fc_s", "lo_proj_s", "lo_qkv_colsum", "lo_qkv_cb", "lo_fc_colsum", "lo_fc_cb")]
 
 
 class ClipmiError(RuntimeError):
@@ -109,6 +110,12 @@ def lib():
     L.clipmi_l2_normalize_rows.argtypes = [vp, i64, i32, vp]
     L.clipmi_dbg_gemm_bf16.restype = i32
     L.clipmi_dbg_gemm_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.clipmi_dbg_cast_stats.restype = i32
+    L.clipmi_dbg_cast_stats.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    L.clipmi_dbg_gemm_ln.restype = i32
+    L.clipmi_dbg_gemm_ln.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.clipmi_dbg_gemm_resid_ln.restype = i32
+    L.clipmi_dbg_gemm_resid_ln.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.clipmi_dbg_layernorm.restype = i32
     L.clipmi_dbg_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     L.clipmi_dbg_attention.restype = i32

@@ -21,6 +21,9 @@ struct Ws {
     int* rowidx;
     unsigned char* a8;        // weight_format 1: the current GEMM's A operand as e4m3 [B*L][<= 4W]
     float* a_scale;           //                  and its row scales [B*L]
+    unsigned short* xb;       // ln_fold: bf16(x * gamma) [B*L][W], the A operand of the LN-folded qkv / c_fc GEMMs
+    float* ln_stats;          //          (mean, rstd) per row [B*L][2]
+    float* ln_part;           //          per-tile partials of the persistent residual GEMM [B*L][W/256][2]
 };
 
 size_t carve(const clipmi_tower* t, int B, void* base, size_t cap, Ws* out) {
@@ -37,6 +40,11 @@ size_t carve(const clipmi_tower* t, int B, void* base, size_t cap, Ws* out) {
     if (t->weight_format == 1) {
         w.a8 = ar.take<unsigned char>(rows * 4 * W);
         w.a_scale = ar.take<float>(rows);
+    }
+    if (t->ln_fold) {
+        w.xb = ar.take<unsigned short>(rows * W);
+        w.ln_stats = ar.take<float>(rows * 2);
+        w.ln_part = ar.take<float>(rows * 2 * (W / 256));
     }
     if (out) *out = w;
     return ar.off + 256;
@@ -56,6 +64,8 @@ int check_tower(const clipmi_tower* t, int kind, const char* who) {
         return set_err(CLIPMI_EINVAL, "%s: weight_format %d", who, t->weight_format);
     if (t->weight_format == 1 && t->width % 256 != 0)
         return set_err(CLIPMI_EUNSUPPORTED, "%s: fp8 weights need width %% 256 == 0 (width %d)", who, t->width);
+    if (t->ln_fold != 0 && (t->ln_fold != 1 || t->weight_format != 0 || t->width % 256 != 0))
+        return set_err(CLIPMI_EINVAL, "%s: ln_fold %d needs bf16 weights and width %% 256 == 0 (width %d)", who, t->ln_fold, t->width);
     if (t->tokens > 80 && kind == 1)
         return set_err(CLIPMI_EUNSUPPORTED, "%s: %d tokens (causal attention covers <= 80)", who, t->tokens);
     return 0;
@@ -71,7 +81,7 @@ const T* at(const void* blob, uint64_t off) {
 // (packed by weights.py), the bf16 activation rows are quantised to e4m3 with one scale per row right before each
 // GEMM (quantize_rows_fp8_kernel), gemm256f8 applies both scales in its epilogue. LayerNorm, attention, the
 // residual stream, patch embedding and the final projection are unchanged.
-int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int causal, hipStream_t st) {
+int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int causal, hipStream_t st, GemmProbe* probe) {
     const int W = t->width, L = t->tokens, M = B * L;
     const bool fp8 = t->weight_format == 1;
     // A == nullptr: the A operand is already in w.a8 / w.a_scale (LayerNorm wrote it as e4m3)
@@ -88,8 +98,42 @@ int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int 
             return launch_gemm_fp8(g, epi, st);
         }
         g.A = A; g.W = at<unsigned short>(blob, w_off);
-        return launch_gemm_algo(g, epi, 0, st);
+        return launch_gemm_algo(g, epi, 0, st, probe);
     };
+    if (t->ln_fold) {
+        // LN-folded blocks (gemm.hpp): ln_1 / ln_2 never run as passes of their own. Invariant at the top of every
+        // layer: w.xb = bf16(x * ln_1.weight) and w.ln_stats = (mean, rstd) of x, left there by the previous layer's
+        // c_proj GEMM (layer 0: by one cast_stats pass over the embedded rows).
+        auto lb_of = [&](int l) { return t->off_layers + (uint64_t)l * t->layer_stride; };
+        auto ln_linear = [&](uint64_t w_off, uint64_t cb_off, uint64_t cs_off, int N, int epi) -> int {
+            GemmArgs g{};
+            g.A = w.xb; g.W = at<unsigned short>(blob, w_off); g.bias = at<float>(blob, cb_off);
+            g.colsum = at<float>(blob, cs_off); g.ln_stats = w.ln_stats;
+            g.out = w.big; g.M = M; g.N = N; g.K = W;
+            return launch_gemm_algo(g, epi, 0, st, probe);
+        };
+        // residual GEMM that also prepares the NEXT LN-folded GEMM's inputs (gamma_off = that LayerNorm's weight)
+        auto resid_linear = [&](const unsigned short* A, int K, uint64_t w_off, uint64_t b_off, bool has_next, uint64_t gamma_off) -> int {
+            GemmArgs g{};
+            g.A = A; g.W = at<unsigned short>(blob, w_off); g.bias = at<float>(blob, b_off);
+            g.out = w.x; g.M = M; g.N = W; g.K = K;
+            if (!has_next) return launch_gemm_algo(g, EPI_BIAS_RESID_F32, 0, st, probe);
+            g.gamma = at<float>(blob, gamma_off); g.xb = w.xb; g.ln_part = w.ln_part; g.ln_stats_out = w.ln_stats;
+            return launch_gemm_algo(g, EPI_BIAS_RESID_LN_F32, 0, st, probe);
+        };
+        if (int rc = launch_cast_stats(w.x, at<float>(blob, lb_of(0) + t->lo_ln1_w), w.xb, w.ln_stats, M, W, st)) return rc;
+        for (int l = 0; l < t->layers; ++l) {
+            const uint64_t lb = lb_of(l);
+            if (int rc = ln_linear(lb + t->lo_qkv_w, lb + t->lo_qkv_cb, lb + t->lo_qkv_colsum, 3 * W, EPI_LN_BIAS_BF16)) return rc;
+            if (int rc = launch_attention(w.big, w.h, B, L, t->heads, causal, 1, st)) return rc;
+            if (int rc = resid_linear(w.h, W, lb + t->lo_out_w, lb + t->lo_out_b, true, lb + t->lo_ln2_w)) return rc;
+            if (int rc = ln_linear(lb + t->lo_fc_w, lb + t->lo_fc_cb, lb + t->lo_fc_colsum, 4 * W, EPI_LN_BIAS_QGELU_BF16)) return rc;
+            const bool more = l + 1 < t->layers;
+            if (int rc = resid_linear(w.big, 4 * W, lb + t->lo_proj_w, lb + t->lo_proj_b, more, more ? lb_of(l + 1) + t->lo_ln1_w : 0))
+                return rc;
+        }
+        return 0;
+    }
     for (int l = 0; l < t->layers; ++l) {
         const uint64_t lb = t->off_layers + (uint64_t)l * t->layer_stride;
         LnArgs ln{w.x, at<float>(blob, lb + t->lo_ln1_w), at<float>(blob, lb + t->lo_ln1_b), w.h, nullptr, 1, M, W, 1};
@@ -132,8 +176,8 @@ extern "C" size_t clipmi_encode_image_workspace_bytes(const clipmi_tower* t, int
     return carve(t, B, nullptr, ~(size_t)0, nullptr);
 }
 
-extern "C" int clipmi_encode_image(const clipmi_tower* t, const void* blob_dev, const void* pixels_dev, int pix_dtype,
-                                   int B, float* out_dev, int normalize, void* ws_dev, size_t ws_bytes, void* stream) {
+static int encode_image_impl(const clipmi_tower* t, const void* blob_dev, const void* pixels_dev, int pix_dtype,
+                             int B, float* out_dev, int normalize, void* ws_dev, size_t ws_bytes, void* stream, GemmProbe* probe) {
     if (int rc = check_tower(t, 0, "encode_image")) return rc;
     if (!blob_dev || !pixels_dev || !out_dev || !ws_dev) return set_err(CLIPMI_EINVAL, "encode_image: NULL pointer");
     if (B < 1) return set_err(CLIPMI_EINVAL, "encode_image: B=%d", B);
@@ -161,8 +205,13 @@ extern "C" int clipmi_encode_image(const clipmi_tower* t, const void* blob_dev, 
     CLIPMI_CHECK_LAUNCH("cls_rows_kernel");
     LnArgs ln{w.x, at<float>(blob_dev, t->off_ln_pre_w), at<float>(blob_dev, t->off_ln_pre_b), w.x, nullptr, 1, B * L, W, 0};
     if (int rc = launch_layernorm(ln, st)) return rc;       // ln_pre, in place (each wave owns its row)
-    if (int rc = run_layers(t, blob_dev, w, B, 0, st)) return rc;
+    if (int rc = run_layers(t, blob_dev, w, B, 0, st, probe)) return rc;
     return run_head(t, blob_dev, w, B, nullptr, L, out_dev, normalize, st);
+}
+
+extern "C" int clipmi_encode_image(const clipmi_tower* t, const void* blob_dev, const void* pixels_dev, int pix_dtype,
+                                   int B, float* out_dev, int normalize, void* ws_dev, size_t ws_bytes, void* stream) {
+    return encode_image_impl(t, blob_dev, pixels_dev, pix_dtype, B, out_dev, normalize, ws_dev, ws_bytes, stream, nullptr);
 }
 
 extern "C" size_t clipmi_encode_text_workspace_bytes(const clipmi_tower* t, int Q) {
@@ -188,7 +237,7 @@ extern "C" int clipmi_encode_text(const clipmi_tower* t, const void* blob_dev, c
     CLIPMI_CHECK_LAUNCH("text_embed_kernel");
     hipLaunchKernelGGL(eot_rows_kernel, dim3((Q + 63) / 64), dim3(64), 0, st, ids_dev, w.rowidx, Q, L);
     CLIPMI_CHECK_LAUNCH("eot_rows_kernel");
-    if (int rc = run_layers(t, blob_dev, w, Q, 1, st)) return rc;
+    if (int rc = run_layers(t, blob_dev, w, Q, 1, st, nullptr)) return rc;
     return run_head(t, blob_dev, w, Q, w.rowidx, 1, out_dev, normalize, st);
 }
 
@@ -199,15 +248,14 @@ extern "C" int clipmi_dbg_encode_image_probe_ms(const clipmi_tower* t, const voi
                                                 int pix_dtype, int B, float* out_dev, void* ws_dev, size_t ws_bytes,
                                                 void* stream, int probe_epi, int reps, float* kernel_ms, int* launches) {
     if (!kernel_ms || reps < 1) return set_err(CLIPMI_EINVAL, "dbg_encode_image_probe_ms: bad arguments");
-    GemmProbe& p = gemm_probe();
+    GemmProbe p;             // lives on this call's stack: the library keeps no mutable state (clipmi.h)
     for (int i = 0; i < 2 * GemmProbe::MAX; ++i)
         if (hipEventCreate(&p.ev[i]) != hipSuccess) return set_err(CLIPMI_EHIP, "hipEventCreate");
     double total = 0.0;
     int count = 0, rc = 0;
     for (int r = 0; r < reps && rc == 0; ++r) {
-        p.active = true; p.epi = probe_epi; p.n = 0;
-        rc = clipmi_encode_image(t, blob_dev, pixels_dev, pix_dtype, B, out_dev, 1, ws_dev, ws_bytes, stream);
-        p.active = false;
+        p.epi = probe_epi; p.n = 0;
+        rc = encode_image_impl(t, blob_dev, pixels_dev, pix_dtype, B, out_dev, 1, ws_dev, ws_bytes, stream, &p);
         if (rc) break;
         if (hipStreamSynchronize(as_stream(stream)) != hipSuccess) { rc = set_err(CLIPMI_EHIP, "hipStreamSynchronize"); break; }
         for (int i = 0; i < p.n; ++i) {

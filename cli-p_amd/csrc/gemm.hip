@@ -6,18 +6,21 @@
 
 namespace clipmi {
 
-// Measurement probe (bench.py roofline): while active on this thread, every launch of the GEMM
-// with epilogue `epi` is bracketed by a pair of HIP events on its own stream.
-GemmProbe& gemm_probe() {
-    static thread_local GemmProbe p;
-    return p;
+// LDS opt-in (hipFuncSetAttribute) is remembered per (kernel, device): a second device in the same thread gets its own
+static bool lds_opted(int* slots) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return false;
+    if (slots[dev]) return true;
+    slots[dev] = 1;
+    return false;
 }
 
 template <int EPI>
-static int launch_epi(const GemmArgs& g, hipStream_t st) {
+static int launch_epi(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
     const int grid = (g.N / GEMM_BN) * ((g.M + GEMM_BM - 1) / GEMM_BM);
-    GemmProbe& p = gemm_probe();
-    if (p.active && p.epi == EPI && p.n < GemmProbe::MAX) {
+    if (probe && probe->wants(EPI)) {
+        GemmProbe& p = *probe;
         // measurement probe: the events take the dispatch's own begin/end timestamps
         hipExtLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(grid), dim3(256), GEMM_LDS_BYTES, st, p.ev[2 * p.n],
                               p.ev[2 * p.n + 1], 0, g);
@@ -30,17 +33,16 @@ static int launch_epi(const GemmArgs& g, hipStream_t st) {
 }
 
 template <int EPI>
-static int launch_epi256(const GemmArgs& g, hipStream_t st) {
+static int launch_epi256(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
     const int grid = (g.N / 256) * ((g.M + 255) / 256);
-    static thread_local bool opted = false;
-    if (!opted) {
+    static thread_local int opted[64];
+    if (!lds_opted(opted)) {
         if (hipFuncSetAttribute((const void*)gemm256_bf16_nt_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 G256_LDS) != hipSuccess)
             return set_err(CLIPMI_EHIP, "hipFuncSetAttribute(gemm256, %d B LDS)", G256_LDS);
-        opted = true;
     }
-    GemmProbe& p = gemm_probe();
-    if (p.active && p.epi == EPI && p.n < GemmProbe::MAX) {
+    if (probe && probe->wants(EPI)) {
+        GemmProbe& p = *probe;
         hipExtLaunchKernelGGL(gemm256_bf16_nt_kernel<EPI>, dim3(grid), dim3(512), G256_LDS, st, p.ev[2 * p.n],
                               p.ev[2 * p.n + 1], 0, g);
         ++p.n;
@@ -58,20 +60,27 @@ static int persist_mode() {
     return mode;
 }
 
+// LDS beyond the two K-tile buffers: bias[N]; a second [N] row for FP8 (w_scale) and the LN-folded forms (colsum /
+// gamma); the tile's 256 row values (FP8: a_scale, 1 KiB; LN consumer: (mean, rstd), 2 KiB)
+constexpr int g256p_lds(int epi, bool fp8, int N, int dbg) {
+    const bool two = fp8 || epi_is_ln(epi) || epi == EPI_BIAS_RESID_LN_F32;
+    return G256_LDS + N * 4 * (two ? 2 : 1) + (fp8 ? 1024 : epi_is_ln(epi) ? 2048 : 0) + ((dbg & 12) ? 2048 : 0);
+}
+
 template <int EPI, bool FP8 = false>
-static int launch_epi256p(const GemmArgs& g, hipStream_t st) {
+static int launch_epi256p(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
     const int tiles = (g.N / 256) * ((g.M + 255) / 256);
     const int grid = tiles < NUM_CU ? tiles : NUM_CU;
-    const int lds = G256_LDS + g.N * 4 * (FP8 ? 2 : 1) + (FP8 ? 1024 : 0) + ((g.dbg & 12) ? 2048 : 0);
-    static thread_local int opted = 0;
-    if (opted < lds) {
+    const int lds = g256p_lds(EPI, FP8, g.N, g.dbg);
+    if (lds > LDS_BYTES) return set_err(CLIPMI_EUNSUPPORTED, "gemm256p: %d B of LDS for N=%d", lds, g.N);
+    static thread_local int opted[64];
+    if (!lds_opted(opted)) {
         if (hipFuncSetAttribute((const void*)gemm256p_bf16_nt_kernel<EPI, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                G256_LDS + G256P_MAX_N * 4) != hipSuccess)
-            return set_err(CLIPMI_EHIP, "hipFuncSetAttribute(gemm256p, %d B LDS)", G256_LDS + G256P_MAX_N * 4);
-        opted = G256_LDS + G256P_MAX_N * 4;
+                                LDS_BYTES) != hipSuccess)
+            return set_err(CLIPMI_EHIP, "hipFuncSetAttribute(gemm256p, %d B LDS)", LDS_BYTES);
     }
-    GemmProbe& p = gemm_probe();
-    if (p.active && p.epi == EPI && p.n < GemmProbe::MAX) {
+    if (probe && probe->wants(EPI)) {
+        GemmProbe& p = *probe;
         hipExtLaunchKernelGGL((gemm256p_bf16_nt_kernel<EPI, FP8>), dim3(grid), dim3(512), lds, st, p.ev[2 * p.n],
                               p.ev[2 * p.n + 1], 0, g);
         ++p.n;
@@ -82,16 +91,32 @@ static int launch_epi256p(const GemmArgs& g, hipStream_t st) {
     return 0;
 }
 
+// The residual producer of the LN-folded layers (EPI_BIAS_RESID_LN_F32) must leave three things behind: the updated
+// f32 rows, xb = bf16(rows * gamma) and the rows' (mean, rstd) in g.ln_stats_out. The persistent kernel's storers write
+// xb and per-tile partials on their way out (then ln_finish_kernel folds the partials: 8 B per row and segment); every
+// other kernel runs the plain residual epilogue followed by cast_stats_kernel (one LayerNorm-sized pass). Both give the
+// same bits (canonical statistics, gemm.hpp).
+static int finish_resid_ln(const GemmArgs& g, bool fused, hipStream_t st) {
+    if (fused) return launch_ln_finish(g.ln_part, g.ln_stats_out, g.M, g.N, st);
+    return launch_cast_stats(static_cast<const float*>(g.out), g.gamma, g.xb, g.ln_stats_out, g.M, g.N, st);
+}
+
 // algo: 0 = choose by shape, 1 = force the 128x128 kernel, 2 = force the 256x256 kernel,
 //       3 = force the persistent 256x256 kernel
-int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st) {
+int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmProbe* probe) {
+    if (epi_is_ln(epi) && (!g.ln_stats || !g.colsum || !g.bias))
+        return set_err(CLIPMI_EINVAL, "gemm: LN-folded epilogue %d needs ln_stats, colsum and bias", epi);
+    if (epi == EPI_BIAS_RESID_LN_F32 && (!g.xb || !g.gamma || !g.ln_part || !g.ln_stats_out || g.N % 256 != 0))
+        return set_err(CLIPMI_EINVAL, "gemm: EPI_BIAS_RESID_LN_F32 needs xb, gamma, ln_part, ln_stats_out and N %% 256 == 0");
     const bool ok256 = g.N % 256 == 0 && g.K % 64 == 0 && g.K >= 128;
     if (algo == 2 && !ok256) return set_err(CLIPMI_EINVAL, "gemm256: N=%d K=%d (need N %% 256 == 0, K %% 64 == 0, K >= 128)", g.N, g.K);
-    const bool ok256p = ok256 && g.K % 128 == 0 && g.N <= G256P_MAX_N &&
-                        (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_QGELU_BF16 || epi == EPI_BIAS_RESID_F32) &&
-                        g.K <= (1 << 20);
+    const bool store_only = epi == EPI_BIAS_BF16 || epi == EPI_BIAS_QGELU_BF16 || epi == EPI_BIAS_RESID_F32 || epi_is_ln(epi) ||
+                            epi == EPI_BIAS_RESID_LN_F32;
+    const bool ok256p = ok256 && g.K % 128 == 0 && g.N <= G256P_MAX_N && store_only && g.K <= (1 << 20) &&
+                        g256p_lds(epi, false, g.N, g.dbg) <= LDS_BYTES;
     if (algo == 3 && !ok256p)
-        return set_err(CLIPMI_EINVAL, "gemm256p: M=%d N=%d K=%d epi=%d (need N %% 256 == 0, K %% 128 == 0, epilogue 0, 1 or 2)", g.M, g.N, g.K, epi);
+        return set_err(CLIPMI_EINVAL, "gemm256p: M=%d N=%d K=%d epi=%d (need N %% 256 == 0, K %% 128 == 0, a store-only epilogue "
+                       "and bias/colsum rows that fit LDS)", g.M, g.N, g.K, epi);
     // by shape: the 256x256 pipeline wins when its tiles fill the 256 CUs in whole rounds (r01 on MI355X,
     // M=25600: N=2304/3072 -> 781/841 TF vs 702/685; N=768 -> 300 tiles = 1.17 rounds, 408/769 vs 521/904)
     bool use256 = algo == 2 || algo == 3;
@@ -107,19 +132,34 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st) {
         // tile's K-loop
         use256p = use256 && ok256p && tiles > NUM_CU && persist_mode() != 0;
     }
-    if (!use256) return launch_gemm(g, epi, st);
     if (g.M < 1 || !g.A || !g.W || !g.out) return set_err(CLIPMI_EINVAL, "gemm: bad arguments");
+    if (epi == EPI_BIAS_RESID_LN_F32 && !use256p) {
+        // not the persistent kernel: plain residual epilogue, then the cast + statistics pass
+        if (int rc = use256 ? launch_epi256<EPI_BIAS_RESID_F32>(g, st, probe) : launch_gemm(g, EPI_BIAS_RESID_F32, st, probe)) return rc;
+        return finish_resid_ln(g, false, st);
+    }
+    if (!use256) return launch_gemm(g, epi, st, probe);
     if (use256p) {
-        if (epi == EPI_BIAS_BF16) return launch_epi256p<EPI_BIAS_BF16>(g, st);
-        if (epi == EPI_BIAS_RESID_F32) return launch_epi256p<EPI_BIAS_RESID_F32>(g, st);
-        return launch_epi256p<EPI_BIAS_QGELU_BF16>(g, st);
+        switch (epi) {
+            case EPI_BIAS_BF16: return launch_epi256p<EPI_BIAS_BF16>(g, st, probe);
+            case EPI_BIAS_QGELU_BF16: return launch_epi256p<EPI_BIAS_QGELU_BF16>(g, st, probe);
+            case EPI_BIAS_RESID_F32: return launch_epi256p<EPI_BIAS_RESID_F32>(g, st, probe);
+            case EPI_LN_BIAS_BF16: return launch_epi256p<EPI_LN_BIAS_BF16>(g, st, probe);
+            case EPI_LN_BIAS_QGELU_BF16: return launch_epi256p<EPI_LN_BIAS_QGELU_BF16>(g, st, probe);
+            case EPI_BIAS_RESID_LN_F32:
+                if (int rc = launch_epi256p<EPI_BIAS_RESID_LN_F32>(g, st, probe)) return rc;
+                return finish_resid_ln(g, true, st);
+        }
+        return set_err(CLIPMI_EINVAL, "gemm256p: epilogue %d", epi);
     }
     switch (epi) {
-        case EPI_BIAS_BF16: return launch_epi256<EPI_BIAS_BF16>(g, st);
-        case EPI_BIAS_QGELU_BF16: return launch_epi256<EPI_BIAS_QGELU_BF16>(g, st);
-        case EPI_BIAS_RESID_F32: return launch_epi256<EPI_BIAS_RESID_F32>(g, st);
-        case EPI_F32: return launch_epi256<EPI_F32>(g, st);
-        case EPI_PATCH_F32: return launch_epi256<EPI_PATCH_F32>(g, st);
+        case EPI_BIAS_BF16: return launch_epi256<EPI_BIAS_BF16>(g, st, probe);
+        case EPI_BIAS_QGELU_BF16: return launch_epi256<EPI_BIAS_QGELU_BF16>(g, st, probe);
+        case EPI_BIAS_RESID_F32: return launch_epi256<EPI_BIAS_RESID_F32>(g, st, probe);
+        case EPI_F32: return launch_epi256<EPI_F32>(g, st, probe);
+        case EPI_PATCH_F32: return launch_epi256<EPI_PATCH_F32>(g, st, probe);
+        case EPI_LN_BIAS_BF16: return launch_epi256<EPI_LN_BIAS_BF16>(g, st, probe);
+        case EPI_LN_BIAS_QGELU_BF16: return launch_epi256<EPI_LN_BIAS_QGELU_BF16>(g, st, probe);
     }
     return set_err(CLIPMI_EINVAL, "gemm: unknown epilogue %d", epi);
 }
@@ -127,12 +167,11 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st) {
 template <int EPI, bool MX>
 static int launch_epi256f8(const GemmArgs& g, hipStream_t st) {
     const int grid = (g.N / 256) * ((g.M + 255) / 256);
-    static thread_local bool opted = false;
-    if (!opted) {
+    static thread_local int opted[64];
+    if (!lds_opted(opted)) {
         if (hipFuncSetAttribute((const void*)gemm256f8_nt_kernel<EPI, MX>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 G256_LDS) != hipSuccess)
             return set_err(CLIPMI_EHIP, "hipFuncSetAttribute(gemm256f8, %d B LDS)", G256_LDS);
-        opted = true;
     }
     hipLaunchKernelGGL((gemm256f8_nt_kernel<EPI, MX>), dim3(grid), dim3(512), G256_LDS, st, g);
     CLIPMI_CHECK_LAUNCH("gemm256f8_nt_kernel");
@@ -147,8 +186,8 @@ int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st, int mx) {
     // more than one round of tiles: the persistent role-split kernel on FP8 operands (mx = 2 keeps gemm256f8 for tests)
     const long long tiles = (long long)(g.N / 256) * ((g.M + 255) / 256);
     if (mx == 1 && tiles > NUM_CU && g.K % 256 == 0 && g.N <= 3840 && persist_mode() != 0) {
-        if (epi == EPI_BIAS_BF16) return launch_epi256p<EPI_BIAS_BF16, true>(g, st);
-        if (epi == EPI_BIAS_QGELU_BF16) return launch_epi256p<EPI_BIAS_QGELU_BF16, true>(g, st);
+        if (epi == EPI_BIAS_BF16) return launch_epi256p<EPI_BIAS_BF16, true>(g, st, nullptr);
+        if (epi == EPI_BIAS_QGELU_BF16) return launch_epi256p<EPI_BIAS_QGELU_BF16, true>(g, st, nullptr);
         // (the residual epilogue stays on gemm256f8: its persistent FP8 form does not fit 256 registers)
     }
     switch (epi) {
@@ -162,16 +201,18 @@ int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st, int mx) {
     return set_err(CLIPMI_EINVAL, "gemm_fp8: epilogue %d", epi);
 }
 
-int launch_gemm(const GemmArgs& g, int epi, hipStream_t st) {
+int launch_gemm(const GemmArgs& g, int epi, hipStream_t st, GemmProbe* probe) {
     if (g.M < 1 || g.N < 1 || g.K < 1 || g.N % GEMM_BN != 0 || g.K % GEMM_BK != 0)
         return set_err(CLIPMI_EINVAL, "gemm: M=%d N=%d K=%d (need N %% 128 == 0, K %% 64 == 0)", g.M, g.N, g.K);
     if (!g.A || !g.W || !g.out) return set_err(CLIPMI_EINVAL, "gemm: NULL pointer");
     switch (epi) {
-        case EPI_BIAS_BF16: return launch_epi<EPI_BIAS_BF16>(g, st);
-        case EPI_BIAS_QGELU_BF16: return launch_epi<EPI_BIAS_QGELU_BF16>(g, st);
-        case EPI_BIAS_RESID_F32: return launch_epi<EPI_BIAS_RESID_F32>(g, st);
-        case EPI_F32: return launch_epi<EPI_F32>(g, st);
-        case EPI_PATCH_F32: return launch_epi<EPI_PATCH_F32>(g, st);
+        case EPI_BIAS_BF16: return launch_epi<EPI_BIAS_BF16>(g, st, probe);
+        case EPI_BIAS_QGELU_BF16: return launch_epi<EPI_BIAS_QGELU_BF16>(g, st, probe);
+        case EPI_BIAS_RESID_F32: return launch_epi<EPI_BIAS_RESID_F32>(g, st, probe);
+        case EPI_F32: return launch_epi<EPI_F32>(g, st, probe);
+        case EPI_PATCH_F32: return launch_epi<EPI_PATCH_F32>(g, st, probe);
+        case EPI_LN_BIAS_BF16: return launch_epi<EPI_LN_BIAS_BF16>(g, st, probe);
+        case EPI_LN_BIAS_QGELU_BF16: return launch_epi<EPI_LN_BIAS_QGELU_BF16>(g, st, probe);
     }
     return set_err(CLIPMI_EINVAL, "gemm: unknown epilogue %d", epi);
 }
@@ -194,6 +235,37 @@ extern "C" int clipmi_dbg_gemm_bf16(const void* a_dev, const void* w_dev, const 
     if (const char* e = getenv("CLIPMI_GEMM_DBG")) g.dbg = atoi(e);
     if (g.dbg & 12) { g.pos = bias_dev; g.bias = nullptr; }     // stamps land in the caller's "bias" buffer (>= 4 KiB)
     return launch_gemm_algo(g, epi, algo, as_stream(stream));
+}
+
+// Test hooks of the LN-folded layers (gemm.hpp). `epi` = EPI_LN_BIAS_BF16 (5) or EPI_LN_BIAS_QGELU_BF16 (6), bits 8-9
+// force a kernel as in clipmi_dbg_gemm_bf16.
+extern "C" int clipmi_dbg_gemm_ln(const void* xb_dev, const void* w_dev, const float* cb_dev, const float* colsum_dev,
+                                  const float* stats_dev, void* out_dev, int M, int N, int K, int epi, void* stream) {
+    const int algo = (epi >> 8) & 3;
+    epi &= 0xff;
+    if (!epi_is_ln(epi)) return set_err(CLIPMI_EINVAL, "dbg_gemm_ln: epi %d", epi);
+    GemmArgs g{};
+    g.A = static_cast<const unsigned short*>(xb_dev);
+    g.W = static_cast<const unsigned short*>(w_dev);
+    g.bias = cb_dev; g.colsum = colsum_dev; g.ln_stats = stats_dev;
+    g.out = out_dev;
+    g.M = M; g.N = N; g.K = K;
+    return launch_gemm_algo(g, epi, algo, as_stream(stream));
+}
+
+// x (f32 [M][N], in place) += a @ w^T + bias; xb = bf16(x * gamma); stats = (mean, rstd) of the new rows.
+// part_dev: [M][N/256][2] scratch. algo as in clipmi_dbg_gemm_bf16 (3 = the persistent kernel's fused store pass).
+extern "C" int clipmi_dbg_gemm_resid_ln(const void* a_dev, const void* w_dev, const float* bias_dev, float* x_dev,
+                                        const float* gamma_dev, void* xb_dev, float* part_dev, float* stats_dev, int M, int N,
+                                        int K, int algo, void* stream) {
+    GemmArgs g{};
+    g.A = static_cast<const unsigned short*>(a_dev);
+    g.W = static_cast<const unsigned short*>(w_dev);
+    g.bias = bias_dev;
+    g.out = x_dev;
+    g.gamma = gamma_dev; g.xb = static_cast<unsigned short*>(xb_dev); g.ln_part = part_dev; g.ln_stats_out = stats_dev;
+    g.M = M; g.N = N; g.K = K;
+    return launch_gemm_algo(g, EPI_BIAS_RESID_LN_F32, algo & 3, as_stream(stream));
 }
 
 extern "C" int clipmi_dbg_gemm_fp8(const void* a8_dev, const void* w8_dev, const float* a_scale_dev, const float* w_scale_dev,

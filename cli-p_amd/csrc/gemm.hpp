@@ -59,8 +59,60 @@ enum Epilogue {
     EPI_BIAS_QGELU_BF16 = 1,  // out bf16 = quick_gelu(acc + bias)
     EPI_BIAS_RESID_F32 = 2,   // out f32 [M][N] += acc + bias        (residual stream, in place)
     EPI_F32 = 3,              // out f32 = acc (+ bias if given)
-    EPI_PATCH_F32 = 4         // out f32 [b*L + 1 + p][n] = acc + pos[1 + p][n],  m = b*np + p
+    EPI_PATCH_F32 = 4,        // out f32 [b*L + 1 + p][n] = acc + pos[1 + p][n],  m = b*np + p
+    // LayerNorm folded into the GEMM that consumes it ("LN-folded" linear layers, see ln_fold below):
+    EPI_LN_BIAS_BF16 = 5,        // out bf16 = rstd[m] * (acc - mean[m] * colsum[n]) + bias[n]
+    EPI_LN_BIAS_QGELU_BF16 = 6,  // out bf16 = quick_gelu(the same)
+    EPI_BIAS_RESID_LN_F32 = 7    // EPI_BIAS_RESID_F32 + xb[m][n] = bf16(out[m][n] * gamma[n]) + row-statistics partials
 };
+
+// ---- LN-folded linear layers ---------------------------------------------------------------------------------
+// y = LayerNorm(x; gamma, beta) W^T + b, with mean / rstd the row statistics of x, equals
+//     y[m][n] = rstd[m] * ( sum_k (x[m][k] gamma[k]) W[n][k]  -  mean[m] * colsum[n] ) + cb[n]
+//     colsum[n] = sum_k gamma[k] W[n][k],   cb[n] = sum_k beta[k] W[n][k] + b[n]        (packed by weights.py)
+// so the GEMM can take A = xb = bf16(x * gamma) — written by the kernel that produced x (the residual GEMM's
+// store pass, EPI_BIAS_RESID_LN_F32) — and the stand-alone LayerNorm pass (read f32 x, write bf16 h: 200 MB per
+// launch at B = 870, 8.5 % of the r01 encode step) disappears. W stays the plain bf16 weight matrix.
+// Row statistics are CANONICAL so that every producer gives the same bits (batch-size invariance): per
+// 256-column segment a wave holds 4 consecutive columns per lane, lane sums in a fixed order, then a butterfly
+// over xor masks 32, 16, 8, 4, 2, 1; segments are combined left to right (ln_row_stats).
+constexpr float LN_EPS = 1e-5f;
+
+__device__ __forceinline__ float ln_lane_sum(f32x4 v) { return (v.x + v.y) + (v.z + v.w); }
+__device__ __forceinline__ float ln_lane_sumsq(f32x4 v) {
+    float q = v.x * v.x;
+    q = __builtin_fmaf(v.y, v.y, q);
+    q = __builtin_fmaf(v.z, v.z, q);
+    return __builtin_fmaf(v.w, v.w, q);
+}
+// all 64 lanes end with the wave total; the xor order is part of the contract
+__device__ __forceinline__ float ln_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// (mean, rstd) from per-segment (sum, sum of squares) partials, combined left to right
+__device__ __forceinline__ f32x2 ln_row_stats(const float* part, int nseg, int W) {
+    float s = part[0], q = part[1];
+    for (int j = 1; j < nseg; ++j) { s += part[2 * j]; q += part[2 * j + 1]; }
+    const float inv = 1.0f / (float)W;
+    const float mean = s * inv;
+    float var = __builtin_fmaf(-mean, mean, q * inv);
+    var = var > 0.f ? var : 0.f;
+    return f32x2{mean, __builtin_amdgcn_rsqf(var + LN_EPS)};
+}
+// the LN-folded epilogue, identical in every GEMM kernel (explicit fmas: no contraction choices left to the compiler)
+__device__ __forceinline__ f32x4 ln_apply(f32x4 acc, float mean, float rstd, f32x4 colsum, f32x4 cb) {
+    f32x4 r;
+    r.x = __builtin_fmaf(__builtin_fmaf(-mean, colsum.x, acc.x), rstd, cb.x);
+    r.y = __builtin_fmaf(__builtin_fmaf(-mean, colsum.y, acc.y), rstd, cb.y);
+    r.z = __builtin_fmaf(__builtin_fmaf(-mean, colsum.z, acc.z), rstd, cb.z);
+    r.w = __builtin_fmaf(__builtin_fmaf(-mean, colsum.w, acc.w), rstd, cb.w);
+    return r;
+}
+constexpr bool epi_is_ln(int e) { return e == EPI_LN_BIAS_BF16 || e == EPI_LN_BIAS_QGELU_BF16; }
+constexpr bool epi_is_qgelu(int e) { return e == EPI_BIAS_QGELU_BF16 || e == EPI_LN_BIAS_QGELU_BF16; }
+constexpr bool epi_is_bf16_out(int e) { return e == EPI_BIAS_BF16 || e == EPI_BIAS_QGELU_BF16 || epi_is_ln(e); }
 
 struct GemmArgs {
     const unsigned short* A;   // bf16 [M][K]
@@ -75,6 +127,14 @@ struct GemmArgs {
     // FP8 path (gemm256f8.hpp): A and W point at e4m3 bytes; per-row / per-output-channel dequantisation scales
     const float* a_scale;      // [M]
     const float* w_scale;      // [N]
+    // LN-folded layers: consumers (EPI_LN_*) read ln_stats [M][2] = (mean, rstd) and colsum [N] (bias = cb);
+    // the producer (EPI_BIAS_RESID_LN_F32) writes xb [M][N] bf16 = bf16(out * gamma) and ln_part [M][N/256][2]
+    const float* ln_stats;
+    const float* colsum;
+    const float* gamma;        // [N]
+    unsigned short* xb;
+    float* ln_part;
+    float* ln_stats_out;       // [M][2]: complete (mean, rstd) of the updated rows, whichever kernel ran
 };
 
 // Tile order shared by both GEMM kernels. (1) XCD split: hardware deals workgroups round-robin over
@@ -185,11 +245,12 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
 
     // --- epilogue: lane holds, per (mt, nt): row m = ..+fr, columns n = ..+4*fg+{0,1,2,3}.
     // Bias loaded once per lane; the residual read-modify-write is software-pipelined (see gemm256.hpp).
-    f32x4 bz[4];
+    f32x4 bz[4], cs[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int n = n0 + wn * 64 + nt * 16 + 4 * fg;
         bz[nt] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (epi_is_ln(EPI)) cs[nt] = *reinterpret_cast<const f32x4*>(g.colsum + n);
     }
     constexpr bool RMW = (EPI == EPI_BIAS_RESID_F32) || (EPI == EPI_PATCH_F32);
     auto row_of = [&](int mt, size_t& orow, const float*& addrow, bool& valid) {
@@ -226,9 +287,15 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n = n0 + wn * 64 + nt * 16 + 4 * fg;
-            f32x4 v = acc[mt][nt] + bz[nt];
-            if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16) {
-                if (EPI == EPI_BIAS_QGELU_BF16) {
+            f32x4 v;
+            if (epi_is_ln(EPI)) {
+                const f32x2 st = *reinterpret_cast<const f32x2*>(g.ln_stats + 2 * orow);
+                v = ln_apply(acc[mt][nt], st.x, st.y, cs[nt], bz[nt]);
+            } else {
+                v = acc[mt][nt] + bz[nt];
+            }
+            if (epi_is_bf16_out(EPI)) {
+                if (epi_is_qgelu(EPI)) {
                     v = quick_gelu4(v);
                 }
                 if (valid)
@@ -247,16 +314,26 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
 }
 
 // host-side launcher (defined in gemm.hip)
-int launch_gemm(const GemmArgs& g, int epi, hipStream_t st);
-int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st);
-int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st, int mx = 1);      // gemm256f8.hpp: e4m3 operands + scales
-
+// Measurement probe (bench.py roofline), passed down by the caller that wants it (nullptr everywhere else: the
+// library keeps no mutable state of its own): every launch whose epilogue is `epi` (or its LN-folded twin) is
+// bracketed by a pair of HIP events on its own stream.
 struct GemmProbe {
     static constexpr int MAX = 64;
-    bool active = false;
     int epi = -1, n = 0;
     hipEvent_t ev[2 * MAX];
+    bool wants(int e) const {
+        const int base = e == EPI_LN_BIAS_BF16 ? EPI_BIAS_BF16 : e == EPI_LN_BIAS_QGELU_BF16 ? EPI_BIAS_QGELU_BF16 :
+                         e == EPI_BIAS_RESID_LN_F32 ? EPI_BIAS_RESID_F32 : e;
+        return base == epi && n < MAX;
+    }
 };
-GemmProbe& gemm_probe();
+
+int launch_gemm(const GemmArgs& g, int epi, hipStream_t st, GemmProbe* probe = nullptr);
+int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmProbe* probe = nullptr);
+int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st, int mx = 1);      // gemm256f8.hpp: e4m3 operands + scales
+// vit_kernels.hip: x f32 [M][W] -> xb = bf16(x * gamma) + (mean, rstd) per row (canonical statistics); and the fold
+// of the persistent residual GEMM's per-tile partials [M][W/256][2] into (mean, rstd)
+int launch_cast_stats(const float* x, const float* gamma, unsigned short* xb, float* stats, int M, int W, hipStream_t st);
+int launch_ln_finish(const float* part, float* stats, int M, int W, hipStream_t st);
 
 }  // namespace clipmi

@@ -194,26 +194,34 @@ __global__ void __launch_bounds__(512, 2) gemm256_bf16_nt_kernel(GemmArgs g) {
     // row-major LDS image of the tile — 16-byte chunks XOR-swizzled with row & 15 so that the 16 rows
     // of a fragment column do not share banks — and the tile leaves as whole rows, 16 B per lane,
     // 512 B..1 KiB contiguous per wave-instruction; the residual / positional add happens on that pass.
-    f32x4 bz[2][2];
+    f32x4 bz[2][2], cs[2][2];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int n = n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg;
             bz[b][nt] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (epi_is_ln(EPI)) cs[b][nt] = *reinterpret_cast<const f32x4*>(g.colsum + n);
         }
     __syncthreads();
-    if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16) {
+    if (epi_is_bf16_out(EPI)) {
         // image: 256 rows x 512 B
 #pragma unroll
         for (int idx = 0; idx < 8; ++idx) {
             const int row = (idx >> 2) * 128 + wm * 64 + (idx & 3) * 16 + fr;
+            f32x2 st = {0.f, 1.f};
+            if (epi_is_ln(EPI)) {
+                const int m = m0 + row;
+                st = *reinterpret_cast<const f32x2*>(g.ln_stats + 2 * (size_t)(m < g.M ? m : g.M - 1));
+            }
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    f32x4 v = acc[idx >> 2][idx & 3][b][nt] + bz[b][nt];
-                    if (EPI == EPI_BIAS_QGELU_BF16) {
+                    f32x4 v;
+                    if (epi_is_ln(EPI)) v = ln_apply(acc[idx >> 2][idx & 3][b][nt], st.x, st.y, cs[b][nt], bz[b][nt]);
+                    else v = acc[idx >> 2][idx & 3][b][nt] + bz[b][nt];
+                    if (epi_is_qgelu(EPI)) {
                         v = quick_gelu4(v);
                     }
                     const int colbyte = (b * 128 + wn * 32 + nt * 16 + 4 * fg) * 2;

@@ -38,7 +38,15 @@ constexpr int G256P_MAX_N = 8192;
 // values arrive by one LDS-DMA instruction under the last K-tile.
 template <int EPI, bool FP8 = false>
 __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
-    static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_RESID_F32, "store-only epilogues");
+    static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_RESID_F32 || epi_is_ln(EPI) ||
+                      EPI == EPI_BIAS_RESID_LN_F32, "store-only epilogues");
+    // LN-folded forms (gemm.hpp "LN-folded linear layers"): LNC = consumer epilogue (row statistics of the tile by
+    // LDS-DMA under the last K-tile, colsum[N] in LDS beside the bias row), RLN = residual producer (the storers also
+    // write xb = bf16(x * gamma) and the tile's 256-column row-statistics partials)
+    constexpr bool LNC = epi_is_ln(EPI);
+    constexpr bool RESID = EPI == EPI_BIAS_RESID_F32 || EPI == EPI_BIAS_RESID_LN_F32;
+    constexpr bool RLN = EPI == EPI_BIAS_RESID_LN_F32;
+    static_assert(!(FP8 && (LNC || RLN)), "LN-folded epilogues exist for bf16 operands only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -115,7 +123,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     __amdgpu_buffer_rsrc_t rsO;
     int last_lr = 0;
     auto set_out = [&](int mm, int nn) {
-        if constexpr (EPI == EPI_BIAS_RESID_F32) {
+        if constexpr (RESID) {
             rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<float*>(g.out) + (size_t)mm * g.N + nn), 0, 0x7fffffff, 0x00020000);
             last_lr = g.M - 1 - mm;
         }
@@ -198,7 +206,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     // the K-loop, so the write-after-read distances are the K-loop's)
 #define P_SLOT(H, KT, NB)                                                                            \
     do {                                                                                             \
-        if (EPI == EPI_BIAS_RESID_F32 && last_kt) P_ISSUE_RESID(H, ((H) & 1) * 64 + ((H) >> 1) * 16); \
+        if (RESID && last_kt) P_ISSUE_RESID(H, ((H) & 1) * 64 + ((H) >> 1) * 16); \
         else P_ISSUE(H, KT, NB);                                                                     \
     } while (0)
 #define P_KTILE(CUR, PRE, KT, NB, W0, W1, W3)                                                        \
@@ -245,12 +253,17 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     P_ISSUE(1, 0, 0);
     float* sbias = reinterpret_cast<float*>(smem + G256_LDS);
     for (int i = tid; i < g.N; i += 512) sbias[i] = g.bias ? g.bias[i] : 0.f;
-    float* sws = sbias + g.N;                          // FP8: per-output-channel weight scales [N]
-    float* sas = sws + g.N;                            // FP8: the current tile's 256 activation-row scales
+    float* sws = sbias + g.N;                          // FP8: per-output-channel weight scales [N]; LNC: colsum[N]; RLN: gamma[N]
+    float* sas = sws + g.N;                            // FP8: the current tile's 256 activation-row scales; LNC: 256 x (mean, rstd)
     if (FP8)
         for (int i = tid; i < g.N; i += 512) sws[i] = g.w_scale[i];
+    if (LNC)
+        for (int i = tid; i < g.N; i += 512) sws[i] = g.colsum[i];
+    if (RLN)
+        for (int i = tid; i < g.N; i += 512) sws[i] = g.gamma[i];
     __amdgpu_buffer_rsrc_t rsS;
     if (FP8) rsS = __builtin_amdgcn_make_buffer_rsrc((void*)g.a_scale, 0, (unsigned)g.M * 4u, 0x00020000);
+    if (LNC) rsS = __builtin_amdgcn_make_buffer_rsrc((void*)g.ln_stats, 0, (unsigned)g.M * 8u, 0x00020000);
     // (the compiler's wait for these loads also retires the loaders' DMA above; harmless, once per launch.
     //  The tile-start barrier below publishes sbias: every wave reaches it after its ds_write + lgkmcnt(0).)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -260,7 +273,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     unsigned short* const outp = static_cast<unsigned short*>(g.out);
 
     // development stamps (dbg & 4): [wave][tile][stamp] 100 MHz wall-clock ticks in LDS, dumped at the end
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + G256_LDS + g.N * 4 * (FP8 ? 2 : 1) + (FP8 ? 1024 : 0));
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + G256_LDS + g.N * 4 * ((FP8 || LNC || RLN) ? 2 : 1) + (FP8 ? 1024 : LNC ? 2048 : 0));
     int tile_i = 0;
     unsigned long long kst[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define P_STAMP(k)                                                                                   \
@@ -306,6 +319,15 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) char*)sas, 16,
                                                              (unsigned)m0 * 4u + lo_ * 16u, 0, 0, 0);
                 }
+                if (LNC && wave == 0) {                // (mean, rstd)[m0 .. m0+255] -> sas: two 1-KiB pieces (rows past M read
+                    // as (0, 0): never stored); older than this K-tile's prefetch: retired by its P3 wait
+                    unsigned lo_;
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo_));
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) char*)sas, 16,
+                                                             (unsigned)m0 * 8u + lo_ * 16u, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) char*)sas + 1024, 16,
+                                                             (unsigned)m0 * 8u + 1024u + lo_ * 16u, 0, 0, 0);
+                }
             }
             P_KTILE(cur, 1, ktn, nb, 8, 8, 8);
         }
@@ -343,8 +365,25 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                 : "v"(sa_)
                 : "memory");
         }
-        // bias (and the FP8 scales) are folded into the accumulators in place, before the staging passes: the
-        // per-column / per-row factors are dead by the time the passes need registers for their LDS traffic
+        f32x2 lst[2][4];         // LNC: (mean, rstd) of the lane's 8 accumulator rows
+        if constexpr (LNC) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    wsv[b][nt] = *reinterpret_cast<const f32x4*>(sws + n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg);
+            const unsigned sa_ = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sas + (wm * 64 + fr) * 8;
+            asm volatile(
+                "ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:128\n\tds_read_b64 %2, %8 offset:256\n\tds_read_b64 %3, %8 offset:384\n\t"
+                "ds_read_b64 %4, %8 offset:1024\n\tds_read_b64 %5, %8 offset:1152\n\tds_read_b64 %6, %8 offset:1280\n\t"
+                "ds_read_b64 %7, %8 offset:1408\n\ts_waitcnt lgkmcnt(0)"
+                : "=&v"(lst[0][0]), "=&v"(lst[0][1]), "=&v"(lst[0][2]), "=&v"(lst[0][3]), "=&v"(lst[1][0]), "=&v"(lst[1][1]),
+                  "=&v"(lst[1][2]), "=&v"(lst[1][3])
+                : "v"(sa_)
+                : "memory");
+        }
+        // bias (and the FP8 scales / the LN-folded correction) are folded into the accumulators in place, before the
+        // staging passes: the per-column / per-row factors are dead by the time the passes need registers for their LDS traffic
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -354,10 +393,11 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
                         if constexpr (FP8) acc[a][mt][b][nt] = acc[a][mt][b][nt] * (wsv[b][nt] * asv[a][mt]) + bz[b][nt];
+                        else if constexpr (LNC) acc[a][mt][b][nt] = ln_apply(acc[a][mt][b][nt], lst[a][mt].x, lst[a][mt].y, wsv[b][nt], bz[b][nt]);
                         else acc[a][mt][b][nt] = acc[a][mt][b][nt] + bz[b][nt];
                     }
 #define P_SCALED(accv, a_, mt_, b_, nt_) (accv)
-        if constexpr (EPI == EPI_BIAS_RESID_F32) {
+        if constexpr (RESID) {
             // Residual stream update out[m][n] = (acc + bias) + out[m][n] (the add order of gemm256: bit-identical).
             // Eight sub-passes sp of 32 tile rows ((sp>>2)*128 + (sp&1)*64 + ((sp>>1)&1)*32 ..+31: the rows the
             // wave group wm = sp&1 holds for A half sp>>2, mt in {2((sp>>1)&1), +1}):
@@ -378,6 +418,14 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
             for (int nt = 0; nt < 2; ++nt)
                 stage_addr[nt] = img_base + fr * 1024 + (wn >> 1) * 256 + (((((wn & 1) * 8 + nt * 4 + fg) ^ fr)) << 4);
             float* const outf = static_cast<float*>(g.out);
+            f32x4 gam = {1.f, 1.f, 1.f, 1.f};
+            if constexpr (RLN) {
+                // storers' columns n0 + 4 lane ..; asm read: a compiler-visible LDS read that the compiler sinks into the
+                // storer blocks would drag a vmcnt(0) (= every store so far) in with it
+                const unsigned ga_ = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sws + (unsigned)(n0 + lane * 4) * 4u;
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(gam) : "v"(ga_) : "memory");
+            }
+            const int nseg = g.N >> 8, seg = n0 >> 8;
             P_ISSUE_RESID(4, 32);                          // sub-pass 2 (tile rows 32..63) -> Z
             P_ISSUE_RESID(5, 48);
 #pragma unroll
@@ -408,26 +456,86 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
                         aa[i] = img_base + (wn * 8 + i) * 1024 + ((lane ^ ((wn & 1) * 8 + i)) << 4);
-                    f32x4 x0, x1, x2, x3, x4, x5, x6, x7, r0, r1, r2, r3, r4, r5, r6, r7;
-                    // one statement: 16 reads in flight and their wait (asm destinations are unprotected until it)
-                    asm volatile(
-                        "ds_read_b128 %0, %16\n\tds_read_b128 %1, %17\n\tds_read_b128 %2, %18\n\tds_read_b128 %3, %19\n\t"
-                        "ds_read_b128 %4, %20\n\tds_read_b128 %5, %21\n\tds_read_b128 %6, %22\n\tds_read_b128 %7, %23\n\t"
-                        "ds_read_b128 %8, %24\n\tds_read_b128 %9, %24 offset:1024\n\tds_read_b128 %10, %24 offset:2048\n\t"
-                        "ds_read_b128 %11, %24 offset:3072\n\tds_read_b128 %12, %24 offset:4096\n\tds_read_b128 %13, %24 offset:5120\n\t"
-                        "ds_read_b128 %14, %24 offset:6144\n\tds_read_b128 %15, %24 offset:7168\n\ts_waitcnt lgkmcnt(0)"
-                        : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7),
-                          "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
-                        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(aa[4]), "v"(aa[5]), "v"(aa[6]), "v"(aa[7]), "v"(ra)
-                        : "memory");
-                    const f32x4 xs[8] = {x0, x1, x2, x3, x4, x5, x6, x7};
-                    const f32x4 rs[8] = {r0, r1, r2, r3, r4, r5, r6, r7};
                     const int lr0 = (sp >> 2) * 128 + (sp & 1) * 64 + ((sp >> 1) & 1) * 32 + wn * 8;
+                    float sa[8], sq[8];          // RLN: per-lane (sum, sum of squares) of the 8 new rows
+                    if constexpr (!RLN) {
+                        f32x4 x0, x1, x2, x3, x4, x5, x6, x7, r0, r1, r2, r3, r4, r5, r6, r7;
+                        // one statement: 16 reads in flight and their wait (asm destinations are unprotected until it)
+                        asm volatile(
+                            "ds_read_b128 %0, %16\n\tds_read_b128 %1, %17\n\tds_read_b128 %2, %18\n\tds_read_b128 %3, %19\n\t"
+                            "ds_read_b128 %4, %20\n\tds_read_b128 %5, %21\n\tds_read_b128 %6, %22\n\tds_read_b128 %7, %23\n\t"
+                            "ds_read_b128 %8, %24\n\tds_read_b128 %9, %24 offset:1024\n\tds_read_b128 %10, %24 offset:2048\n\t"
+                            "ds_read_b128 %11, %24 offset:3072\n\tds_read_b128 %12, %24 offset:4096\n\tds_read_b128 %13, %24 offset:5120\n\t"
+                            "ds_read_b128 %14, %24 offset:6144\n\tds_read_b128 %15, %24 offset:7168\n\ts_waitcnt lgkmcnt(0)"
+                            : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7),
+                              "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+                            : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(aa[4]), "v"(aa[5]), "v"(aa[6]), "v"(aa[7]), "v"(ra)
+                            : "memory");
+                        const f32x4 xs[8] = {x0, x1, x2, x3, x4, x5, x6, x7};
+                        const f32x4 rs[8] = {r0, r1, r2, r3, r4, r5, r6, r7};
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int m = m0 + lr0 + i;
-                        if (m < g.M && !(g.dbg & 1))
-                            *reinterpret_cast<f32x4*>(outf + (size_t)m * g.N + n0 + lane * 4) = xs[i] + rs[i];
+                        for (int i = 0; i < 8; ++i) {
+                            const int m = m0 + lr0 + i;
+                            if (m < g.M && !(g.dbg & 1))
+                                *reinterpret_cast<f32x4*>(outf + (size_t)m * g.N + n0 + lane * 4) = xs[i] + rs[i];
+                        }
+                    } else {
+                        // new residual rows o_i; beside the f32 store: xb = bf16(o * gamma) (the next LN-folded GEMM's A
+                        // operand) and this tile's share of the row statistics (canonical order, gemm.hpp). Two groups of
+                        // four rows (8 reads in flight each): sixteen row registers fewer than the plain form, which is
+                        // what keeps this variant out of scratch (a reload costs a storer a vmcnt(0) = all its stores).
+#pragma unroll
+                        for (int hgrp = 0; hgrp < 2; ++hgrp) {
+                            f32x4 x0, x1, x2, x3, r0, r1, r2, r3;
+                            const unsigned rb = ra + hgrp * 4096;
+                            asm volatile(
+                                "ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+                                "ds_read_b128 %4, %12\n\tds_read_b128 %5, %12 offset:1024\n\tds_read_b128 %6, %12 offset:2048\n\t"
+                                "ds_read_b128 %7, %12 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                                : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                                : "v"(aa[4 * hgrp]), "v"(aa[4 * hgrp + 1]), "v"(aa[4 * hgrp + 2]), "v"(aa[4 * hgrp + 3]), "v"(rb)
+                                : "memory");
+                            const f32x4 xs[4] = {x0, x1, x2, x3};
+                            const f32x4 rs[4] = {r0, r1, r2, r3};
+#pragma unroll
+                            for (int i4 = 0; i4 < 4; ++i4) {
+                                const int i = 4 * hgrp + i4;
+                                const f32x4 o = xs[i4] + rs[i4];
+                                const int m = m0 + lr0 + i;
+                                if (m < g.M && !(g.dbg & 1)) {
+                                    *reinterpret_cast<f32x4*>(outf + (size_t)m * g.N + n0 + lane * 4) = o;
+                                    const f32x4 og = o * gam;
+                                    *reinterpret_cast<uint2*>(g.xb + (size_t)m * g.N + n0 + lane * 4) =
+                                        make_uint2(pack_bf16x2(og.x, og.y), pack_bf16x2(og.z, og.w));
+                                }
+                                sa[i] = ln_lane_sum(o);
+                                sq[i] = ln_lane_sumsq(o);
+                            }
+                        }
+                        // 8 rows x (sum, sum of squares) reduced TRANSPOSED over xor 32, 16, 8 (each lane keeps half of
+                        // what it held), then over 4, 2, 1: 20 lane exchanges instead of 96, the same adds as ln_wave_sum
+                        const bool h32 = lane & 32, h16 = lane & 16, h8 = lane & 8;
+                        float a4[4], q4[4], a2[2], q2[2];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            a4[j] = (h32 ? sa[j + 4] : sa[j]) + __shfl_xor(h32 ? sa[j] : sa[j + 4], 32);
+                            q4[j] = (h32 ? sq[j + 4] : sq[j]) + __shfl_xor(h32 ? sq[j] : sq[j + 4], 32);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            a2[j] = (h16 ? a4[j + 2] : a4[j]) + __shfl_xor(h16 ? a4[j] : a4[j + 2], 16);
+                            q2[j] = (h16 ? q4[j + 2] : q4[j]) + __shfl_xor(h16 ? q4[j] : q4[j + 2], 16);
+                        }
+                        float a1 = (h8 ? a2[1] : a2[0]) + __shfl_xor(h8 ? a2[0] : a2[1], 8);
+                        float q1 = (h8 ? q2[1] : q2[0]) + __shfl_xor(h8 ? q2[0] : q2[1], 8);
+#pragma unroll
+                        for (int o_ = 4; o_ >= 1; o_ >>= 1) {
+                            a1 += __shfl_xor(a1, o_);
+                            q1 += __shfl_xor(q1, o_);
+                        }
+                        const int mrow = m0 + lr0 + (lane >> 3);          // the row this lane group ended up with
+                        if ((lane & 7) == 0 && mrow < g.M && !(g.dbg & 1))
+                            *reinterpret_cast<f32x2*>(g.ln_part + ((size_t)mrow * nseg + seg) * 2) = f32x2{a1, q1};
                     }
                 }
                 __builtin_amdgcn_s_barrier();              // sub-pass sp is out of LDS: image and buffer may be refilled
@@ -466,7 +574,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     #define P_STAGE(mt, b, nt)                                                                           \
         do {                                                                                             \
             f32x4 x_ = P_SCALED(acc[a][mt][b][nt], a, mt, b, nt);                                        \
-            if (EPI == EPI_BIAS_QGELU_BF16) x_ = quick_gelu4(x_);                                        \
+            if (epi_is_qgelu(EPI)) x_ = quick_gelu4(x_);                                                  \
             const uint2 pk_ = make_uint2(pack_bf16x2(x_.x, x_.y), pack_bf16x2(x_.z, x_.w));              \
             asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(stage_addr[nt]), "v"(pk_), "n"((mt) * 8192 + (b) * 256) : "memory"); \
         } while (0)

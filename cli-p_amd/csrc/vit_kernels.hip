@@ -12,6 +12,23 @@ int launch_layernorm(const LnArgs& a, hipStream_t st) {
     return 0;
 }
 
+int launch_cast_stats(const float* x, const float* gamma, unsigned short* xb, float* stats, int M, int W, hipStream_t st) {
+    if (M < 1) return 0;
+    if (!x || !gamma || !xb || !stats || W % 256 != 0 || W < 256 || W > 1024)
+        return set_err(CLIPMI_EINVAL, "cast_stats: W=%d (need W %% 256 == 0, 256 <= W <= 1024)", W);
+    hipLaunchKernelGGL(cast_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, gamma, xb, stats, M, W);
+    CLIPMI_CHECK_LAUNCH("cast_stats_kernel");
+    return 0;
+}
+
+int launch_ln_finish(const float* part, float* stats, int M, int W, hipStream_t st) {
+    if (M < 1) return 0;
+    if (!part || !stats || W % 256 != 0 || W < 256 || W > 1024) return set_err(CLIPMI_EINVAL, "ln_finish: W=%d", W);
+    hipLaunchKernelGGL(ln_finish_kernel, dim3((M + 255) / 256), dim3(256), 0, st, part, stats, M, W);
+    CLIPMI_CHECK_LAUNCH("ln_finish_kernel");
+    return 0;
+}
+
 template <int NT, bool CAUSAL, bool TR>
 static int launch_attn_t(const unsigned short* qkv, unsigned short* out, int B, int L, int heads, hipStream_t st) {
     constexpr int KS = (NT + 1) / 2;
@@ -105,4 +122,9 @@ extern "C" int clipmi_dbg_quantize_rows_fp8(const void* in_bf16_dev, void* out_f
                                             void* stream) {
     return launch_quantize_rows_fp8(static_cast<const unsigned short*>(in_bf16_dev), static_cast<unsigned char*>(out_fp8_dev),
                                     scale_dev, M, K, as_stream(stream));
+}
+
+extern "C" int clipmi_dbg_cast_stats(const float* x_dev, const float* gamma_dev, void* xb_dev, float* stats_dev, int M, int W,
+                                     void* stream) {
+    return launch_cast_stats(x_dev, gamma_dev, static_cast<unsigned short*>(xb_dev), stats_dev, M, W, as_stream(stream));
 }

@@ -219,6 +219,53 @@ static __global__ void __launch_bounds__(256) layernorm_kernel(LnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// LN-folded layers (gemm.hpp): the stand-alone producer of a GEMM's A operand and row statistics,
+//   xb[m][:] = bf16(x[m][:] * gamma),  stats[m] = (mean, rstd) of x[m][:]
+// used where the residual GEMM's own store pass cannot do it (ln_pre's output, non-persistent residual
+// GEMMs). One wave per row, W % 256 == 0, W <= 1024; statistics in the canonical order (same bits as the
+// persistent GEMM's storers + ln_finish_kernel).
+// ---------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256) cast_stats_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                unsigned short* __restrict__ xb, float* __restrict__ stats,
+                                                                int M, int W) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const int nseg = W >> 8;
+    const float* p = x + (size_t)r * W;
+    f32x4 v[4];
+    float part[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < nseg) {
+            v[j] = *reinterpret_cast<const f32x4*>(p + j * 256 + lane * 4);
+            part[2 * j] = ln_wave_sum(ln_lane_sum(v[j]));
+            part[2 * j + 1] = ln_wave_sum(ln_lane_sumsq(v[j]));
+        }
+    }
+    const f32x2 st = ln_row_stats(part, nseg, W);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < nseg) {
+            const f32x4 y = v[j] * *reinterpret_cast<const f32x4*>(gamma + j * 256 + lane * 4);
+            *reinterpret_cast<uint2*>(xb + (size_t)r * W + j * 256 + lane * 4) =
+                make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+        }
+    }
+    if (lane == 0) *reinterpret_cast<f32x2*>(stats + 2 * (size_t)r) = st;
+}
+
+// part [M][W/256][2] (sum, sum of squares per 256-column tile, written by gemm256p's residual storers) -> stats [M][2]
+static __global__ void __launch_bounds__(256) ln_finish_kernel(const float* __restrict__ part, float* __restrict__ stats, int M, int W) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= M) return;
+    const int nseg = W >> 8;
+    float loc[8];
+    for (int j = 0; j < 2 * nseg; ++j) loc[j] = part[(size_t)r * 2 * nseg + j];
+    *reinterpret_cast<f32x2*>(stats + 2 * (size_t)r) = ln_row_stats(loc, nseg, W);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused attention for short sequences (L <= 16*NT; ViT-B/32: L = 50, text: L = 77), head dim 64.
 // One wave per (sequence, head). qkv bf16 [B*L][3W] (q | k | v, head h at columns 64h..64h+63
 // of each third) -> out bf16 [B*L][W].

@@ -8,6 +8,7 @@ come from a LOCAL file with OpenAI key names (SURVEY.md §8b "weight-file contra
 `random_state_dict` (synthetic benchmarks and parity tests).
 """
 import math
+import os
 
 import torch
 
@@ -210,10 +211,22 @@ def quantize_fp8_rows(w):
     return q.view(torch.uint8), scale
 
 
+def ln_fold_terms(w, bias, gamma, beta):
+    """LN-folded linear layer (include/clipmi.h, tower ABI 3): for y = LayerNorm(x; gamma, beta) W^T + bias with the
+    bf16-rounded W the kernels multiply by, colsum[n] = sum_k gamma[k] W[n][k] and cb[n] = sum_k beta[k] W[n][k] +
+    bias[n], summed in float64, returned as f32."""
+    wd = w.detach().to("cpu").to(torch.bfloat16).double()
+    colsum = wd @ gamma.detach().double()
+    cb = wd @ beta.detach().double() + bias.detach().double()
+    return colsum.float(), cb.float()
+
+
 def _pack_layers(tw, blob, sd, prefix, width, layers, fp8=False):
     bf, f32 = torch.bfloat16, torch.float32
     first = None
     stride = None
+    # (CLIPMI_LN_FOLD=0: development switch for A/B runs on one box — the stand-alone LayerNorm passes)
+    tw.ln_fold = 1 if (not fp8 and width % 256 == 0 and os.environ.get("CLIPMI_LN_FOLD", "1") != "0") else 0
     names = [("lo_ln1_w", "ln_1.weight", f32), ("lo_ln1_b", "ln_1.bias", f32),
              ("lo_qkv_w", "attn.in_proj_weight", bf), ("lo_qkv_b", "attn.in_proj_bias", f32),
              ("lo_out_w", "attn.out_proj.weight", bf), ("lo_out_b", "attn.out_proj.bias", f32),
@@ -242,6 +255,17 @@ def _pack_layers(tw, blob, sd, prefix, width, layers, fp8=False):
                 setattr(tw, field, off - base)
             else:
                 assert off - base == getattr(tw, field), "layers must have identical layouts"
+        if tw.ln_fold:
+            p_ = f"{prefix}.resblocks.{i}"
+            for fld_s, fld_c, wk, bk, ln in (("lo_qkv_colsum", "lo_qkv_cb", "attn.in_proj_weight", "attn.in_proj_bias", "ln_1"),
+                                             ("lo_fc_colsum", "lo_fc_cb", "mlp.c_fc.weight", "mlp.c_fc.bias", "ln_2")):
+                colsum, cb = ln_fold_terms(sd[f"{p_}.{wk}"], sd[f"{p_}.{bk}"], sd[f"{p_}.{ln}.weight"], sd[f"{p_}.{ln}.bias"])
+                for fld, t in ((fld_s, colsum), (fld_c, cb)):
+                    off = blob.put(t, f32)
+                    if i == 0:
+                        setattr(tw, fld, off - base)
+                    else:
+                        assert off - base == getattr(tw, fld)
         if i == 0:
             first = base
         elif i == 1:

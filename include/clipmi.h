@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CLIPMI_ABI_VERSION 2
+#define CLIPMI_ABI_VERSION 3
 
 enum {
     CLIPMI_OK = 0,
@@ -95,8 +95,16 @@ typedef struct clipmi_tower {
        (BASELINE.json configs[4], FP8 matrix cores): lo_qkv_w / lo_out_w / lo_fc_w / lo_proj_w point at OCP e4m3
        bytes [out_features][in_features] and lo_*_s at f32 [out_features] per-output-channel scales
        (weight = scale * e4m3 value); activations are quantised per row on the fly. Needs width % 256 == 0. */
-    int32_t weight_format, reserved0;
+    int32_t weight_format, ln_fold;
     uint64_t lo_qkv_s, lo_out_s, lo_fc_s, lo_proj_s;
+
+    /* ABI 3. ln_fold = 1 (weight_format 0, width % 256 == 0): ln_1 / ln_2 are folded into the GEMMs that consume
+       them. With mean / rstd the row statistics of the residual row x,
+           LayerNorm(x; g, b) W^T + bias = rstd * ((x * g) W^T - mean * colsum) + cb,
+       colsum[n] = sum_k g[k] W[n][k], cb[n] = sum_k b[k] W[n][k] + bias[n]   (W = the bf16-rounded weights, sums in
+       float64, stored f32 [3W] / [4W]): the residual GEMM's store pass writes bf16(x * g) and the statistics, and the
+       stand-alone LayerNorm pass over the residual stream disappears. The plain lo_ln*_w/b stay (ln_fold = 0 path). */
+    uint64_t lo_qkv_colsum, lo_qkv_cb, lo_fc_colsum, lo_fc_cb;
 } clipmi_tower;
 
 /* ---- a3/a4: model.encode_image(image) and the row L2-normalise that follows it ----------
@@ -227,6 +235,19 @@ int clipmi_dbg_topk_coarse_i8_scan_ms(const void* db_dev, const void* db_i8_dev,
 int clipmi_dbg_quantize_rows_fp8(const void* in_bf16_dev, void* out_fp8_dev, float* scale_dev, int M, int K, void* stream);
 int clipmi_dbg_gemm_fp8(const void* a8_dev, const void* w8_dev, const float* a_scale_dev, const float* w_scale_dev,
                         const float* bias_dev, void* out_dev, int M, int N, int K, int epi, void* stream);
+
+/* LN-folded linear layers (tower ABI 3, csrc/gemm.hpp), kernel by kernel:
+ *   cast_stats    x f32 [M][W] -> xb = bf16(x * gamma), stats [M][2] = (mean, rstd)            (W % 256 == 0, <= 1024)
+ *   gemm_ln       out bf16 = [quick_gelu] (rstd * (xb w^T - mean * colsum) + cb); epi 5 | 6, bits 8-9 force a kernel
+ *   gemm_resid_ln x += a w^T + bias (f32, in place), xb = bf16(x * gamma), stats of the new rows; part = scratch
+ *                 [M][N/256][2]; algo 3 = the persistent kernel's fused store pass, else residual GEMM + cast_stats */
+int clipmi_dbg_cast_stats(const float* x_dev, const float* gamma_dev, void* xb_dev, float* stats_dev, int M, int W,
+                          void* stream);
+int clipmi_dbg_gemm_ln(const void* xb_dev, const void* w_dev, const float* cb_dev, const float* colsum_dev,
+                       const float* stats_dev, void* out_dev, int M, int N, int K, int epi, void* stream);
+int clipmi_dbg_gemm_resid_ln(const void* a_dev, const void* w_dev, const float* bias_dev, float* x_dev,
+                             const float* gamma_dev, void* xb_dev, float* part_dev, float* stats_dev, int M, int N, int K,
+                             int algo, void* stream);
 
 /* clipmi_encode_image `reps` times with HIP events around every launch of the GEMM whose
  * epilogue is `probe_epi` (1 = MLP c_fc + QuickGELU), on `stream`; synchronises;

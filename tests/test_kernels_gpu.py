@@ -272,3 +272,108 @@ def test_gemm256p_rejects(clipmi, gpu):
     # K = 192: three K-tiles (odd) -> refused; f32 epilogues -> refused
     assert L.clipmi_dbg_gemm_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 256, 256, 192, 0 | (3 << 8), None) == 1
     assert L.clipmi_dbg_gemm_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 256, 256, 128, 3 | (3 << 8), None) == 1
+
+
+# ---- LN-folded linear layers (csrc/gemm.hpp): LayerNorm folded into the GEMM that consumes it -----------------------
+def _ln_fold_case(gpu, M, W, N, seed):
+    g = torch.Generator(device="cpu"); g.manual_seed(seed)
+    x = torch.randn(M, W, generator=g) * 2 + 0.3
+    x[:, 5] += 40.0                                           # an outlier channel, as in real CLIP residual streams
+    gamma = 1 + 0.1 * torch.randn(W, generator=g)
+    beta = 0.1 * torch.randn(W, generator=g)
+    w = _bf16(torch.randn(N, W, generator=g) * W ** -0.5)
+    bias = 0.1 * torch.randn(N, generator=g)
+    return x.to(gpu), gamma.to(gpu), beta.to(gpu), w.to(gpu), bias.to(gpu)
+
+
+@pytest.mark.parametrize("M,W", [(1, 768), (7, 512), (1003, 768), (33, 1024), (260, 256)])
+def test_cast_stats(clipmi, gpu, M, W):
+    """xb = bf16(x * gamma) exactly; (mean, rstd) = torch's LayerNorm statistics of the f32 row."""
+    L = clipmi._lib.lib()
+    x, gamma, _, _, _ = _ln_fold_case(gpu, M, W, 256, M + W)
+    xb = torch.empty(M, W, dtype=torch.bfloat16, device=gpu)
+    st = torch.empty(M, 2, dtype=torch.float32, device=gpu)
+    clipmi._lib.check(L.clipmi_dbg_cast_stats(x.data_ptr(), gamma.data_ptr(), xb.data_ptr(), st.data_ptr(), M, W, None), "cast_stats")
+    torch.cuda.synchronize()
+    assert torch.equal(xb, (x * gamma).to(torch.bfloat16))
+    mean = x.double().mean(dim=1)
+    rstd = (x.double().var(dim=1, unbiased=False) + 1e-5).rsqrt()
+    assert (st[:, 0].double() - mean).abs().max().item() <= 2e-6 * x.abs().max().item()
+    assert ((st[:, 1].double() - rstd) / rstd).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("M,W,N", [(1, 768, 2304), (77, 512, 1536), (6400, 768, 3072), (6401, 768, 2304), (300, 1024, 4096),
+                                   (70000, 768, 2304)])
+@pytest.mark.parametrize("epi", [5, 6])
+def test_gemm_ln_folded_consumer(clipmi, gpu, M, W, N, epi):
+    """out = [quick_gelu](LayerNorm(x; gamma, beta) W^T + bias) through cast_stats + the LN-folded epilogue, against
+    torch fp32 on the bf16-rounded weights; every kernel that can run the shape returns the SAME bits (batch-size
+    invariance of the encoder rests on that)."""
+    L = clipmi._lib.lib()
+    x, gamma, beta, w, bias = _ln_fold_case(gpu, M, W, N, M + W + N + epi)
+    colsum, cb = clipmi.weights.ln_fold_terms(w.float().cpu(), bias.cpu(), gamma.cpu(), beta.cpu())
+    colsum, cb = colsum.to(gpu), cb.to(gpu)
+    xb = torch.empty(M, W, dtype=torch.bfloat16, device=gpu)
+    st = torch.empty(M, 2, dtype=torch.float32, device=gpu)
+    clipmi._lib.check(L.clipmi_dbg_cast_stats(x.data_ptr(), gamma.data_ptr(), xb.data_ptr(), st.data_ptr(), M, W, None), "cast_stats")
+    ref = torch.nn.functional.layer_norm(x, (W,), gamma, beta, 1e-5) @ w.float().t() + bias
+    if epi == 6:
+        ref = _qgelu(ref)
+    outs = {}
+    for algo in (0, 1, 2, 3):
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=gpu)
+        rc = L.clipmi_dbg_gemm_ln(xb.data_ptr(), w.data_ptr(), cb.data_ptr(), colsum.data_ptr(), st.data_ptr(), out.data_ptr(),
+                                  M, N, W, epi | (algo << 8), None)
+        if rc != 0 and algo == 3:
+            assert N > 3840                         # the persistent form keeps bias + colsum rows in LDS
+            continue
+        clipmi._lib.check(rc, f"gemm_ln algo {algo}")
+        torch.cuda.synchronize()
+        outs[algo] = out
+    scale = ref.abs().max().item()
+    # the A operand is bf16(x * gamma) (one rounding of the un-normalised value): 2^-8 of the output scale covers it
+    err = (outs[0].float() - ref).abs().max().item()
+    assert torch.isfinite(outs[0].float()).all() and err <= 2.5 * (2.0 ** -8) * scale, f"err {err} scale {scale}"
+    for algo, out in outs.items():
+        assert torch.equal(out, outs[0]), f"algo {algo} differs from the default kernel's bits"
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 768, 768), (300, 512, 2048), (6400, 768, 768), (6401, 768, 3072), (70000, 768, 768),
+                                   (43500, 768, 3072), (1000, 1024, 1024)])
+def test_gemm_resid_ln_producer(clipmi, gpu, M, N, K):
+    """x += a W^T + bias (f32), xb = bf16(x * gamma), stats of the new rows: the persistent kernel's fused store pass
+    (algo 3) and residual GEMM + cast_stats (algos 1, 2) give identical bits in all three outputs, and x matches the
+    plain residual epilogue and torch."""
+    L = clipmi._lib.lib()
+    g = torch.Generator(device="cpu"); g.manual_seed(M + N + K)
+    a = _bf16(torch.randn(M, K, generator=g)).to(gpu)
+    w = _bf16(torch.randn(N, K, generator=g) * K ** -0.5).to(gpu)
+    bias = torch.randn(N, generator=g).to(gpu)
+    gamma = (1 + 0.1 * torch.randn(N, generator=g)).to(gpu)
+    x0 = (torch.randn(M, N, generator=g) * 2).to(gpu)
+    x0[:, 7] += 30.0
+    res = {}
+    for algo in (1, 2, 3):
+        x = x0.clone()
+        xb = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=gpu)
+        part = torch.full((M, N // 256, 2), float("nan"), dtype=torch.float32, device=gpu)
+        st = torch.full((M, 2), float("nan"), dtype=torch.float32, device=gpu)
+        clipmi._lib.check(L.clipmi_dbg_gemm_resid_ln(a.data_ptr(), w.data_ptr(), bias.data_ptr(), x.data_ptr(), gamma.data_ptr(),
+                                                     xb.data_ptr(), part.data_ptr(), st.data_ptr(), M, N, K, algo, None),
+                          f"gemm_resid_ln algo {algo}")
+        torch.cuda.synchronize()
+        res[algo] = (x, xb, st)
+    plain = x0.clone()
+    clipmi._lib.check(L.clipmi_dbg_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), plain.data_ptr(), M, N, K, 2, None), "gemm")
+    torch.cuda.synchronize()
+    ref = a.float() @ w.float().t() + bias + x0
+    x3, xb3, st3 = res[3]
+    assert torch.equal(x3, plain) and (x3 - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+    assert torch.equal(xb3, (x3 * gamma).to(torch.bfloat16))
+    mean = x3.double().mean(dim=1)
+    rstd = (x3.double().var(dim=1, unbiased=False) + 1e-5).rsqrt()
+    assert (st3[:, 0].double() - mean).abs().max().item() <= 2e-6 * x3.abs().max().item()
+    assert ((st3[:, 1].double() - rstd) / rstd).abs().max().item() <= 2e-5
+    for algo in (1, 2):
+        for got, want, what in zip(res[algo], res[3], ("x", "xb", "stats")):
+            assert torch.equal(got, want), f"algo {algo} vs the fused store pass: {what} differs"
