@@ -318,14 +318,32 @@ def search_leg(L, a, dev, dist, world, rank, rows_total, n_local, seed, steps, w
 
     def search_step():
         res[0] = searcher.search_device(q, K)
-    dt_s = timed(search_step, steps, warmup, dist, world)
+    dt_one = timed(search_step, steps, warmup, dist, world)
     assert (res[0][1][:, 0] >= 0).all()
+    ref_i = res[0][1].clone()
+    # the same K steps with TWO batches in flight on two HIP streams (every call owns its stream's workspace and
+    # result buffers): one batch's short latency-bound kernels (pre-pass, re-scoring, selects, merge) run beside the
+    # other batch's HBM-bound scan. Results are identical; throughput is what BASELINE.json's queries/s asks for.
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    turn = [0]
+
+    def search_step2():
+        with torch.cuda.stream(streams[turn[0] & 1]):
+            res[0] = searcher.search_device(q, K)
+        turn[0] += 1
+    dt_two = timed(search_step2, steps, warmup + (warmup & 1), dist, world)
+    torch.cuda.synchronize()
+    assert torch.equal(res[0][1], ref_i)
+    dt_s = min(dt_one, dt_two)
     Qp = min(Q, 64 if coarse else 32)            # queries of ONE pass
     scan_ms, surv, scan_bytes, scan_name, traffic_key = scan_probe(L, idx, q, Qp, K, dev, kind)
     scan_gbs = scan_bytes / (scan_ms * 1e-3) / 1e9
     passes = (Q + Qp - 1) // Qp
     traffic, tsrc = pmc_traffic(traffic_key)
     out = {"value": Q * steps / dt_s, "unit": "queries/s", "ms_per_step": dt_s / steps * 1e3, "steps": steps,
+           "batches_in_flight": 2 if dt_two < dt_one else 1,
+           "one_batch_in_flight": {"value": Q * steps / dt_one, "ms_per_step": dt_one / steps * 1e3},
+           "two_batches_in_flight": {"value": Q * steps / dt_two, "ms_per_step": dt_two / steps * 1e3},
            "dtype": ("int8 coarse scan (i32 MFMA) + f32 exact re-scoring" if kind == "int8" else
                      "bf16 coarse scan + f32 exact re-scoring" if kind == "bf16" else "f32"),
            "path": ("coarse-then-exact (clipmi_topk_ip_coarse_i8)" if kind == "int8" else

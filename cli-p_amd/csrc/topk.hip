@@ -254,6 +254,90 @@ __global__ void __launch_bounds__(256) scan_topk_f32_kernel(ScanArgs a) {
     }
 }
 
+// Level 1 of the coarse path's pre-pass: exact scores of the first `nrows` rows (a few thousand) for up to 64 queries
+// in ONE launch, written out unfiltered as candidate entries cand[q][row] = (score bits, row) for the radix select to
+// take the K-th best of. Same MFMA sequence per (row, query) as scan_topk_f32_kernel (score order of this file's
+// header); with no candidate buffers to keep, the 128-KiB image of 64 queries fits LDS, which the filtering kernel's
+// 32-query passes (two scans + two selects) could not. A NaN score is stored as -inf ("never ranks").
+template <int E>
+__global__ void __launch_bounds__(256) sample_scores_kernel(const float* __restrict__ db, long long nrows,
+                                                            const float* __restrict__ q, int QA, uint2* __restrict__ cand,
+                                                            long long cap, unsigned* __restrict__ gcnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = E / 16, QG = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, g = lane >> 4;
+    f32x4* qimg = reinterpret_cast<f32x4*>(smem);
+    // QG*NT*64 = 8192 entries over 256 threads, 8 loads in flight per thread (one at a time cost ~10 us per block)
+    for (int base = tid; base < QG * NT * 64; base += 8 * 256) {
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = base + j * 256;
+            const int l = idx & 63, t = (idx >> 6) % NT, qg = (idx >> 6) / NT;
+            const int c_ = qg * 16 + (l & 15), g_ = l >> 4;
+            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c_ < QA) v[j] = *reinterpret_cast<const f32x4*>(q + (size_t)c_ * E + 16 * t + 4 * g_);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qimg[base + j * 256] = v[j];
+    }
+    if (blockIdx.x == 0 && tid < QA) gcnt[tid] = (unsigned)nrows;
+    __syncthreads();
+    const long long ntiles = (nrows + 15) >> 4;
+    const long long last_row = nrows - 1;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        long long r = tile * 16 + col;
+        r = r > last_row ? last_row : r;
+        const float* p = db + r * E + 4 * g;
+        f32x4 T[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) T[t] = *reinterpret_cast<const f32x4*>(p + 16 * t);
+        f32x4 acc[QG];
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) acc[qg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 bq[QG];
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) bq[qg] = qimg[(qg * NT + t) * 64 + lane];
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) acc[qg] = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t].x, bq[qg].x, acc[qg], 0, 0, 0);
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) acc[qg] = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t].y, bq[qg].y, acc[qg], 0, 0, 0);
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) acc[qg] = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t].z, bq[qg].z, acc[qg], 0, 0, 0);
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) acc[qg] = __builtin_amdgcn_mfma_f32_16x16x4f32(T[t].w, bq[qg].w, acc[qg], 0, 0, 0);
+        }
+        // accumulator qg: column = query 16*qg + col, rows = tile*16 + 4g + r_: a lane's four rows of one query are
+        // 32 contiguous bytes of that query's list (two 16-byte stores; the four lane groups complete the 128-byte line)
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) {
+            const int qi = qg * 16 + col;
+            const long long row = tile * 16 + 4 * g;
+            unsigned sb[4];
+#pragma unroll
+            for (int r_ = 0; r_ < 4; ++r_) {
+                const float sc = acc[qg][r_];
+                sb[r_] = __float_as_uint(sc == sc ? sc : -INFINITY);
+            }
+            if (qi < QA) {
+                uint2* dst = cand + (size_t)qi * cap + row;          // cap and row are multiples of 4: 32-byte aligned
+                if (row + 3 <= last_row) {
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(sb[0], (unsigned)row, sb[1], (unsigned)row + 1);
+                    *reinterpret_cast<uint4*>(dst + 2) = make_uint4(sb[2], (unsigned)row + 2, sb[3], (unsigned)row + 3);
+                } else {
+#pragma unroll
+                    for (int r_ = 0; r_ < 4; ++r_)
+                        if (row + r_ <= last_row) dst[r_] = make_uint2(sb[r_], (unsigned)(row + r_));
+                }
+            }
+        }
+    }
+}
+
 // Composite 64-bit key: larger = better under the ordering rule. High word = order-preserving
 // image of the f32 score (-0 folded into +0), low word = ~id (smaller id wins ties). Keys of
 // distinct rows are distinct, so "the K largest keys" is exactly the rule's top-K.
@@ -265,16 +349,27 @@ __device__ __forceinline__ unsigned long long ckey(uint2 c) {
 }
 
 constexpr int SEL_THREADS = 512;
+constexpr int SEL_STAGE = 12288;      // candidate entries a select block keeps in LDS (96 KiB); longer lists stream from L2
+constexpr int SEL_FIXED = 32 * 8 + (256 + 8 + 8) * 4;
+// large K leaves less room beside the K-entry result buffer; host (LDS size) and device (staging test) share this
+__host__ __device__ constexpr int sel_stage_entries(int K) {
+    return (LDS_LIMIT - SEL_FIXED - K * 8) / 8 < SEL_STAGE ? ((LDS_LIMIT - SEL_FIXED - K * 8) / 8 < 0 ? 0 : (LDS_LIMIT - SEL_FIXED - K * 8) / 8)
+                                                           : SEL_STAGE;
+}
 
 // One block per query: exact top-K of a dense, unsorted candidate list by MSB-first radix
 // select on the composite key (8-bit digits, starting at the highest bit in which the list's
 // keys differ), then a rank-count sort of the K survivors. All passes stream the list from
-// global memory (it is L2-resident: a few thousand 8-byte entries).
+// global memory (it is L2-resident: a few thousand 8-byte entries) - unless it fits SEL_STAGE entries, in which case
+// the block copies it into LDS once (loads batched four deep) and every pass runs out of LDS: the per-pass loop
+// (load, LDS atomic, next load) otherwise pays one L2 round trip per 512 entries, ~17 us for a 7 k-entry list
+// against ~5 us staged (seven selects per 64-query search).
 __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* __restrict__ cand,
                                                                  unsigned* __restrict__ gcnt, long long cap,
                                                                  int K, long long id_base, float* out_s,
                                                                  long long* out_i, float* thr_out,
-                                                                 const unsigned* run_if, unsigned* m_out = nullptr) {
+                                                                 const unsigned* run_if, unsigned* m_out = nullptr,
+                                                                 int keep = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (run_if && *run_if == 0) return;
     unsigned long long* red = reinterpret_cast<unsigned long long*>(smem);   // [16] min, [16] max
@@ -282,6 +377,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
     unsigned* wsum = hist + 256;                                             // [8]
     unsigned* ctl = wsum + 8;                                                // [8] b, above, nsel
     uint2* sel = reinterpret_cast<uint2*>(ctl + 8);                          // [K]
+    uint2* lent = sel + K;                                                   // [SEL_STAGE] staged copy of the list
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
@@ -289,104 +385,131 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
     if (M > cap) M = cap;
     const uint2* src = cand + (size_t)q * cap;
     const int need = (int)(M < K ? M : K);
-
-    unsigned long long T = 0;     // select keys >= T
-    if (M > K) {
-        unsigned long long kmin = ~0ull, kmax = 0ull;
-        for (long long e = tid; e < M; e += SEL_THREADS) {
-            const unsigned long long k = ckey(src[e]);
-            kmin = k < kmin ? k : kmin;
-            kmax = k > kmax ? k : kmax;
-        }
+    const bool staged = M <= sel_stage_entries(K);
+    if (staged) {
+        for (long long e0 = tid; e0 < M; e0 += 4 * SEL_THREADS) {
+            uint2 v[4];
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const unsigned long long a = __shfl_xor(kmin, o), b = __shfl_xor(kmax, o);
-            kmin = a < kmin ? a : kmin;
-            kmax = b > kmax ? b : kmax;
+            for (int j = 0; j < 4; ++j) {
+                const long long e = e0 + (long long)j * SEL_THREADS;
+                v[j] = src[e < M ? e : M - 1];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long e = e0 + (long long)j * SEL_THREADS;
+                if (e < M) lent[e] = v[j];
+            }
         }
-        if (lane == 0) { red[wave] = kmin; red[16 + wave] = kmax; }
         __syncthreads();
-        for (int w = 0; w < SEL_THREADS / 64; ++w) {
-            kmin = red[w] < kmin ? red[w] : kmin;
-            kmax = red[16 + w] > kmax ? red[16 + w] : kmax;
-        }
-        const unsigned long long diff = kmin ^ kmax;          // != 0: M >= 2 distinct keys
-        int hi_shift = 64 - __builtin_clzll(diff);              // low bits not fixed yet, 1..64
-        unsigned long long prefix = hi_shift >= 64 ? 0ull : ((kmax >> hi_shift) << hi_shift);
-        unsigned r = (unsigned)K;                               // wanted: the r largest keys matching prefix
-        while (hi_shift > 0) {
-            const int w = hi_shift < 8 ? hi_shift : 8;
-            const int shift = hi_shift - w;
-            const unsigned dmask = (1u << w) - 1u;
-            if (tid < 256) hist[tid] = 0;
-            __syncthreads();
-            for (long long e = tid; e < M; e += SEL_THREADS) {
-                const unsigned long long k = ckey(src[e]);
-                const bool match = hi_shift >= 64 || (k >> hi_shift) == (prefix >> hi_shift);
-                if (match) atomicAdd(&hist[(unsigned)(k >> shift) & dmask], 1u);
-            }
-            __syncthreads();
-            // inclusive suffix sums S[t] = sum_{u >= t} hist[u] over 256 bins (waves 0..3)
-            unsigned h = 0, S = 0;
-            if (tid < 256) {
-                h = hist[tid];
-                S = h;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const unsigned v = __shfl_down(S, o);
-                    if (lane + o < 64) S += v;
-                }
-                if (lane == 0) wsum[wave] = S;
-            }
-            __syncthreads();
-            if (tid < 256) {
-                for (int w2 = wave + 1; w2 < 4; ++w2) S += wsum[w2];
-                const unsigned above = S - h;                    // count in bins > tid
-                if (S >= r && above < r) { ctl[0] = (unsigned)tid; ctl[1] = above; ctl[2] = h; }
-            }
-            __syncthreads();
-            const unsigned b = ctl[0], above = ctl[1], cb = ctl[2];
-            prefix |= (unsigned long long)b << shift;
-            hi_shift = shift;
-            r -= above;
-            __syncthreads();
-            if (cb == r) break;                                  // the whole bin is selected
-        }
-        T = prefix;
     }
+    // the passes below exist twice, once per address space of the list (a pointer select would make every access a
+    // flat load, each waiting on both counters in a loop that also holds LDS atomics: 54 us per select, measured)
+    auto passes = [&](auto ent) {
 
-    if (tid == 0) ctl[4] = 0;
-    __syncthreads();
-    for (long long e = tid; e < M; e += SEL_THREADS) {
-        const uint2 c = src[e];
-        if (ckey(c) >= T) {
-            const unsigned pos = atomicAdd(&ctl[4], 1u);
-            if (pos < (unsigned)need) sel[pos] = c;
+        unsigned long long T = 0;     // select keys >= T
+        if (M > K) {
+            unsigned long long kmin = ~0ull, kmax = 0ull;
+            for (long long e = tid; e < M; e += SEL_THREADS) {
+                const unsigned long long k = ckey(ent(e));
+                kmin = k < kmin ? k : kmin;
+                kmax = k > kmax ? k : kmax;
+            }
+    #pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const unsigned long long a = __shfl_xor(kmin, o), b = __shfl_xor(kmax, o);
+                kmin = a < kmin ? a : kmin;
+                kmax = b > kmax ? b : kmax;
+            }
+            if (lane == 0) { red[wave] = kmin; red[16 + wave] = kmax; }
+            __syncthreads();
+            for (int w = 0; w < SEL_THREADS / 64; ++w) {
+                kmin = red[w] < kmin ? red[w] : kmin;
+                kmax = red[16 + w] > kmax ? red[16 + w] : kmax;
+            }
+            const unsigned long long diff = kmin ^ kmax;          // != 0: M >= 2 distinct keys
+            int hi_shift = 64 - __builtin_clzll(diff);              // low bits not fixed yet, 1..64
+            unsigned long long prefix = hi_shift >= 64 ? 0ull : ((kmax >> hi_shift) << hi_shift);
+            unsigned r = (unsigned)K;                               // wanted: the r largest keys matching prefix
+            while (hi_shift > 0) {
+                const int w = hi_shift < 8 ? hi_shift : 8;
+                const int shift = hi_shift - w;
+                const unsigned dmask = (1u << w) - 1u;
+                if (tid < 256) hist[tid] = 0;
+                __syncthreads();
+                for (long long e = tid; e < M; e += SEL_THREADS) {
+                    const unsigned long long k = ckey(ent(e));
+                    const bool match = hi_shift >= 64 || (k >> hi_shift) == (prefix >> hi_shift);
+                    if (match) atomicAdd(&hist[(unsigned)(k >> shift) & dmask], 1u);
+                }
+                __syncthreads();
+                // inclusive suffix sums S[t] = sum_{u >= t} hist[u] over 256 bins (waves 0..3)
+                unsigned h = 0, S = 0;
+                if (tid < 256) {
+                    h = hist[tid];
+                    S = h;
+    #pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const unsigned v = __shfl_down(S, o);
+                        if (lane + o < 64) S += v;
+                    }
+                    if (lane == 0) wsum[wave] = S;
+                }
+                __syncthreads();
+                if (tid < 256) {
+                    for (int w2 = wave + 1; w2 < 4; ++w2) S += wsum[w2];
+                    const unsigned above = S - h;                    // count in bins > tid
+                    if (S >= r && above < r) { ctl[0] = (unsigned)tid; ctl[1] = above; ctl[2] = h; }
+                }
+                __syncthreads();
+                const unsigned b = ctl[0], above = ctl[1], cb = ctl[2];
+                prefix |= (unsigned long long)b << shift;
+                hi_shift = shift;
+                r -= above;
+                __syncthreads();
+                if (cb == r) break;                                  // the whole bin is selected
+            }
+            T = prefix;
         }
-    }
-    __syncthreads();
-    for (int e = tid; e < need; e += SEL_THREADS) {
-        const uint2 me = sel[e];
-        const unsigned long long mk = ckey(me);
-        int rank = 0;
-        for (int j = 0; j < need; ++j) rank += ckey(sel[j]) > mk ? 1 : 0;
-        if (out_s) {
-            out_s[(size_t)q * K + rank] = __uint_as_float(me.x);
-            out_i[(size_t)q * K + rank] = id_base + (long long)me.y;
+
+        if (tid == 0) ctl[4] = 0;
+        __syncthreads();
+        for (long long e = tid; e < M; e += SEL_THREADS) {
+            const uint2 c = ent(e);
+            if (ckey(c) >= T) {
+                const unsigned pos = atomicAdd(&ctl[4], 1u);
+                if (pos < (unsigned)need) sel[pos] = c;
+            }
         }
-        if (thr_out && rank == K - 1) thr_out[q] = __uint_as_float(me.x);
-    }
-    if (out_s)
-        for (int e = need + tid; e < K; e += SEL_THREADS) {
-            out_s[(size_t)q * K + e] = -FLT_MAX;
-            out_i[(size_t)q * K + e] = -1;
+        __syncthreads();
+        uint2* dst_keep = keep ? const_cast<uint2*>(src) : nullptr;      // every read of src is behind the barrier above
+        for (int e = tid; e < need; e += SEL_THREADS) {
+            const uint2 me = sel[e];
+            const unsigned long long mk = ckey(me);
+            int rank = 0;
+            for (int j = 0; j < need; ++j) rank += ckey(sel[j]) > mk ? 1 : 0;
+            if (dst_keep) dst_keep[rank] = me;
+            if (out_s) {
+                out_s[(size_t)q * K + rank] = __uint_as_float(me.x);
+                out_i[(size_t)q * K + rank] = id_base + (long long)me.y;
+            }
+            if (thr_out && rank == K - 1) thr_out[q] = __uint_as_float(me.x);
         }
-    if (thr_out && need < K && tid == 0) thr_out[q] = -INFINITY;
+        if (out_s)
+            for (int e = need + tid; e < K; e += SEL_THREADS) {
+                out_s[(size_t)q * K + e] = -FLT_MAX;
+                out_i[(size_t)q * K + e] = -1;
+            }
+        if (thr_out && need < K && tid == 0) thr_out[q] = -INFINITY;
+    };
+    if (staged) passes([&](long long e) -> uint2 { return lent[e]; });
+    else passes([&](long long e) -> uint2 { return src[e]; });
     // leave the counter zeroed for the next scan of this call (every thread read M at entry; the
     // barriers above order that read before this store) — saves a memset node per scan
+    // keep = 1 (segmented coarse scan): the K selected entries stay at the head of the list and the next segment's
+    // survivors are appended behind them; keep bit 1: add to the measurement counter instead of overwriting it
     if (tid == 0) {
-        gcnt[q] = 0;
-        if (m_out) m_out[q] = (unsigned)M;        // list length, for measurement hooks
+        gcnt[q] = keep & 1 ? (unsigned)need : 0u;
+        if (m_out) m_out[q] = (keep & 2 ? m_out[q] : 0u) + (unsigned)M;        // list length(s), for measurement hooks
     }
 }
 
@@ -570,6 +693,7 @@ struct CoarseArgs {
     const void* dbc;             // coarse copy of the matrix: bf16 [nrows][E] or int8 [nrows][E]
     const float2* rmeta;         // int8 only: per row (scale s_r, error norm a_r >= ||x_r - s_r q_r||), padded to 32 rows
     const float* qmeta;          // int8 only: [3][64]: 1/t_q | 1.001 ||y|| / t_q | threshold / t_q
+    long long row0;              // this launch scans rows [row0, row0 + nrows) of the copy; row0 % 32 == 0 (ids stay global)
     long long nrows;
     const float* q;              // f32 [QA][E]
     int QA;                      // 1..16*QG
@@ -662,12 +786,14 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
         wave_lds_sync();
     };
 
-    const long long nsteps = (a.nrows + 31) >> 5;
+    // steps are counted from row 0 of the copy (row0 % 32 == 0), so row = 32 step + ... is the global row id
+    const long long step0 = a.row0 >> 5;
+    const long long nsteps = step0 + ((a.nrows + 31) >> 5);
     const long long wg = (long long)blockIdx.x * nwaves + wave;
     const long long tw = (long long)gridDim.x * nwaves;
-    const long long last_row = a.nrows - 1;
+    const long long last_row = a.row0 + a.nrows - 1;
 
-    long long step = wg;
+    long long step = step0 + wg;
     if (step < nsteps) {
         uint4 T[SLOTS];
         auto frag_ptr = [&](long long st, int rt) {
@@ -896,7 +1022,8 @@ bool make_plan(long long N, int E, int Q, int K, Plan& p) {
             }
         }
     if (p.waves == 0) return false;
-    p.lds_sel = 32 * 8 + (256 + 8 + 8) * 4 + (size_t)K * 8;
+    if (SEL_FIXED + (long long)K * 8 > LDS_LIMIT) return false;
+    p.lds_sel = SEL_FIXED + (size_t)K * 8 + (size_t)sel_stage_entries(K) * 8;
     if (p.lds_sel > (size_t)LDS_LIMIT) return false;
     const int qimg = p.QG * (E / 16) * 1024;
     p.wave_bytes = (p.QA + 1) * p.C * 8 + 256;
@@ -1117,22 +1244,24 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
         while (S2 < N / 8 && S2 * 2048 < N * (long long)K) S2 *= 2;
         // level 1 only has to thin level 2's candidates (S2*K/S1 per query): 8 k rows are enough, and its
         // select then ranks 8 k entries per query instead of 32 k
-        const long long S1 = p.sample_rows < 8192 ? p.sample_rows : 8192;
-        const int g1 = (int)((S1 / 16 + p.waves - 1) / p.waves);
+        // (12288 = what the select keeps in LDS; N >= 65536 here)
+        long long S1 = sel_stage_entries(K) < 4096 ? 4096 : (sel_stage_entries(K) / 16) * 16;
+        if (S1 > 12288) S1 = 12288;
         if (S2 < S1) S2 = S1;
-        long long g2 = ((S2 + 15) / 16 + p.waves - 1) / p.waves;
-        if (g2 > NUM_CU) g2 = NUM_CU;
         // (one unfiltered scan of S2 rows was tried for small shards: its 32 k-entry selects cost more
         //  than the level-1 scan + select they replace)
         const bool two_level = S2 > S1;
         CoarseArgs c;
-        c.dbc = dbh_dev; c.rmeta = rmeta; c.qmeta = w.qmeta; c.q = qg; c.QA = qa; c.tauc = w.tauc;
+        c.dbc = dbh_dev; c.rmeta = rmeta; c.qmeta = w.qmeta; c.q = qg; c.QA = qa; c.tauc = w.tauc; c.row0 = 0;
         c.cand = w.cand_c; c.gcnt = w.gcnt_c; c.cap = COARSE_CAP; c.overflow = w.flag;
-        auto coarse_pass = [&](long long rows, float* thr_out, float* os, long long* oi, long long idb, hipEvent_t* ev,
-                               unsigned* m_out) -> int {
-            c.nrows = rows;
-            const long long nsteps = (rows + 31) / 32;
-            const bool pre = thr_out != nullptr;
+        // rows [r0, r1) of the copy through the coarse machinery: scan -> exact re-scoring of the survivors -> select.
+        // keep & 1: the K best so far stay at the head of the candidate lists (gcnt = K) and the next segment appends behind
+        // them, so no row is scanned twice; `pre` only picks the kernel NAME profilers average under.
+        auto coarse_pass = [&](long long r0, long long r1, bool pre, float* thr_out, float* os, long long* oi, long long idb,
+                               hipEvent_t* ev, unsigned* m_out, int keep) -> int {
+            c.row0 = r0;
+            c.nrows = r1 - r0;
+            const long long nsteps = (c.nrows + 31) / 32;
             int rc_;
             if (i8)
                 rc_ = qa <= 16 ? (pre ? launch_coarse<1, true, true>(c, nsteps, st, ev) : launch_coarse<1, false, true>(c, nsteps, st, ev))
@@ -1143,23 +1272,27 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
                     : qa <= 32 ? (pre ? launch_coarse<2, true, false>(c, nsteps, st, ev) : launch_coarse<2, false, false>(c, nsteps, st, ev))
                                : (pre ? launch_coarse<4, true, false>(c, nsteps, st, ev) : launch_coarse<4, false, false>(c, nsteps, st, ev));
             if (rc_) return rc_;
-            // ~2-3 k survivors per query = ~11 blocks of 256 pairs; a larger grid only queues idle blocks
+            // ~1-3 k survivors per query = ~11 blocks of 256 pairs; a larger grid only queues idle blocks
             hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(12, qa), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
                                static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, COARSE_CAP);
             CLIPMI_CHECK_LAUNCH("rescore_pairs_kernel");
             hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, w.cand_c, w.gcnt_c, COARSE_CAP, K,
-                               idb, os, oi, thr_out, (const unsigned*)nullptr, m_out);
+                               idb, os, oi, thr_out, (const unsigned*)nullptr, m_out, keep);
             CLIPMI_CHECK_LAUNCH("select_topk_kernel(coarse)");
             return 0;
         };
-        // level 1 (exact, S1 rows, no threshold): in sub-passes of <= 32 queries
-        for (int sub = 0; sub < qa; sub += p.QA) {
-            const int qs = (qa - sub) < p.QA ? (qa - sub) : p.QA;
-            a.q = qg + (size_t)sub * E; a.QA = qs; a.run_if = nullptr; a.thr_in = nullptr;
-            a.nrows = two_level ? S1 : S2;
-            if (int rc = launch_scan<true>(E, p.QG, a, two_level ? g1 : (int)g2, p.waves, p.lds_scan, st)) return rc;
-            hipLaunchKernelGGL(select_topk_kernel, dim3(qs), dim3(SEL_THREADS), p.lds_sel, st, w.cand_e, w.gcnt_e, p.cap, K,
-                               (long long)0, (float*)nullptr, (long long*)nullptr, (two_level ? w.tauc : w.thr0) + sub,
+        // level 1 (exact, unfiltered, all <= 64 queries in one launch): scores of the first rows -> K-th best per query
+        {
+            const long long rows1 = two_level ? S1 : S2;
+            const size_t lds1 = (size_t)4 * (512 / 16) * 1024;
+            if (int rc = opt_in_lds((const void*)sample_scores_kernel<512>, lds1)) return rc;
+            long long gs = ((rows1 + 15) / 16 + 3) / 4;
+            if (gs > NUM_CU) gs = NUM_CU;
+            hipLaunchKernelGGL(sample_scores_kernel<512>, dim3((unsigned)gs), dim3(256), lds1, st, static_cast<const float*>(db_dev),
+                               rows1, qg, qa, w.cand_c, (long long)COARSE_CAP, w.gcnt_c);
+            CLIPMI_CHECK_LAUNCH("sample_scores_kernel");
+            hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, w.cand_c, w.gcnt_c, COARSE_CAP, K,
+                               (long long)0, (float*)nullptr, (long long*)nullptr, two_level ? w.tauc : w.thr0,
                                (const unsigned*)nullptr);
             CLIPMI_CHECK_LAUNCH("select_topk_kernel(sample 1)");
         }
@@ -1174,14 +1307,30 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             CLIPMI_CHECK_LAUNCH("coarse_thresholds_kernel");
             return 0;
         };
+        // Segments of the copy, each scanned ONCE: [0, S2) (level 2 of the pre-pass, threshold from level 1), then
+        // [S2, N1) and [N1, N) with N1 ~ N/4. After every segment the exact K-th best of all rows seen so far is the
+        // next segment's threshold: the last 75 % of the rows are filtered by the K-th best of the first 25 % (about 100
+        // survivors per query at 10 M rows instead of 6 k with the level-2 threshold), which is what the exact re-scoring
+        // pass - a 2-KB row read per survivor - is paid for. One more segment would save ~25 us of re-scoring and cost
+        // ~55 us of launches.
+        float* os_final = out_score_dev + (size_t)q0 * K;
+        long long* oi_final = (long long*)out_id_dev + (size_t)q0 * K;
+        long long r_done = 0;
         if (two_level) {
             if (int rc = thresholds(w.tauc)) return rc;
-            if (int rc = coarse_pass(S2, w.thr0, nullptr, nullptr, 0, nullptr, nullptr)) return rc;
+            if (int rc = coarse_pass(0, S2, true, w.thr0, nullptr, nullptr, 0, scan_ev ? scan_ev + 2 : nullptr, w.last_m, 1)) return rc;
+            r_done = S2;
+            long long N1 = (N / 4) & ~31ll;
+            if (N1 < 4 * S2) N1 = 4 * S2;
+            if (N1 + 65536 <= N) {
+                if (int rc = thresholds(w.thr0)) return rc;
+                if (int rc = coarse_pass(r_done, N1, true, w.thr0, nullptr, nullptr, 0, scan_ev ? scan_ev + 4 : nullptr, w.last_m, 3)) return rc;
+                r_done = N1;
+            }
         }
-        // 2. coarse thresholds, 3. bf16 scan of all rows, 4. exact re-scoring, 5. select
+        // last segment: coarse thresholds from the latest bound, scan, exact re-scoring, select into the result
         if (int rc = thresholds(w.thr0)) return rc;
-        if (int rc = coarse_pass(N, nullptr, out_score_dev + (size_t)q0 * K, (long long*)out_id_dev + (size_t)q0 * K,
-                                 (long long)id_base, scan_ev, w.last_m))
+        if (int rc = coarse_pass(r_done, N, false, nullptr, os_final, oi_final, (long long)id_base, scan_ev, w.last_m, two_level ? 2 : 0))
             return rc;
         // 6. fallback: exact scan + select, exiting at once unless a coarse list overflowed
         for (int sub = 0; sub < qa; sub += p.QA) {
@@ -1258,22 +1407,26 @@ static int dbg_coarse_scan_ms(const void* db_dev, const void* db_bf16_dev, bool 
                               int64_t* out_id_dev, void* ws_dev, size_t ws_bytes, void* stream, int reps, float* scan_ms,
                               long long* survivors) {
     if (!scan_ms || reps < 1 || Q > COARSE_Q) return set_err(CLIPMI_EINVAL, "dbg_topk_coarse_scan_ms: bad arguments");
-    hipEvent_t ev[2];
-    if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess)
-        return set_err(CLIPMI_EHIP, "hipEventCreate");
+    // three event pairs: [0,1] the last segment, [2,3] rows [0, S2), [4,5] rows [S2, N1) of the coarse copy (see
+    // topk_ip_coarse_impl): together the launches that stream the copy ONCE; *scan_ms = their summed duration
+    hipEvent_t ev[6];
+    for (int i = 0; i < 6; ++i)
+        if (hipEventCreate(&ev[i]) != hipSuccess) return set_err(CLIPMI_EHIP, "hipEventCreate");
     double total = 0.0;
     int rc = 0;
     for (int i = 0; i < reps && rc == 0; ++i) {
+        for (int j = 0; j < 6; ++j) (void)hipEventRecord(ev[j], as_stream(stream));     // a skipped segment reads ~0
         rc = topk_ip_coarse_impl(db_dev, db_bf16_dev, i8, rmeta, amax, N, E, rmax, q_dev, Q, K, 0, out_score_dev, out_id_dev,
                                  ws_dev, ws_bytes, stream, ev);
         if (rc) break;
-        if (hipEventSynchronize(ev[1]) != hipSuccess) { rc = set_err(CLIPMI_EHIP, "hipEventSynchronize"); break; }
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
-        total += ms;
+        if (hipStreamSynchronize(as_stream(stream)) != hipSuccess) { rc = set_err(CLIPMI_EHIP, "hipStreamSynchronize"); break; }
+        for (int j = 0; j < 3; ++j) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[2 * j], ev[2 * j + 1]);
+            total += ms;
+        }
     }
-    (void)hipEventDestroy(ev[0]);
-    (void)hipEventDestroy(ev[1]);
+    for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ev[i]);
     if (rc == 0) *scan_ms = (float)(total / reps);
     if (rc == 0 && survivors) {       // rows that survived the coarse pass, summed over the Q queries of the last call
         Plan p;

@@ -75,7 +75,7 @@ class IndexFlatIP:
         self.id_base = 0         # global id of local row 0 (non-zero on shards)
         self._chunks = []
         self._db = None
-        self._ws = None
+        self._ws = {}            # workspace per HIP stream: searches in flight on different streams never share one
 
     # -- build side ---------------------------------------------------------------------------
     def train(self, x):
@@ -179,8 +179,12 @@ class IndexFlatIP:
         need = (L.clipmi_topk_ip_coarse_workspace_bytes if coarse else L.clipmi_topk_ip_workspace_bytes)(N, self.d, Q, K)
         if need == 0:
             raise _lib.ClipmiError("topk_ip: " + _lib.last_error())
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        # the workspace belongs to the stream the call is enqueued on (torch's current stream): two batches in flight on
+        # two streams each get their own, and the caching allocator hands a block back only to the stream that owned it
+        skey = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(skey)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[skey] = torch.empty(need, dtype=torch.uint8, device=self.device)
         if out is None:
             out_s = torch.empty((Q, K), dtype=torch.float32, device=self.device)
             out_i = torch.empty((Q, K), dtype=torch.int64, device=self.device)
@@ -188,18 +192,18 @@ class IndexFlatIP:
             out_s, out_i = out
         if coarse and self.coarse == "int8":
             rc = L.clipmi_topk_ip_coarse_i8(db.data_ptr(), db8.data_ptr(), meta.data_ptr(), amax, N, self.d, rmax, q.data_ptr(),
-                                            Q, K, self.id_base, out_s.data_ptr(), out_i.data_ptr(), self._ws.data_ptr(),
-                                            self._ws.numel(), _lib.stream_ptr(self.device))
+                                            Q, K, self.id_base, out_s.data_ptr(), out_i.data_ptr(), ws.data_ptr(),
+                                            ws.numel(), _lib.stream_ptr(self.device))
             _lib.check(rc, "clipmi_topk_ip_coarse_i8")
             return out_s, out_i
         if coarse:
             rc = L.clipmi_topk_ip_coarse(db.data_ptr(), dbh.data_ptr(), N, self.d, rmax, q.data_ptr(), Q, K, self.id_base,
-                                         out_s.data_ptr(), out_i.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                         out_s.data_ptr(), out_i.data_ptr(), ws.data_ptr(), ws.numel(),
                                          _lib.stream_ptr(self.device))
             _lib.check(rc, "clipmi_topk_ip_coarse")
             return out_s, out_i
         rc = L.clipmi_topk_ip(db.data_ptr(), _lib.F32, N, self.d, q.data_ptr(), Q, K, self.id_base,
-                              out_s.data_ptr(), out_i.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                              out_s.data_ptr(), out_i.data_ptr(), ws.data_ptr(), ws.numel(),
                               _lib.stream_ptr(self.device))
         _lib.check(rc, "clipmi_topk_ip")
         return out_s, out_i
@@ -248,7 +252,12 @@ class ShardedFlatIP:
 
     def _record(self, Q, K, device):
         """Per-rank packed record [scores f32 Q*K | pad | ids i64 Q*K] and the gather buffer, cached."""
-        key = (Q, K, str(device))
+        skey = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+        key = (Q, K, str(device), skey)
+        cache = self.__dict__.setdefault("_rec_cache", {})
+        if key in cache:
+            (self._rec, self._gath, self._rec_s, self._rec_i, self._out_s, self._out_i) = cache[key]
+            self._rec_key = key
         if getattr(self, "_rec_key", None) != key:
             ids_off = (Q * K * 4 + 7) // 8 * 8
             nbytes = ids_off + Q * K * 8
@@ -259,6 +268,7 @@ class ShardedFlatIP:
             self._out_s = torch.empty((Q, K), dtype=torch.float32, device=device)
             self._out_i = torch.empty((Q, K), dtype=torch.int64, device=device)
             self._rec_key = key
+            cache[key] = (self._rec, self._gath, self._rec_s, self._rec_i, self._out_s, self._out_i)
         return self._rec, self._gath, self._rec_s, self._rec_i
 
     def search_device(self, q, K):

@@ -45,17 +45,23 @@ class CLIP:
         self.visual = _Visual(self.dims["res"])
         self.context_length = self.dims["ctx"]
         self.embed_dim = self.dims["embed"]
-        self._ws = None
+        self._ws = {}                # workspace per (HIP stream, tower): concurrent encoders never share one
         self.max_batch = 1024        # images per kernel sequence; larger inputs are chunked
 
     def eval(self):
         return self
 
-    def _workspace(self, need):
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
-        return self._ws
+    def _workspace(self, need, stream_key, tower):
+        """One workspace per (stream, tower). A block that has to grow is dropped only after the stream that used it
+        has drained (a raw hipStream_t passed by the caller is unknown to torch's caching allocator, which would
+        otherwise hand the freed block to another tensor while kernels still write to it)."""
+        key = (stream_key, tower)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            if ws is not None:
+                torch.cuda.synchronize(self.device)
+            ws = self._ws[key] = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        return ws
 
     def _require_gpu(self, what):
         if self.device.type != "cuda":
@@ -87,7 +93,7 @@ class CLIP:
             need = L.clipmi_encode_image_workspace_bytes(self.vision, hi - lo)
             if need == 0:
                 raise _lib.ClipmiError("encode_image: " + _lib.last_error())
-            ws = self._workspace(need)
+            ws = self._workspace(need, sp.value, "vision")
             rc = L.clipmi_encode_image(self.vision, self._vblob.data_ptr(), image[lo:hi].data_ptr(),
                                        _DTYPES[image.dtype], hi - lo, out[lo:hi].data_ptr(), int(bool(normalize)),
                                        ws.data_ptr(), ws.numel(), sp)
@@ -110,7 +116,7 @@ class CLIP:
             need = L.clipmi_encode_text_workspace_bytes(self.text, hi - lo)
             if need == 0:
                 raise _lib.ClipmiError("encode_text: " + _lib.last_error())
-            ws = self._workspace(need)
+            ws = self._workspace(need, _lib.stream_ptr(self.device).value, "text")
             rc = L.clipmi_encode_text(self.text, self._tblob.data_ptr(), ids[lo:hi].data_ptr(), hi - lo,
                                       out[lo:hi].data_ptr(), int(bool(normalize)), ws.data_ptr(), ws.numel(),
                                       _lib.stream_ptr(self.device))

@@ -309,6 +309,61 @@ def test_coarse_prepass_threshold_useless(clipmi, gpu, topk_oracle, kind):
     assert (I >= 40000).all()
 
 
+def _anisotropic_rows(rng, n, d=512, strong=8, gain=6.0):
+    """Unit rows with a few dominant dimensions (real CLIP embeddings are not isotropic: a handful of components
+    carry much of the norm), so per-row int8 scales are set by those components and the rest quantise coarsely."""
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    x[:, :strong] *= np.float32(gain)
+    x[:, 0] += np.float32(2.0 * gain)                       # a common offset direction, as CLIP's mean embedding is
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize("kind", ["int8", "bf16"])
+def test_coarse_anisotropic_db_exact_and_survivors(clipmi, gpu, topk_oracle, kind):
+    """on an ANISOTROPIC database (8 dominant dimensions + a shared offset direction) the coarse
+    path must still return the oracle's bits; the test prints how many rows per query survive the coarse filter and
+    whether the exact fallback had to run (a list reaching its 2^18 capacity), next to the isotropic case."""
+    import ctypes as C
+    L = clipmi._lib.lib()
+    N, Q, K = 300_000, 64, 51
+    report = {}
+    for name, gen in (("isotropic", unit_rows), ("anisotropic", lambda r, n, d: _anisotropic_rows(r, n, d))):
+        rng = np.random.default_rng(4242)
+        db = gen(rng, N, 512)
+        q = gen(rng, Q, 512)
+        idx = clipmi.IndexFlatIP(512, device=gpu, coarse=kind)
+        idx.add(db)
+        D, I = idx.search(q, K)
+        Ds, Is = topk_oracle.topk(db, q, K)
+        _assert_exact(D, I, Ds, Is, f"{kind} {name}")
+        dbt = idx.matrix()
+        qd = torch.from_numpy(q).to(gpu)
+        os_ = torch.empty((Q, K), dtype=torch.float32, device=gpu)
+        oi_ = torch.empty((Q, K), dtype=torch.int64, device=gpu)
+        ws = torch.empty(L.clipmi_topk_ip_coarse_workspace_bytes(N, 512, Q, K), dtype=torch.uint8, device=gpu)
+        ms, surv = C.c_float(0), C.c_longlong(-1)
+        if kind == "int8":
+            db8, meta, amax, rmax = idx.matrix_i8()
+            rc = L.clipmi_dbg_topk_coarse_i8_scan_ms(dbt.data_ptr(), db8.data_ptr(), meta.data_ptr(), amax, N, 512, rmax,
+                                                     qd.data_ptr(), Q, K, os_.data_ptr(), oi_.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                     None, 1, C.byref(ms), C.byref(surv))
+        else:
+            dbh, rmax = idx.matrix_bf16()
+            rc = L.clipmi_dbg_topk_coarse_scan_ms(dbt.data_ptr(), dbh.data_ptr(), N, 512, rmax, qd.data_ptr(), Q, K,
+                                                  os_.data_ptr(), oi_.data_ptr(), ws.data_ptr(), ws.numel(), None, 1,
+                                                  C.byref(ms), C.byref(surv))
+        clipmi._lib.check(rc, "coarse scan hook")
+        torch.cuda.synchronize()
+        assert np.array_equal(oi_.cpu().numpy(), Is)
+        report[name] = surv.value / Q
+        # survivors counts every exactly re-scored pair of the call; a list that had reached its capacity (the only way
+        # into the exact fallback) would show up as >= 2^18 here
+        assert surv.value / Q < (1 << 18), f"{kind} {name}: coarse lists overflowed (fallback taken)"
+    print(f"{kind}: exactly re-scored rows per query (N={N}, K={K}): isotropic {report['isotropic']:.0f}, "
+          f"anisotropic {report['anisotropic']:.0f}; fallback not taken in either case")
+
+
 def test_quantize_rows_i8_matches_numpy(clipmi, gpu):
     """clipmi_quantize_rows_i8: scale = max|x| / 127, q = rint(x / scale) (round half to even), error norm >= the
     true one and within 0.2 % of it."""
