@@ -63,7 +63,15 @@ int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int 
     }
     const int nt = (L + 15) / 16;
     // development switch for A/B runs on one box: CLIPMI_ATTN52=0 keeps ViT-B/32 on attention_kernel<4>
-    static const bool use52 = [] { const char* e = getenv("CLIPMI_ATTN52"); return !e || atoi(e) != 0; }();
+    // (CLIPMI_ATTN52: 0 = attention_kernel<4>, 1 = attention52_kernel, default 2 = attention52x4_kernel)
+    static const int use52 = [] { const char* e = getenv("CLIPMI_ATTN52"); return e ? atoi(e) : 2; }();
+    if (L >= 49 && L <= 52 && !causal && tr == 1 && use52 == 2) {
+        // one workgroup per (image, head), one query tile per wave
+        const long long items = (long long)B * heads;
+        hipLaunchKernelGGL(attention52x4_kernel, dim3((unsigned)items), dim3(256), 64 * 128 + 52 * 128, st, qkv, out, B, L, heads);
+        CLIPMI_CHECK_LAUNCH("attention52x4_kernel");
+        return 0;
+    }
     if (L >= 49 && L <= 52 && !causal && tr && use52) {
         // ViT-B/32: the low-register form (24 waves per CU); tr = 0 keeps the plain-read reference kernel for tests
         const long long items = (long long)B * heads;
@@ -110,12 +118,13 @@ extern "C" int clipmi_dbg_layernorm(const float* x_dev, const float* w_dev, cons
     return launch_layernorm(a, as_stream(stream));
 }
 
-// `causal` bit 0 = causal mask; bit 1 = use the 2-byte LDS reads instead of ds_read_b64_tr_b16
+// `causal` bit 0 = causal mask; bit 1 = use the 2-byte LDS reads instead of ds_read_b64_tr_b16; bit 2 = the one-wave-
+// per-(image, head) form attention52_kernel where the default is attention52x4_kernel (49 <= L <= 52)
 extern "C" int clipmi_dbg_attention(const void* qkv_dev, void* out_dev, int B, int L, int heads, int causal,
                                     void* stream) {
     if (!qkv_dev || !out_dev) return set_err(CLIPMI_EINVAL, "dbg_attention: NULL pointer");
     return launch_attention(static_cast<const unsigned short*>(qkv_dev), static_cast<unsigned short*>(out_dev), B, L,
-                            heads, causal & 1, (causal & 2) ? 0 : 1, as_stream(stream));
+                            heads, causal & 1, (causal & 2) ? 0 : ((causal & 4) ? 2 : 1), as_stream(stream));
 }
 
 extern "C" int clipmi_dbg_quantize_rows_fp8(const void* in_bf16_dev, void* out_fp8_dev, float* scale_dev, int M, int K,

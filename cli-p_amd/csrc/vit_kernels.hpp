@@ -602,6 +602,134 @@ static __global__ void __launch_bounds__(256, 6) attention52_kernel(const unsign
 }
 
 // ---------------------------------------------------------------------------------------------
+// attention52x4_kernel: the ViT-B/32 attention (49 <= L <= 52, no mask) with ONE WORKGROUP per (image, head) and one
+// 16-query tile per wave. attention52_kernel gives a whole (image, head) to one wave: 17 dependent-latency global loads
+// in 64-byte pieces, then four query tiles one after the other - a wave lives ~20 us and the launch is bound by that
+// residency (65 us per layer at B = 870 = 4.1 TB/s). Here the four waves stage K (64 rows, 16-byte chunks XOR-swizzled by
+// row & 7 for conflict-free ds_read_b128 fragments) and V (52 rows, row-major for ds_read_b64_tr_b16) ONCE as whole
+// 128-byte head rows, <= 4 loads per lane, one barrier, and each wave then runs exactly one iteration of
+// attention52_kernel's query-tile loop: same MFMA sequence, same softmax: bit-identical output, a quarter of the serial
+// chain. 14.5 KiB of LDS per workgroup, 8 workgroups (32 waves) per CU.
+// ---------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256, 8) attention52x4_kernel(const unsigned short* __restrict__ qkv,
+                                                                      unsigned short* __restrict__ out, int B, int L,
+                                                                      int heads) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = 4, ROWS = 52;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int W = heads * 64;
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    const unsigned short* base = qkv + (size_t)b * L * 3 * W + h * 64;
+    const size_t rs = (size_t)3 * W;
+    char* kt_ = smem;                       // K: 64 rows x 128 B, swizzled
+    char* vt = smem + 64 * 128;             // V: 52 rows x 128 B
+
+    // ---- this wave's Q fragments first (longest consumer chain), then its share of the K / V staging loads
+    int qrow = wave * 16 + fr;
+    qrow = qrow < L ? qrow : L - 1;
+    const unsigned short* qp = base + (size_t)qrow * rs + fg * 8;
+    const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(qp);
+    const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+    uint4 kd[2], vd[2];
+    const int srow = lane >> 3, sch = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int row = (wave * 2 + i) * 8 + srow;                            // K rows 0..63
+        row = row < L ? row : L - 1;
+        kd[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * rs + W + sch * 8);
+        int vrow = (wave * 2 + i) * 8 + srow;                           // V rows 0..55 (52..55 dropped)
+        vrow = vrow < L ? vrow : L - 1;                                 // rows L..51: finite filler, weight 0
+        vd[i] = *reinterpret_cast<const uint4*>(base + (size_t)vrow * rs + 2 * W + sch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + srow;
+        *reinterpret_cast<uint4*>(kt_ + row * 128 + ((sch ^ (row & 7)) << 4)) = kd[i];
+        if (row < ROWS) *reinterpret_cast<uint4*>(vt + row * 128 + sch * 16) = vd[i];
+    }
+    __syncthreads();
+    if (wave * 16 >= L) return;             // (L >= 49: never; keeps the tail generic)
+
+    // K fragments of all four key tiles out of LDS: row t*16 + fr, logical chunks fg and 4 + fg
+    bf16x8 kf[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int row = t * 16 + fr;
+        kf[t][0] = *reinterpret_cast<const bf16x8*>(kt_ + row * 128 + (((0 + fg) ^ (row & 7)) << 4));
+        kf[t][1] = *reinterpret_cast<const bf16x8*>(kt_ + row * 128 + (((4 + fg) ^ (row & 7)) << 4));
+    }
+    const int k00 = 4 * fg + (fr >> 2);
+    const int krow[4] = {k00, k00 + 16, k00 + 32, (k00 + 48 < ROWS ? k00 + 48 : ROWS - 1)};
+    const char* vcol = vt + (4 * (fr & 3)) * 2;
+
+    f32x4 s[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], q0, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][1], q1, a, 0, 0, 0);
+        s[kt] = a;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ki = kt * 16 + 4 * fg + r;
+            float x = s[kt][r] * 0.125f;
+            if (ki >= L) x = -INFINITY;
+            s[kt][r] = x;
+            mx = fmaxf(mx, x);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = __expf(s[kt][r] - mx);             // key 0 is never masked: mx is finite
+            s[kt][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) s[kt] *= inv;
+
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const f32x4 lo = s[2 * ks], hi = s[2 * ks + 1];
+        const uint4 u = make_uint4(pack_bf16x2(lo.x, lo.y), pack_bf16x2(lo.z, lo.w), pack_bf16x2(hi.x, hi.y),
+                                   pack_bf16x2(hi.z, hi.w));
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, u);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(vcol + krow[2 * ks] * 128 + dt * 32));
+            const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(vcol + krow[2 * ks + 1] * 128 + dt * 32));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 t = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, t), pf, o[dt], 0, 0, 0);
+        }
+    }
+    const int qi = wave * 16 + fr;
+    if (qi < L) {
+        unsigned short* dst = out + ((size_t)b * L + qi) * W + h * 64 + 4 * fg;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<uint2*>(dst + dt * 16) = make_uint2(pack_bf16x2(o[dt].x, o[dt].y), pack_bf16x2(o[dt].z, o[dt].w));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Flash-style attention for long sequences (L > 80: ViT-B/16 L = 197, ViT-L/14 L = 257,
 // ViT-L/14@336 L = 577), head dim 64, no mask. A workgroup of WPB waves owns one (sequence, head) and
 // WPB consecutive 64-query blocks (one per wave); keys/values stream through in 64-key blocks that the

@@ -117,6 +117,27 @@ def test_attention(clipmi, gpu, B, L, heads, causal, no_tr):
     assert err <= 3 * (2.0 ** -8) * ref.abs().max().item(), f"err {err} scale {ref.abs().max().item()}"
 
 
+@pytest.mark.parametrize("B,L,heads", [(3, 50, 12), (257, 50, 12), (5, 49, 2), (2, 52, 3), (870, 50, 12)])
+def test_attention52_forms_are_bit_identical(clipmi, gpu, B, L, heads):
+    """The three kernels that can run ViT-B/32's attention (one workgroup per (image, head) with a query tile per wave =
+    the default; one wave per (image, head); the generic attention_kernel) perform the same arithmetic per
+    (query, key, d): identical bits."""
+    Lb = clipmi._lib.lib()
+    g = torch.Generator(device="cpu"); g.manual_seed(B * 31 + L)
+    W = heads * 64
+    qd = _bf16(torch.randn(B * L, 3 * W, generator=g) * 1.5).to(gpu)
+    outs = []
+    for flags in (0, 4):
+        out = torch.full((B * L, W), float("nan"), dtype=torch.bfloat16, device=gpu)
+        clipmi._lib.check(Lb.clipmi_dbg_attention(qd.data_ptr(), out.data_ptr(), B, L, heads, flags, None), "attn")
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1])
+    if B <= 257:
+        ref = _attn_ref(qd.cpu(), B, L, heads, 0)
+        assert (outs[0].float().cpu() - ref).abs().max().item() <= 3 * (2.0 ** -8) * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("B,L,heads", [(2, 197, 12), (1, 257, 16), (2, 577, 16), (3, 81, 2), (1, 128, 1), (1, 129, 3)])
 def test_attention_long_sequences(clipmi, gpu, B, L, heads):
     """Flash-style kernel (L > 80): online softmax over 64-key blocks, no mask."""

@@ -1,0 +1,10 @@
+#!/bin/bash
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$ROOT"; mkdir -p gpurun_out
+timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py tests/test_encode_gpu.py -q -m gpu -x > gpurun_out/r02i_test.log 2>&1; rc=$?
+tail -5 gpurun_out/r02i_test.log
+[ $rc -ne 0 ] && exit $rc
+for v in 1 2 1 2; do
+CLIPMI_ATTN52=$v timeout -k 10 300 python bench.py --quick --steps 30 --rows 1000000 > gpurun_out/r02i_bench_attn$v.json 2> gpurun_out/r02i_bench.err || { tail -5 gpurun_out/r02i_bench.err; exit 1; }
+python -c "import json; d=json.loads(open('gpurun_out/r02i_bench_attn$v.json').read().strip().splitlines()[-1]); print('ATTN52=$v', round(d['value']), d['ms_per_step'])"
+done
+bash tools/gpu_stats_quick.sh r02i --rows 1000000 2>&1 | grep -E "attention|gemm256p|cast_stats|ln_finish|patchify|layernorm"
