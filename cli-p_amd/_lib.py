@@ -24,7 +24,7 @@ SYMBOLS = [
     "clipmi_l2_normalize_rows", "clipmi_last_error", "clipmi_abi_version",
     "clipmi_dbg_gemm_bf16", "clipmi_dbg_layernorm", "clipmi_dbg_attention", "clipmi_dbg_topk_scan_ms",
     "clipmi_dbg_encode_image_probe_ms",
-    "clipmi_dbg_cast_stats", "clipmi_dbg_gemm_ln", "clipmi_dbg_gemm_resid_ln",
+    "clipmi_dbg_split_stats", "clipmi_dbg_gemm_ln", "clipmi_dbg_gemm_resid_ln",
 ]
 
 
@@ -110,12 +110,12 @@ def lib():
     L.clipmi_l2_normalize_rows.argtypes = [vp, i64, i32, vp]
     L.clipmi_dbg_gemm_bf16.restype = i32
     L.clipmi_dbg_gemm_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
-    L.clipmi_dbg_cast_stats.restype = i32
-    L.clipmi_dbg_cast_stats.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    L.clipmi_dbg_split_stats.restype = i32
+    L.clipmi_dbg_split_stats.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp]
     L.clipmi_dbg_gemm_ln.restype = i32
     L.clipmi_dbg_gemm_ln.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.clipmi_dbg_gemm_resid_ln.restype = i32
-    L.clipmi_dbg_gemm_resid_ln.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.clipmi_dbg_gemm_resid_ln.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.clipmi_dbg_layernorm.restype = i32
     L.clipmi_dbg_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     L.clipmi_dbg_attention.restype = i32

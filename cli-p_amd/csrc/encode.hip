@@ -21,9 +21,9 @@ struct Ws {
     int* rowidx;
     unsigned char* a8;        // weight_format 1: the current GEMM's A operand as e4m3 [B*L][<= 4W]
     float* a_scale;           //                  and its row scales [B*L]
-    unsigned short* xb;       // ln_fold: bf16(x * gamma) [B*L][W], the A operand of the LN-folded qkv / c_fc GEMMs
-    float* ln_stats;          //          (mean, rstd) per row [B*L][2]
-    float* ln_part;           //          per-tile partials of the persistent residual GEMM [B*L][W/256][2]
+    unsigned short* xhi;      // ln_fold: the residual stream kept split, x = hi + lo (bf16 [B*L][W] each, contiguous);
+    unsigned short* xlo;      //          hi is also the A operand of the LN-folded qkv / c_fc GEMMs
+    float* ln_part;           //          row statistics of x as per-256-column (sum, sum of squares) [B*L][W/256][2]
 };
 
 size_t carve(const clipmi_tower* t, int B, void* base, size_t cap, Ws* out) {
@@ -42,8 +42,8 @@ size_t carve(const clipmi_tower* t, int B, void* base, size_t cap, Ws* out) {
         w.a_scale = ar.take<float>(rows);
     }
     if (t->ln_fold) {
-        w.xb = ar.take<unsigned short>(rows * W);
-        w.ln_stats = ar.take<float>(rows * 2);
+        w.xhi = ar.take<unsigned short>(2 * rows * W);
+        w.xlo = w.xhi + rows * W;
         w.ln_part = ar.take<float>(rows * 2 * (W / 256));
     }
     if (out) *out = w;
@@ -101,36 +101,32 @@ int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int 
         return launch_gemm_algo(g, epi, 0, st, probe);
     };
     if (t->ln_fold) {
-        // LN-folded blocks (gemm.hpp): ln_1 / ln_2 never run as passes of their own. Invariant at the top of every
-        // layer: w.xb = bf16(x * ln_1.weight) and w.ln_stats = (mean, rstd) of x, left there by the previous layer's
-        // c_proj GEMM (layer 0: by one cast_stats pass over the embedded rows).
+        // LN-folded blocks (gemm.hpp): ln_1 / ln_2 never run as passes of their own and the residual stream lives split
+        // in (w.xhi, w.xlo) with its row statistics in w.ln_part; w.x (f32) is only the embedding stage's output and the
+        // scratch of residual GEMMs that run on a non-persistent kernel. lo_qkv_w / lo_fc_w hold W * diag(ln weight).
         auto lb_of = [&](int l) { return t->off_layers + (uint64_t)l * t->layer_stride; };
         auto ln_linear = [&](uint64_t w_off, uint64_t cb_off, uint64_t cs_off, int N, int epi) -> int {
             GemmArgs g{};
-            g.A = w.xb; g.W = at<unsigned short>(blob, w_off); g.bias = at<float>(blob, cb_off);
-            g.colsum = at<float>(blob, cs_off); g.ln_stats = w.ln_stats;
+            g.A = w.xhi; g.W = at<unsigned short>(blob, w_off); g.bias = at<float>(blob, cb_off);
+            g.colsum = at<float>(blob, cs_off); g.ln_part_in = w.ln_part;
             g.out = w.big; g.M = M; g.N = N; g.K = W;
             return launch_gemm_algo(g, epi, 0, st, probe);
         };
-        // residual GEMM that also prepares the NEXT LN-folded GEMM's inputs (gamma_off = that LayerNorm's weight)
-        auto resid_linear = [&](const unsigned short* A, int K, uint64_t w_off, uint64_t b_off, bool has_next, uint64_t gamma_off) -> int {
+        auto resid_linear = [&](const unsigned short* A, int K, uint64_t w_off, uint64_t b_off) -> int {
             GemmArgs g{};
             g.A = A; g.W = at<unsigned short>(blob, w_off); g.bias = at<float>(blob, b_off);
-            g.out = w.x; g.M = M; g.N = W; g.K = K;
-            if (!has_next) return launch_gemm_algo(g, EPI_BIAS_RESID_F32, 0, st, probe);
-            g.gamma = at<float>(blob, gamma_off); g.xb = w.xb; g.ln_part = w.ln_part; g.ln_stats_out = w.ln_stats;
+            g.M = M; g.N = W; g.K = K;
+            g.xhi = w.xhi; g.xlo = w.xlo; g.ln_part = w.ln_part; g.tmp_f32 = w.x;
             return launch_gemm_algo(g, EPI_BIAS_RESID_LN_F32, 0, st, probe);
         };
-        if (int rc = launch_cast_stats(w.x, at<float>(blob, lb_of(0) + t->lo_ln1_w), w.xb, w.ln_stats, M, W, st)) return rc;
+        if (int rc = launch_split_stats(w.x, false, w.xhi, w.xlo, w.ln_part, M, W, st)) return rc;
         for (int l = 0; l < t->layers; ++l) {
             const uint64_t lb = lb_of(l);
             if (int rc = ln_linear(lb + t->lo_qkv_w, lb + t->lo_qkv_cb, lb + t->lo_qkv_colsum, 3 * W, EPI_LN_BIAS_BF16)) return rc;
             if (int rc = launch_attention(w.big, w.h, B, L, t->heads, causal, 1, st)) return rc;
-            if (int rc = resid_linear(w.h, W, lb + t->lo_out_w, lb + t->lo_out_b, true, lb + t->lo_ln2_w)) return rc;
+            if (int rc = resid_linear(w.h, W, lb + t->lo_out_w, lb + t->lo_out_b)) return rc;
             if (int rc = ln_linear(lb + t->lo_fc_w, lb + t->lo_fc_cb, lb + t->lo_fc_colsum, 4 * W, EPI_LN_BIAS_QGELU_BF16)) return rc;
-            const bool more = l + 1 < t->layers;
-            if (int rc = resid_linear(w.big, 4 * W, lb + t->lo_proj_w, lb + t->lo_proj_b, more, more ? lb_of(l + 1) + t->lo_ln1_w : 0))
-                return rc;
+            if (int rc = resid_linear(w.big, 4 * W, lb + t->lo_proj_w, lb + t->lo_proj_b)) return rc;
         }
         return 0;
     }
@@ -154,8 +150,9 @@ int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int 
 // pooled rows -> final LayerNorm -> projection [E][W] -> f32 [B][E] (-> optional L2 normalise)
 int run_head(const clipmi_tower* t, const void* blob, const Ws& w, int B, const int* rowidx, long long row_step,
              float* out, int normalize, hipStream_t st) {
-    LnArgs ln{w.x, at<float>(blob, t->off_ln_post_w), at<float>(blob, t->off_ln_post_b), w.pooled, rowidx, row_step,
-              B, t->width, 1};
+    LnArgs ln{t->ln_fold ? nullptr : w.x, at<float>(blob, t->off_ln_post_w), at<float>(blob, t->off_ln_post_b), w.pooled, rowidx,
+              row_step, B, t->width, 1};
+    ln.xhi = w.xhi; ln.xlo = w.xlo;        // ln_fold: the residual stream is (hi, lo)
     if (int rc = launch_layernorm(ln, st)) return rc;
     GemmArgs g{};
     g.A = w.pooled; g.W = at<unsigned short>(blob, t->off_out_proj); g.bias = nullptr; g.out = out;

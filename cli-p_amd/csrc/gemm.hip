@@ -60,18 +60,21 @@ static int persist_mode() {
     return mode;
 }
 
-// LDS beyond the two K-tile buffers: bias[N]; a second [N] row for FP8 (w_scale) and the LN-folded forms (colsum /
-// gamma); the tile's 256 row values (FP8: a_scale, 1 KiB; LN consumer: (mean, rstd), 2 KiB)
-constexpr int g256p_lds(int epi, bool fp8, int N, int dbg) {
-    const bool two = fp8 || epi_is_ln(epi) || epi == EPI_BIAS_RESID_LN_F32;
-    return G256_LDS + N * 4 * (two ? 2 : 1) + (fp8 ? 1024 : epi_is_ln(epi) ? 2048 : 0) + ((dbg & 12) ? 2048 : 0);
+// LDS beyond the two K-tile buffers: bias[N]; a second [N] row for FP8 (w_scale) and the LN-folded consumers (colsum);
+// the tile's 256 row values (FP8: a_scale, 1 KiB; LN consumer: K/256 statistics pairs per row, + 8 B where the 4-pair
+// read of the last row runs past them)
+constexpr int g256p_lds(int epi, bool fp8, int N, int K, int dbg) {
+    const bool two = fp8 || epi_is_ln(epi);
+    const int nseg = K >> 8;
+    return G256_LDS + N * 4 * (two ? 2 : 1) + (fp8 ? 1024 : epi_is_ln(epi) ? 256 * nseg * 8 + (nseg < 4 ? 8 : 0) : 0) +
+           ((dbg & 12) ? 8192 + 2048 : 0);
 }
 
 template <int EPI, bool FP8 = false>
 static int launch_epi256p(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
     const int tiles = (g.N / 256) * ((g.M + 255) / 256);
     const int grid = tiles < NUM_CU ? tiles : NUM_CU;
-    const int lds = g256p_lds(EPI, FP8, g.N, g.dbg);
+    const int lds = g256p_lds(EPI, FP8, g.N, g.K, g.dbg);
     if (lds > LDS_BYTES) return set_err(CLIPMI_EUNSUPPORTED, "gemm256p: %d B of LDS for N=%d", lds, g.N);
     static thread_local int opted[64];
     if (!lds_opted(opted)) {
@@ -91,29 +94,26 @@ static int launch_epi256p(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
     return 0;
 }
 
-// The residual producer of the LN-folded layers (EPI_BIAS_RESID_LN_F32) must leave three things behind: the updated
-// f32 rows, xb = bf16(rows * gamma) and the rows' (mean, rstd) in g.ln_stats_out. The persistent kernel's storers write
-// xb and per-tile partials on their way out (then ln_finish_kernel folds the partials: 8 B per row and segment); every
-// other kernel runs the plain residual epilogue followed by cast_stats_kernel (one LayerNorm-sized pass). Both give the
-// same bits (canonical statistics, gemm.hpp).
-static int finish_resid_ln(const GemmArgs& g, bool fused, hipStream_t st) {
-    if (fused) return launch_ln_finish(g.ln_part, g.ln_stats_out, g.M, g.N, st);
-    return launch_cast_stats(static_cast<const float*>(g.out), g.gamma, g.xb, g.ln_stats_out, g.M, g.N, st);
-}
+// The residual producer of the LN-folded layers (EPI_BIAS_RESID_LN_F32) updates the split residual (xhi, xlo) and leaves
+// the new rows' statistics partials in g.ln_part. The persistent kernel's storers do all of it on their way out; every
+// other kernel writes acc + bias as f32 into g.tmp_f32 and split_stats_kernel (add form) does the rest in one
+// LayerNorm-sized pass. Both give the same bits (same adds in the same order, canonical statistics: gemm.hpp).
 
 // algo: 0 = choose by shape, 1 = force the 128x128 kernel, 2 = force the 256x256 kernel,
 //       3 = force the persistent 256x256 kernel
 int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmProbe* probe) {
-    if (epi_is_ln(epi) && (!g.ln_stats || !g.colsum || !g.bias))
-        return set_err(CLIPMI_EINVAL, "gemm: LN-folded epilogue %d needs ln_stats, colsum and bias", epi);
-    if (epi == EPI_BIAS_RESID_LN_F32 && (!g.xb || !g.gamma || !g.ln_part || !g.ln_stats_out || g.N % 256 != 0))
-        return set_err(CLIPMI_EINVAL, "gemm: EPI_BIAS_RESID_LN_F32 needs xb, gamma, ln_part, ln_stats_out and N %% 256 == 0");
+    if (epi_is_ln(epi) && (!g.ln_part_in || !g.colsum || !g.bias || g.K % 256 != 0 || g.K > 1024))
+        return set_err(CLIPMI_EINVAL, "gemm: LN-folded epilogue %d needs ln_part_in, colsum, bias and K %% 256 == 0, K <= 1024", epi);
+    if (epi == EPI_BIAS_RESID_LN_F32 &&
+        (!g.xhi || !g.xlo || !g.ln_part || !g.tmp_f32 || g.N % 256 != 0 || g.N > 1024 ||
+         (const char*)g.xlo < (const char*)g.xhi || (const char*)g.xlo - (const char*)g.xhi >= (1ll << 31) - (long long)256 * g.N * 2))
+        return set_err(CLIPMI_EINVAL, "gemm: EPI_BIAS_RESID_LN_F32 needs xhi <= xlo < xhi + 2 GiB, ln_part, tmp_f32 and N %% 256 == 0, N <= 1024");
     const bool ok256 = g.N % 256 == 0 && g.K % 64 == 0 && g.K >= 128;
     if (algo == 2 && !ok256) return set_err(CLIPMI_EINVAL, "gemm256: N=%d K=%d (need N %% 256 == 0, K %% 64 == 0, K >= 128)", g.N, g.K);
     const bool store_only = epi == EPI_BIAS_BF16 || epi == EPI_BIAS_QGELU_BF16 || epi == EPI_BIAS_RESID_F32 || epi_is_ln(epi) ||
                             epi == EPI_BIAS_RESID_LN_F32;
     const bool ok256p = ok256 && g.K % 128 == 0 && g.N <= G256P_MAX_N && store_only && g.K <= (1 << 20) &&
-                        g256p_lds(epi, false, g.N, g.dbg) <= LDS_BYTES;
+                        g256p_lds(epi, false, g.N, g.K, g.dbg) <= LDS_BYTES && (!epi_is_ln(epi) || (g.K % 256 == 0 && g.K <= 1024));
     if (algo == 3 && !ok256p)
         return set_err(CLIPMI_EINVAL, "gemm256p: M=%d N=%d K=%d epi=%d (need N %% 256 == 0, K %% 128 == 0, a store-only epilogue "
                        "and bias/colsum rows that fit LDS)", g.M, g.N, g.K, epi);
@@ -132,11 +132,17 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmP
         // tile's K-loop
         use256p = use256 && ok256p && tiles > NUM_CU && persist_mode() != 0;
     }
-    if (g.M < 1 || !g.A || !g.W || !g.out) return set_err(CLIPMI_EINVAL, "gemm: bad arguments");
+    if (g.M < 1 || !g.A || !g.W || (!g.out && epi != EPI_BIAS_RESID_LN_F32)) return set_err(CLIPMI_EINVAL, "gemm: bad arguments");
     if (epi == EPI_BIAS_RESID_LN_F32 && !use256p) {
-        // not the persistent kernel: plain residual epilogue, then the cast + statistics pass
-        if (int rc = use256 ? launch_epi256<EPI_BIAS_RESID_F32>(g, st, probe) : launch_gemm(g, EPI_BIAS_RESID_F32, st, probe)) return rc;
-        return finish_resid_ln(g, false, st);
+        // not the persistent kernel: acc + bias as f32 into the scratch rows, then the add + split + statistics pass
+        GemmArgs t = g;
+        t.out = g.tmp_f32;
+        GemmProbe* pr = (probe && probe->wants(EPI_BIAS_RESID_LN_F32)) ? probe : nullptr;
+        if (pr) pr->epi = EPI_F32;                       // the probe brackets the GEMM launch itself
+        const int rc = use256 ? launch_epi256<EPI_F32>(t, st, pr) : launch_gemm(t, EPI_F32, st, pr);
+        if (pr) pr->epi = EPI_BIAS_RESID_F32;
+        if (rc) return rc;
+        return launch_split_stats(g.tmp_f32, true, g.xhi, g.xlo, g.ln_part, g.M, g.N, st);
     }
     if (!use256) return launch_gemm(g, epi, st, probe);
     if (use256p) {
@@ -146,9 +152,7 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmP
             case EPI_BIAS_RESID_F32: return launch_epi256p<EPI_BIAS_RESID_F32>(g, st, probe);
             case EPI_LN_BIAS_BF16: return launch_epi256p<EPI_LN_BIAS_BF16>(g, st, probe);
             case EPI_LN_BIAS_QGELU_BF16: return launch_epi256p<EPI_LN_BIAS_QGELU_BF16>(g, st, probe);
-            case EPI_BIAS_RESID_LN_F32:
-                if (int rc = launch_epi256p<EPI_BIAS_RESID_LN_F32>(g, st, probe)) return rc;
-                return finish_resid_ln(g, true, st);
+            case EPI_BIAS_RESID_LN_F32: return launch_epi256p<EPI_BIAS_RESID_LN_F32>(g, st, probe);
         }
         return set_err(CLIPMI_EINVAL, "gemm256p: epilogue %d", epi);
     }
@@ -238,32 +242,33 @@ extern "C" int clipmi_dbg_gemm_bf16(const void* a_dev, const void* w_dev, const 
 }
 
 // Test hooks of the LN-folded layers (gemm.hpp). `epi` = EPI_LN_BIAS_BF16 (5) or EPI_LN_BIAS_QGELU_BF16 (6), bits 8-9
-// force a kernel as in clipmi_dbg_gemm_bf16.
-extern "C" int clipmi_dbg_gemm_ln(const void* xb_dev, const void* w_dev, const float* cb_dev, const float* colsum_dev,
-                                  const float* stats_dev, void* out_dev, int M, int N, int K, int epi, void* stream) {
+// force a kernel as in clipmi_dbg_gemm_bf16. part_dev: [M][K/256][2] statistics partials of the rows behind xhi.
+extern "C" int clipmi_dbg_gemm_ln(const void* xhi_dev, const void* wg_dev, const float* cb_dev, const float* colsum_dev,
+                                  const float* part_dev, void* out_dev, int M, int N, int K, int epi, void* stream) {
     const int algo = (epi >> 8) & 3;
     epi &= 0xff;
     if (!epi_is_ln(epi)) return set_err(CLIPMI_EINVAL, "dbg_gemm_ln: epi %d", epi);
     GemmArgs g{};
-    g.A = static_cast<const unsigned short*>(xb_dev);
-    g.W = static_cast<const unsigned short*>(w_dev);
-    g.bias = cb_dev; g.colsum = colsum_dev; g.ln_stats = stats_dev;
+    g.A = static_cast<const unsigned short*>(xhi_dev);
+    g.W = static_cast<const unsigned short*>(wg_dev);
+    g.bias = cb_dev; g.colsum = colsum_dev; g.ln_part_in = part_dev;
     g.out = out_dev;
     g.M = M; g.N = N; g.K = K;
     return launch_gemm_algo(g, epi, algo, as_stream(stream));
 }
 
-// x (f32 [M][N], in place) += a @ w^T + bias; xb = bf16(x * gamma); stats = (mean, rstd) of the new rows.
-// part_dev: [M][N/256][2] scratch. algo as in clipmi_dbg_gemm_bf16 (3 = the persistent kernel's fused store pass).
-extern "C" int clipmi_dbg_gemm_resid_ln(const void* a_dev, const void* w_dev, const float* bias_dev, float* x_dev,
-                                        const float* gamma_dev, void* xb_dev, float* part_dev, float* stats_dev, int M, int N,
-                                        int K, int algo, void* stream) {
+// (xhi, xlo) (split residual, bf16 [M][N] each, updated in place) += a @ w^T + bias; part = statistics partials of the
+// new rows [M][N/256][2]; tmp_dev: f32 [M][N] scratch. algo as in clipmi_dbg_gemm_bf16 (3 = the persistent kernel's fused
+// store pass; 1 / 2 = GEMM into tmp + split_stats_kernel).
+extern "C" int clipmi_dbg_gemm_resid_ln(const void* a_dev, const void* w_dev, const float* bias_dev, void* xhi_dev,
+                                        void* xlo_dev, float* part_dev, float* tmp_dev, int M, int N, int K, int algo,
+                                        void* stream) {
     GemmArgs g{};
     g.A = static_cast<const unsigned short*>(a_dev);
     g.W = static_cast<const unsigned short*>(w_dev);
     g.bias = bias_dev;
-    g.out = x_dev;
-    g.gamma = gamma_dev; g.xb = static_cast<unsigned short*>(xb_dev); g.ln_part = part_dev; g.ln_stats_out = stats_dev;
+    g.xhi = static_cast<unsigned short*>(xhi_dev); g.xlo = static_cast<unsigned short*>(xlo_dev);
+    g.ln_part = part_dev; g.tmp_f32 = tmp_dev;
     g.M = M; g.N = N; g.K = K;
     return launch_gemm_algo(g, EPI_BIAS_RESID_LN_F32, algo & 3, as_stream(stream));
 }

@@ -63,19 +63,23 @@ enum Epilogue {
     // LayerNorm folded into the GEMM that consumes it ("LN-folded" linear layers, see ln_fold below):
     EPI_LN_BIAS_BF16 = 5,        // out bf16 = rstd[m] * (acc - mean[m] * colsum[n]) + bias[n]
     EPI_LN_BIAS_QGELU_BF16 = 6,  // out bf16 = quick_gelu(the same)
-    EPI_BIAS_RESID_LN_F32 = 7    // EPI_BIAS_RESID_F32 + xb[m][n] = bf16(out[m][n] * gamma[n]) + row-statistics partials
+    EPI_BIAS_RESID_LN_F32 = 7    // split residual: (xhi, xlo) += acc + bias, + row-statistics partials of the new rows
 };
 
 // ---- LN-folded linear layers ---------------------------------------------------------------------------------
 // y = LayerNorm(x; gamma, beta) W^T + b, with mean / rstd the row statistics of x, equals
-//     y[m][n] = rstd[m] * ( sum_k (x[m][k] gamma[k]) W[n][k]  -  mean[m] * colsum[n] ) + cb[n]
-//     colsum[n] = sum_k gamma[k] W[n][k],   cb[n] = sum_k beta[k] W[n][k] + b[n]        (packed by weights.py)
-// so the GEMM can take A = xb = bf16(x * gamma) — written by the kernel that produced x (the residual GEMM's
-// store pass, EPI_BIAS_RESID_LN_F32) — and the stand-alone LayerNorm pass (read f32 x, write bf16 h: 200 MB per
-// launch at B = 870, 8.5 % of the r01 encode step) disappears. W stays the plain bf16 weight matrix.
+//     y[m][n] = rstd[m] * ( sum_k x[m][k] Wg[n][k]  -  mean[m] * colsum[n] ) + cb[n]
+//     Wg = W * diag(gamma) (stored bf16),  colsum[n] = sum_k Wg[n][k],  cb[n] = sum_k beta[k] W[n][k] + b[n]
+// (packed by weights.py). The residual stream is kept SPLIT: x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (two
+// bf16 arrays, 4 bytes per element as f32 was, ~2^-17 relative error per update), so `hi` is at once half of the
+// residual state and the A operand of the next LN-folded GEMM: the residual GEMM's store pass (EPI_BIAS_RESID_LN_F32)
+// reads hi + lo, adds, writes hi + lo and the row-statistics partials of the new rows, and neither the stand-alone
+// LayerNorm pass (read f32 x, write bf16 h: 200 MB per launch at B = 870, 8.5 % of the r01 encode step) nor a separate
+// bf16 copy of x exists.
 // Row statistics are CANONICAL so that every producer gives the same bits (batch-size invariance): per
 // 256-column segment a wave holds 4 consecutive columns per lane, lane sums in a fixed order, then a butterfly
-// over xor masks 32, 16, 8, 4, 2, 1; segments are combined left to right (ln_row_stats).
+// over xor masks 32, 16, 8, 4, 2, 1; the per-segment (sum, sum of squares) pairs ARE the stored format
+// (ln_part [M][K/256][2]) and consumers combine them left to right (ln_row_stats).
 constexpr float LN_EPS = 1e-5f;
 
 __device__ __forceinline__ float ln_lane_sum(f32x4 v) { return (v.x + v.y) + (v.z + v.w); }
@@ -93,8 +97,11 @@ __device__ __forceinline__ float ln_wave_sum(float v) {
 }
 // (mean, rstd) from per-segment (sum, sum of squares) partials, combined left to right
 __device__ __forceinline__ f32x2 ln_row_stats(const float* part, int nseg, int W) {
+    // nseg <= 4 (W <= 1024); static indices only: a runtime-indexed register array would go to scratch
     float s = part[0], q = part[1];
-    for (int j = 1; j < nseg; ++j) { s += part[2 * j]; q += part[2 * j + 1]; }
+    if (nseg > 1) { s += part[2]; q += part[3]; }
+    if (nseg > 2) { s += part[4]; q += part[5]; }
+    if (nseg > 3) { s += part[6]; q += part[7]; }
     const float inv = 1.0f / (float)W;
     const float mean = s * inv;
     float var = __builtin_fmaf(-mean, mean, q * inv);
@@ -109,6 +116,20 @@ __device__ __forceinline__ f32x4 ln_apply(f32x4 acc, float mean, float rstd, f32
     r.z = __builtin_fmaf(__builtin_fmaf(-mean, colsum.z, acc.z), rstd, cb.z);
     r.w = __builtin_fmaf(__builtin_fmaf(-mean, colsum.w, acc.w), rstd, cb.w);
     return r;
+}
+// split residual: f32 value -> (hi, lo) bf16 pairs for 4 columns, and back
+__device__ __forceinline__ f32x4 split_join(uint2 hi, uint2 lo) {
+    return f32x4{__uint_as_float(hi.x << 16) + __uint_as_float(lo.x << 16),
+                 __uint_as_float(hi.x & 0xffff0000u) + __uint_as_float(lo.x & 0xffff0000u),
+                 __uint_as_float(hi.y << 16) + __uint_as_float(lo.y << 16),
+                 __uint_as_float(hi.y & 0xffff0000u) + __uint_as_float(lo.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void split_make(f32x4 o, uint2& hi, uint2& lo) {
+    hi = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+    const f32x4 hf = {__uint_as_float(hi.x << 16), __uint_as_float(hi.x & 0xffff0000u), __uint_as_float(hi.y << 16),
+                      __uint_as_float(hi.y & 0xffff0000u)};
+    const f32x4 d = o - hf;
+    lo = make_uint2(pack_bf16x2(d.x, d.y), pack_bf16x2(d.z, d.w));
 }
 constexpr bool epi_is_ln(int e) { return e == EPI_LN_BIAS_BF16 || e == EPI_LN_BIAS_QGELU_BF16; }
 constexpr bool epi_is_qgelu(int e) { return e == EPI_BIAS_QGELU_BF16 || e == EPI_LN_BIAS_QGELU_BF16; }
@@ -127,14 +148,16 @@ struct GemmArgs {
     // FP8 path (gemm256f8.hpp): A and W point at e4m3 bytes; per-row / per-output-channel dequantisation scales
     const float* a_scale;      // [M]
     const float* w_scale;      // [N]
-    // LN-folded layers: consumers (EPI_LN_*) read ln_stats [M][2] = (mean, rstd) and colsum [N] (bias = cb);
-    // the producer (EPI_BIAS_RESID_LN_F32) writes xb [M][N] bf16 = bf16(out * gamma) and ln_part [M][N/256][2]
-    const float* ln_stats;
+    // LN-folded layers: consumers (EPI_LN_*) read ln_part_in [M][K/256][2] (per-segment sum / sum of squares of the
+    // f32 rows whose hi halves are A) and colsum [N] (bias = cb); the producer (EPI_BIAS_RESID_LN_F32) updates the
+    // split residual (xhi, xlo) [M][N] bf16 each, xlo - xhi < 2^31 bytes, and writes ln_part [M][N/256][2];
+    // tmp_f32 [M][N]: scratch for the producer's non-persistent form (GEMM into tmp, then resid_combine_kernel)
+    const float* ln_part_in;
     const float* colsum;
-    const float* gamma;        // [N]
-    unsigned short* xb;
+    unsigned short* xhi;
+    unsigned short* xlo;
     float* ln_part;
-    float* ln_stats_out;       // [M][2]: complete (mean, rstd) of the updated rows, whichever kernel ran
+    float* tmp_f32;
 };
 
 // Tile order shared by both GEMM kernels. (1) XCD split: hardware deals workgroups round-robin over
@@ -289,7 +312,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
             const int n = n0 + wn * 64 + nt * 16 + 4 * fg;
             f32x4 v;
             if (epi_is_ln(EPI)) {
-                const f32x2 st = *reinterpret_cast<const f32x2*>(g.ln_stats + 2 * orow);
+                const int nseg = g.K >> 8;
+                const f32x2 st = ln_row_stats(g.ln_part_in + orow * 2 * nseg, nseg, g.K);
                 v = ln_apply(acc[mt][nt], st.x, st.y, cs[nt], bz[nt]);
             } else {
                 v = acc[mt][nt] + bz[nt];
@@ -331,9 +355,9 @@ struct GemmProbe {
 int launch_gemm(const GemmArgs& g, int epi, hipStream_t st, GemmProbe* probe = nullptr);
 int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmProbe* probe = nullptr);
 int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st, int mx = 1);      // gemm256f8.hpp: e4m3 operands + scales
-// vit_kernels.hip: x f32 [M][W] -> xb = bf16(x * gamma) + (mean, rstd) per row (canonical statistics); and the fold
-// of the persistent residual GEMM's per-tile partials [M][W/256][2] into (mean, rstd)
-int launch_cast_stats(const float* x, const float* gamma, unsigned short* xb, float* stats, int M, int W, hipStream_t st);
-int launch_ln_finish(const float* part, float* stats, int M, int W, hipStream_t st);
+// vit_kernels.hip: f32 rows -> split residual (hi, lo) + canonical statistics partials [M][W/256][2]; with `add`
+// (the non-persistent form of EPI_BIAS_RESID_LN_F32) the rows are add[m][:] + (hi + lo)[m][:], updated in place
+int launch_split_stats(const float* x_or_add, bool add, unsigned short* xhi, unsigned short* xlo, float* part, int M, int W,
+                       hipStream_t st);
 
 }  // namespace clipmi

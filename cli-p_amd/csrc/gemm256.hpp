@@ -212,7 +212,8 @@ __global__ void __launch_bounds__(512, 2) gemm256_bf16_nt_kernel(GemmArgs g) {
             f32x2 st = {0.f, 1.f};
             if (epi_is_ln(EPI)) {
                 const int m = m0 + row;
-                st = *reinterpret_cast<const f32x2*>(g.ln_stats + 2 * (size_t)(m < g.M ? m : g.M - 1));
+                const int nseg = g.K >> 8;
+                st = ln_row_stats(g.ln_part_in + (size_t)(m < g.M ? m : g.M - 1) * 2 * nseg, nseg, g.K);
             }
 #pragma unroll
             for (int b = 0; b < 2; ++b)

@@ -123,11 +123,19 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     __amdgpu_buffer_rsrc_t rsO;
     int last_lr = 0;
     auto set_out = [&](int mm, int nn) {
-        if constexpr (RESID) {
+        if constexpr (RLN) {
+            // split residual: one descriptor based at the tile's first hi row covers hi and lo (xlo - xhi < 2^31 bytes)
+            rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(g.xhi + (size_t)mm * g.N + nn), 0, 0x7fffffff, 0x00020000);
+            last_lr = g.M - 1 - mm;
+        } else if constexpr (RESID) {
             rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<float*>(g.out) + (size_t)mm * g.N + nn), 0, 0x7fffffff, 0x00020000);
             last_lr = g.M - 1 - mm;
         }
     };
+    // RLN: a 1-KiB piece = [256 hi values | 256 lo values] of one row: lanes 0-31 fetch hi, lanes 32-63 lo
+    const unsigned resid_lane_off = RLN ? (unsigned)(lane & 31) * 16u + (unsigned)(lane >> 5) * (unsigned)((const char*)g.xlo - (const char*)g.xhi)
+                                        : (unsigned)lane * 16u;
+    const unsigned resid_row_bytes = (unsigned)g.N * (RLN ? 2u : 4u);
 #define P_ISSUE_RESID(H, rbase)                                                                                       \
     do {                                                                                                              \
         if (loader) {                                                                                                 \
@@ -136,8 +144,8 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
                 int lr_ = (rbase) + wn * 4 + i_;                                                                      \
                 lr_ = lr_ < last_lr ? lr_ : last_lr;                                                                  \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, d_ + i_ * 1024, 16, (unsigned)lane * 16u,               \
-                                                         (unsigned)lr_ * (unsigned)g.N * 4u, 0, 0);                   \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, d_ + i_ * 1024, 16, resid_lane_off,                     \
+                                                         (unsigned)lr_ * resid_row_bytes, 0, 0);                      \
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
@@ -253,17 +261,17 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     P_ISSUE(1, 0, 0);
     float* sbias = reinterpret_cast<float*>(smem + G256_LDS);
     for (int i = tid; i < g.N; i += 512) sbias[i] = g.bias ? g.bias[i] : 0.f;
-    float* sws = sbias + g.N;                          // FP8: per-output-channel weight scales [N]; LNC: colsum[N]; RLN: gamma[N]
-    float* sas = sws + g.N;                            // FP8: the current tile's 256 activation-row scales; LNC: 256 x (mean, rstd)
+    float* sws = sbias + g.N;                          // FP8: per-output-channel weight scales [N]; LNC: colsum[N]
+    float* sas = sws + ((FP8 || LNC) ? g.N : 0);       // FP8: the current tile's 256 activation-row scales;
+                                                       // LNC: its 256 x nseg (sum, sum of squares) statistics partials
     if (FP8)
         for (int i = tid; i < g.N; i += 512) sws[i] = g.w_scale[i];
     if (LNC)
         for (int i = tid; i < g.N; i += 512) sws[i] = g.colsum[i];
-    if (RLN)
-        for (int i = tid; i < g.N; i += 512) sws[i] = g.gamma[i];
+    const int nseg_in = K >> 8;                        // LNC: 256-column segments of the rows A came from
     __amdgpu_buffer_rsrc_t rsS;
     if (FP8) rsS = __builtin_amdgcn_make_buffer_rsrc((void*)g.a_scale, 0, (unsigned)g.M * 4u, 0x00020000);
-    if (LNC) rsS = __builtin_amdgcn_make_buffer_rsrc((void*)g.ln_stats, 0, (unsigned)g.M * 8u, 0x00020000);
+    if (LNC) rsS = __builtin_amdgcn_make_buffer_rsrc((void*)g.ln_part_in, 0, (unsigned)g.M * (unsigned)nseg_in * 8u, 0x00020000);
     // (the compiler's wait for these loads also retires the loaders' DMA above; harmless, once per launch.
     //  The tile-start barrier below publishes sbias: every wave reaches it after its ds_write + lgkmcnt(0).)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -273,7 +281,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     unsigned short* const outp = static_cast<unsigned short*>(g.out);
 
     // development stamps (dbg & 4): [wave][tile][stamp] 100 MHz wall-clock ticks in LDS, dumped at the end
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + G256_LDS + g.N * 4 * ((FP8 || LNC || RLN) ? 2 : 1) + (FP8 ? 1024 : LNC ? 2048 : 0));
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + G256_LDS + g.N * 4 * ((FP8 || LNC) ? 2 : 1) + (FP8 ? 1024 : LNC ? 8192 : 0));
     int tile_i = 0;
     unsigned long long kst[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define P_STAMP(k)                                                                                   \
@@ -319,14 +327,14 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) char*)sas, 16,
                                                              (unsigned)m0 * 4u + lo_ * 16u, 0, 0, 0);
                 }
-                if (LNC && wave == 0) {                // (mean, rstd)[m0 .. m0+255] -> sas: two 1-KiB pieces (rows past M read
-                    // as (0, 0): never stored); older than this K-tile's prefetch: retired by its P3 wait
+                if (LNC && wave == 0) {                // statistics partials of rows m0 .. m0+255 -> sas: 2 nseg 1-KiB pieces
+                    // (rows past M read as zeros: never stored); older than this K-tile's prefetch: retired by its waits
                     unsigned lo_;
                     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo_));
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) char*)sas, 16,
-                                                             (unsigned)m0 * 8u + lo_ * 16u, 0, 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) char*)sas + 1024, 16,
-                                                             (unsigned)m0 * 8u + 1024u + lo_ * 16u, 0, 0, 0);
+                    const unsigned src0 = (unsigned)m0 * (unsigned)nseg_in * 8u + lo_ * 16u;
+                    for (int pc = 0; pc < 2 * nseg_in; ++pc)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) char*)sas + pc * 1024, 16,
+                                                                 src0, (unsigned)pc * 1024u, 0, 0);
                 }
             }
             P_KTILE(cur, 1, ktn, nb, 8, 8, 8);
@@ -339,6 +347,38 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
         if (wm == 0) __builtin_amdgcn_s_barrier();     // balance the stagger; all reads of buffer 1 are done
 
         // ---- epilogue through buffer 1: two passes of 128 rows x 512 B
+        f32x2 lst[2][4];         // LNC: (mean, rstd) of the lane's 8 accumulator rows
+        if constexpr (LNC) {
+            // The tile's statistics partials (256 rows x nseg (sum, sumsq) pairs, DMA'd under the last K-tile) are folded
+            // IN PLACE into 256 (mean, rstd) pairs by threads 0..255, one row each: read, barrier, write, barrier. Doing
+            // the fold per lane for its 8 rows costs 16-32 registers of pairs beside the 128 accumulators and pushed the
+            // storers' store addresses into scratch (a reload = vmcnt(0) = every store so far). asm accesses throughout
+            // (a compiler-visible access to an LDS-DMA destination waits vmcnt(0)); always 4 pairs are read: for nseg < 4
+            // the extra ones belong to the next row and are ignored.
+            const unsigned sas_ = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sas;
+            f32x2 mr = {0.f, 0.f};
+            if (tid < 256) {
+                f32x2 p0, p1, p2, p3;
+                const unsigned ra_ = sas_ + (unsigned)tid * (unsigned)nseg_in * 8u;
+                asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\t"
+                             "ds_read_b64 %3, %4 offset:24\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3) : "v"(ra_) : "memory");
+                const float pp[8] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
+                mr = ln_row_stats(pp, nseg_in, K);
+            }
+            __builtin_amdgcn_s_barrier();
+            if (tid < 256) asm volatile("ds_write_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(sas_ + (unsigned)tid * 8u), "v"(mr) : "memory");
+            __builtin_amdgcn_s_barrier();
+            const unsigned sa_ = sas_ + (wm * 64 + fr) * 8;
+            asm volatile(
+                "ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:128\n\tds_read_b64 %2, %8 offset:256\n\tds_read_b64 %3, %8 offset:384\n\t"
+                "ds_read_b64 %4, %8 offset:1024\n\tds_read_b64 %5, %8 offset:1152\n\tds_read_b64 %6, %8 offset:1280\n\t"
+                "ds_read_b64 %7, %8 offset:1408\n\ts_waitcnt lgkmcnt(0)"
+                : "=&v"(lst[0][0]), "=&v"(lst[0][1]), "=&v"(lst[0][2]), "=&v"(lst[0][3]), "=&v"(lst[1][0]), "=&v"(lst[1][1]),
+                  "=&v"(lst[1][2]), "=&v"(lst[1][3])
+                : "v"(sa_)
+                : "memory");
+        }
         f32x4 bz[2][2];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -365,22 +405,12 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                 : "v"(sa_)
                 : "memory");
         }
-        f32x2 lst[2][4];         // LNC: (mean, rstd) of the lane's 8 accumulator rows
         if constexpr (LNC) {
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
                     wsv[b][nt] = *reinterpret_cast<const f32x4*>(sws + n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg);
-            const unsigned sa_ = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sas + (wm * 64 + fr) * 8;
-            asm volatile(
-                "ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:128\n\tds_read_b64 %2, %8 offset:256\n\tds_read_b64 %3, %8 offset:384\n\t"
-                "ds_read_b64 %4, %8 offset:1024\n\tds_read_b64 %5, %8 offset:1152\n\tds_read_b64 %6, %8 offset:1280\n\t"
-                "ds_read_b64 %7, %8 offset:1408\n\ts_waitcnt lgkmcnt(0)"
-                : "=&v"(lst[0][0]), "=&v"(lst[0][1]), "=&v"(lst[0][2]), "=&v"(lst[0][3]), "=&v"(lst[1][0]), "=&v"(lst[1][1]),
-                  "=&v"(lst[1][2]), "=&v"(lst[1][3])
-                : "v"(sa_)
-                : "memory");
         }
         // bias (and the FP8 scales / the LN-folded correction) are folded into the accumulators in place, before the
         // staging passes: the per-column / per-row factors are dead by the time the passes need registers for their LDS traffic
@@ -418,13 +448,6 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
             for (int nt = 0; nt < 2; ++nt)
                 stage_addr[nt] = img_base + fr * 1024 + (wn >> 1) * 256 + (((((wn & 1) * 8 + nt * 4 + fg) ^ fr)) << 4);
             float* const outf = static_cast<float*>(g.out);
-            f32x4 gam = {1.f, 1.f, 1.f, 1.f};
-            if constexpr (RLN) {
-                // storers' columns n0 + 4 lane ..; asm read: a compiler-visible LDS read that the compiler sinks into the
-                // storer blocks would drag a vmcnt(0) (= every store so far) in with it
-                const unsigned ga_ = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sws + (unsigned)(n0 + lane * 4) * 4u;
-                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(gam) : "v"(ga_) : "memory");
-            }
             const int nseg = g.N >> 8, seg = n0 >> 8;
             P_ISSUE_RESID(4, 32);                          // sub-pass 2 (tile rows 32..63) -> Z
             P_ISSUE_RESID(5, 48);
@@ -480,33 +503,40 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                                 *reinterpret_cast<f32x4*>(outf + (size_t)m * g.N + n0 + lane * 4) = xs[i] + rs[i];
                         }
                     } else {
-                        // new residual rows o_i; beside the f32 store: xb = bf16(o * gamma) (the next LN-folded GEMM's A
-                        // operand) and this tile's share of the row statistics (canonical order, gemm.hpp). Two groups of
-                        // four rows (8 reads in flight each): sixteen row registers fewer than the plain form, which is
-                        // what keeps this variant out of scratch (a reload costs a storer a vmcnt(0) = all its stores).
+                        // split residual (gemm.hpp): old rows = hi + lo from the DMA'd pieces ([256 hi | 256 lo] per row),
+                        // new rows o = (acc + bias) + old -> hi' = bf16(o), lo' = bf16(o - hi'), and this tile's share of the
+                        // row statistics (canonical order). Two groups of four rows (12 reads in flight each): fewer live
+                        // row registers than the plain form, which keeps this variant out of scratch (a reload costs a
+                        // storer a vmcnt(0) = all its stores).
+                        const unsigned ra2 = ra - lane * 8;                      // + lane * 8 instead of lane * 16
 #pragma unroll
                         for (int hgrp = 0; hgrp < 2; ++hgrp) {
-                            f32x4 x0, x1, x2, x3, r0, r1, r2, r3;
-                            const unsigned rb = ra + hgrp * 4096;
+                            f32x4 x0, x1, x2, x3;
+                            uint2 h0, h1, h2, h3, l0, l1, l2, l3;
+                            const unsigned rb = ra2 + hgrp * 4096;
                             asm volatile(
-                                "ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
-                                "ds_read_b128 %4, %12\n\tds_read_b128 %5, %12 offset:1024\n\tds_read_b128 %6, %12 offset:2048\n\t"
-                                "ds_read_b128 %7, %12 offset:3072\n\ts_waitcnt lgkmcnt(0)"
-                                : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                                "ds_read_b128 %0, %12\n\tds_read_b128 %1, %13\n\tds_read_b128 %2, %14\n\tds_read_b128 %3, %15\n\t"
+                                "ds_read_b64 %4, %16\n\tds_read_b64 %5, %16 offset:1024\n\tds_read_b64 %6, %16 offset:2048\n\t"
+                                "ds_read_b64 %7, %16 offset:3072\n\t"
+                                "ds_read_b64 %8, %16 offset:512\n\tds_read_b64 %9, %16 offset:1536\n\tds_read_b64 %10, %16 offset:2560\n\t"
+                                "ds_read_b64 %11, %16 offset:3584\n\ts_waitcnt lgkmcnt(0)"
+                                : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3),
+                                  "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
                                 : "v"(aa[4 * hgrp]), "v"(aa[4 * hgrp + 1]), "v"(aa[4 * hgrp + 2]), "v"(aa[4 * hgrp + 3]), "v"(rb)
                                 : "memory");
                             const f32x4 xs[4] = {x0, x1, x2, x3};
-                            const f32x4 rs[4] = {r0, r1, r2, r3};
+                            const uint2 hs[4] = {h0, h1, h2, h3};
+                            const uint2 ls[4] = {l0, l1, l2, l3};
 #pragma unroll
                             for (int i4 = 0; i4 < 4; ++i4) {
                                 const int i = 4 * hgrp + i4;
-                                const f32x4 o = xs[i4] + rs[i4];
+                                const f32x4 o = xs[i4] + split_join(hs[i4], ls[i4]);
                                 const int m = m0 + lr0 + i;
                                 if (m < g.M && !(g.dbg & 1)) {
-                                    *reinterpret_cast<f32x4*>(outf + (size_t)m * g.N + n0 + lane * 4) = o;
-                                    const f32x4 og = o * gam;
-                                    *reinterpret_cast<uint2*>(g.xb + (size_t)m * g.N + n0 + lane * 4) =
-                                        make_uint2(pack_bf16x2(og.x, og.y), pack_bf16x2(og.z, og.w));
+                                    uint2 nh, nl;
+                                    split_make(o, nh, nl);
+                                    *reinterpret_cast<uint2*>(g.xhi + (size_t)m * g.N + n0 + lane * 4) = nh;
+                                    *reinterpret_cast<uint2*>(g.xlo + (size_t)m * g.N + n0 + lane * 4) = nl;
                                 }
                                 sa[i] = ln_lane_sum(o);
                                 sq[i] = ln_lane_sumsq(o);

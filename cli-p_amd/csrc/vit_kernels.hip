@@ -12,20 +12,14 @@ int launch_layernorm(const LnArgs& a, hipStream_t st) {
     return 0;
 }
 
-int launch_cast_stats(const float* x, const float* gamma, unsigned short* xb, float* stats, int M, int W, hipStream_t st) {
+int launch_split_stats(const float* x_or_add, bool add, unsigned short* xhi, unsigned short* xlo, float* part, int M, int W,
+                       hipStream_t st) {
     if (M < 1) return 0;
-    if (!x || !gamma || !xb || !stats || W % 256 != 0 || W < 256 || W > 1024)
-        return set_err(CLIPMI_EINVAL, "cast_stats: W=%d (need W %% 256 == 0, 256 <= W <= 1024)", W);
-    hipLaunchKernelGGL(cast_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, gamma, xb, stats, M, W);
-    CLIPMI_CHECK_LAUNCH("cast_stats_kernel");
-    return 0;
-}
-
-int launch_ln_finish(const float* part, float* stats, int M, int W, hipStream_t st) {
-    if (M < 1) return 0;
-    if (!part || !stats || W % 256 != 0 || W < 256 || W > 1024) return set_err(CLIPMI_EINVAL, "ln_finish: W=%d", W);
-    hipLaunchKernelGGL(ln_finish_kernel, dim3((M + 255) / 256), dim3(256), 0, st, part, stats, M, W);
-    CLIPMI_CHECK_LAUNCH("ln_finish_kernel");
+    if (!x_or_add || !xhi || !xlo || !part || W % 256 != 0 || W < 256 || W > 1024)
+        return set_err(CLIPMI_EINVAL, "split_stats: W=%d (need W %% 256 == 0, 256 <= W <= 1024)", W);
+    if (add) hipLaunchKernelGGL(split_stats_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x_or_add, xhi, xlo, part, M, W);
+    else hipLaunchKernelGGL(split_stats_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x_or_add, xhi, xlo, part, M, W);
+    CLIPMI_CHECK_LAUNCH("split_stats_kernel");
     return 0;
 }
 
@@ -133,7 +127,8 @@ extern "C" int clipmi_dbg_quantize_rows_fp8(const void* in_bf16_dev, void* out_f
                                     scale_dev, M, K, as_stream(stream));
 }
 
-extern "C" int clipmi_dbg_cast_stats(const float* x_dev, const float* gamma_dev, void* xb_dev, float* stats_dev, int M, int W,
-                                     void* stream) {
-    return launch_cast_stats(x_dev, gamma_dev, static_cast<unsigned short*>(xb_dev), stats_dev, M, W, as_stream(stream));
+extern "C" int clipmi_dbg_split_stats(const float* x_dev, int add, void* xhi_dev, void* xlo_dev, float* part_dev, int M, int W,
+                                      void* stream) {
+    return launch_split_stats(x_dev, add != 0, static_cast<unsigned short*>(xhi_dev), static_cast<unsigned short*>(xlo_dev),
+                              part_dev, M, W, as_stream(stream));
 }

@@ -138,6 +138,9 @@ struct LnArgs {
     // quantize_rows_fp8_kernel would make of the bf16 row (the values are rounded to bf16 first)
     unsigned char* out8;
     float* scale8;
+    // split-residual input (gemm.hpp): when x == nullptr the source rows are xhi + xlo (bf16 each)
+    const unsigned short* xhi;
+    const unsigned short* xlo;
 };
 
 static __global__ void __launch_bounds__(256) layernorm_kernel(LnArgs a) {
@@ -152,7 +155,11 @@ static __global__ void __launch_bounds__(256) layernorm_kernel(LnArgs a) {
     for (int i = 0; i < 4; ++i) {
         const int c = i * 256 + lane * 4;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (c < a.W) v[i] = *reinterpret_cast<const f32x4*>(p + c);
+        if (c < a.W) {
+            if (a.x) v[i] = *reinterpret_cast<const f32x4*>(p + c);
+            else v[i] = split_join(*reinterpret_cast<const uint2*>(a.xhi + src_row * a.W + c),
+                                   *reinterpret_cast<const uint2*>(a.xlo + src_row * a.W + c));
+        }
         s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
 #pragma unroll
@@ -219,50 +226,36 @@ static __global__ void __launch_bounds__(256) layernorm_kernel(LnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// LN-folded layers (gemm.hpp): the stand-alone producer of a GEMM's A operand and row statistics,
-//   xb[m][:] = bf16(x[m][:] * gamma),  stats[m] = (mean, rstd) of x[m][:]
-// used where the residual GEMM's own store pass cannot do it (ln_pre's output, non-persistent residual
-// GEMMs). One wave per row, W % 256 == 0, W <= 1024; statistics in the canonical order (same bits as the
-// persistent GEMM's storers + ln_finish_kernel).
+// LN-folded layers (gemm.hpp): the stand-alone producer of the split residual and its row statistics,
+//   rows = ADD ? add[m][:] + (hi + lo)[m][:] : x[m][:];   hi = bf16(rows), lo = bf16(rows - hi),
+//   part[m][j] = (sum, sum of squares) of columns 256 j .. 256 j + 255
+// used where the persistent residual GEMM's own store pass is not available (the embedded rows after ln_pre; residual
+// GEMMs that run on the non-persistent kernels, whose acc + bias arrive as f32 in `add`). One wave per row,
+// W % 256 == 0, W <= 1024; statistics in the canonical order (same bits as gemm256p's storers).
 // ---------------------------------------------------------------------------------------------
-static __global__ void __launch_bounds__(256) cast_stats_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                                unsigned short* __restrict__ xb, float* __restrict__ stats,
-                                                                int M, int W) {
+template <bool ADD>
+static __global__ void __launch_bounds__(256) split_stats_kernel(const float* __restrict__ x, unsigned short* xhi,
+                                                                 unsigned short* xlo, float* __restrict__ part, int M, int W) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
     const int nseg = W >> 8;
     const float* p = x + (size_t)r * W;
-    f32x4 v[4];
-    float part[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (j < nseg) {
-            v[j] = *reinterpret_cast<const f32x4*>(p + j * 256 + lane * 4);
-            part[2 * j] = ln_wave_sum(ln_lane_sum(v[j]));
-            part[2 * j + 1] = ln_wave_sum(ln_lane_sumsq(v[j]));
+            const size_t at_ = (size_t)r * W + j * 256 + lane * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(p + j * 256 + lane * 4);
+            if (ADD) v = v + split_join(*reinterpret_cast<const uint2*>(xhi + at_), *reinterpret_cast<const uint2*>(xlo + at_));
+            uint2 nh, nl;
+            split_make(v, nh, nl);
+            *reinterpret_cast<uint2*>(xhi + at_) = nh;
+            *reinterpret_cast<uint2*>(xlo + at_) = nl;
+            const float sa = ln_wave_sum(ln_lane_sum(v));
+            const float sq = ln_wave_sum(ln_lane_sumsq(v));
+            if (lane == 0) *reinterpret_cast<f32x2*>(part + ((size_t)r * nseg + j) * 2) = f32x2{sa, sq};
         }
     }
-    const f32x2 st = ln_row_stats(part, nseg, W);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (j < nseg) {
-            const f32x4 y = v[j] * *reinterpret_cast<const f32x4*>(gamma + j * 256 + lane * 4);
-            *reinterpret_cast<uint2*>(xb + (size_t)r * W + j * 256 + lane * 4) =
-                make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
-        }
-    }
-    if (lane == 0) *reinterpret_cast<f32x2*>(stats + 2 * (size_t)r) = st;
-}
-
-// part [M][W/256][2] (sum, sum of squares per 256-column tile, written by gemm256p's residual storers) -> stats [M][2]
-static __global__ void __launch_bounds__(256) ln_finish_kernel(const float* __restrict__ part, float* __restrict__ stats, int M, int W) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= M) return;
-    const int nseg = W >> 8;
-    float loc[8];
-    for (int j = 0; j < 2 * nseg; ++j) loc[j] = part[(size_t)r * 2 * nseg + j];
-    *reinterpret_cast<f32x2*>(stats + 2 * (size_t)r) = ln_row_stats(loc, nseg, W);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -212,13 +212,15 @@ def quantize_fp8_rows(w):
 
 
 def ln_fold_terms(w, bias, gamma, beta):
-    """LN-folded linear layer (include/clipmi.h, tower ABI 3): for y = LayerNorm(x; gamma, beta) W^T + bias with the
-    bf16-rounded W the kernels multiply by, colsum[n] = sum_k gamma[k] W[n][k] and cb[n] = sum_k beta[k] W[n][k] +
-    bias[n], summed in float64, returned as f32."""
-    wd = w.detach().to("cpu").to(torch.bfloat16).double()
-    colsum = wd @ gamma.detach().double()
-    cb = wd @ beta.detach().double() + bias.detach().double()
-    return colsum.float(), cb.float()
+    """LN-folded linear layer (include/clipmi.h, tower ABI 3): for y = LayerNorm(x; gamma, beta) W^T + bias ->
+    (Wg bf16 [N][K], colsum f32 [N], cb f32 [N]) with Wg = bf16(W * gamma) (W = the bf16-rounded weights the
+    un-folded path multiplies by), colsum[n] = sum_k Wg[n][k] (of the ROUNDED Wg: it must cancel what the GEMM adds up)
+    and cb[n] = sum_k beta[k] W[n][k] + bias[n]; sums in float64."""
+    wb = w.detach().to("cpu").to(torch.bfloat16)
+    wg = (wb.float() * gamma.detach().float()[None, :]).to(torch.bfloat16)
+    colsum = wg.double().sum(dim=1)
+    cb = wb.double() @ beta.detach().double() + bias.detach().double()
+    return wg, colsum.float(), cb.float()
 
 
 def _pack_layers(tw, blob, sd, prefix, width, layers, fp8=False):
@@ -236,8 +238,16 @@ def _pack_layers(tw, blob, sd, prefix, width, layers, fp8=False):
     scale_field = {"lo_qkv_w": "lo_qkv_s", "lo_out_w": "lo_out_s", "lo_fc_w": "lo_fc_s", "lo_proj_w": "lo_proj_s"}
     for i in range(layers):
         base = None
+        folded = {}
+        if tw.ln_fold:
+            p_ = f"{prefix}.resblocks.{i}"
+            for fld_w, wk, bk, ln in (("lo_qkv_w", "attn.in_proj_weight", "attn.in_proj_bias", "ln_1"),
+                                      ("lo_fc_w", "mlp.c_fc.weight", "mlp.c_fc.bias", "ln_2")):
+                folded[fld_w] = ln_fold_terms(sd[f"{p_}.{wk}"], sd[f"{p_}.{bk}"], sd[f"{p_}.{ln}.weight"], sd[f"{p_}.{ln}.bias"])
         for field, key, dt in names:
             t = sd[f"{prefix}.resblocks.{i}.{key}"]
+            if field in folded:
+                t = folded[field][0]                   # W * diag(ln weight), already bf16
             if fp8 and field in scale_field:
                 # the weights as the bf16 path stores them, then e4m3 + one scale per output channel
                 q, sc = quantize_fp8_rows(t.to(torch.bfloat16).float())
@@ -256,10 +266,8 @@ def _pack_layers(tw, blob, sd, prefix, width, layers, fp8=False):
             else:
                 assert off - base == getattr(tw, field), "layers must have identical layouts"
         if tw.ln_fold:
-            p_ = f"{prefix}.resblocks.{i}"
-            for fld_s, fld_c, wk, bk, ln in (("lo_qkv_colsum", "lo_qkv_cb", "attn.in_proj_weight", "attn.in_proj_bias", "ln_1"),
-                                             ("lo_fc_colsum", "lo_fc_cb", "mlp.c_fc.weight", "mlp.c_fc.bias", "ln_2")):
-                colsum, cb = ln_fold_terms(sd[f"{p_}.{wk}"], sd[f"{p_}.{bk}"], sd[f"{p_}.{ln}.weight"], sd[f"{p_}.{ln}.bias"])
+            for fld_s, fld_c, fld_w in (("lo_qkv_colsum", "lo_qkv_cb", "lo_qkv_w"), ("lo_fc_colsum", "lo_fc_cb", "lo_fc_w")):
+                _, colsum, cb = folded[fld_w]
                 for fld, t in ((fld_s, colsum), (fld_c, cb)):
                     off = blob.put(t, f32)
                     if i == 0:

@@ -100,10 +100,11 @@ typedef struct clipmi_tower {
 
     /* ABI 3. ln_fold = 1 (weight_format 0, width % 256 == 0): ln_1 / ln_2 are folded into the GEMMs that consume
        them. With mean / rstd the row statistics of the residual row x,
-           LayerNorm(x; g, b) W^T + bias = rstd * ((x * g) W^T - mean * colsum) + cb,
-       colsum[n] = sum_k g[k] W[n][k], cb[n] = sum_k b[k] W[n][k] + bias[n]   (W = the bf16-rounded weights, sums in
-       float64, stored f32 [3W] / [4W]): the residual GEMM's store pass writes bf16(x * g) and the statistics, and the
-       stand-alone LayerNorm pass over the residual stream disappears. The plain lo_ln*_w/b stay (ln_fold = 0 path). */
+           LayerNorm(x; g, b) W^T + bias = rstd * (x Wg^T - mean * colsum) + cb,
+       Wg = W diag(g) (lo_qkv_w / lo_fc_w then hold Wg, rounded to bf16 once), colsum[n] = sum_k Wg[n][k],
+       cb[n] = sum_k b[k] W[n][k] + bias[n] (W = the bf16-rounded plain weights; sums in float64, stored f32 [3W] / [4W]).
+       The residual stream is kept split x = hi + lo (two bf16 arrays); hi is the GEMM operand, the residual GEMM's
+       store pass updates hi / lo and the statistics, and no stand-alone LayerNorm pass over the stream remains. */
     uint64_t lo_qkv_colsum, lo_qkv_cb, lo_fc_colsum, lo_fc_cb;
 } clipmi_tower;
 
@@ -237,17 +238,18 @@ int clipmi_dbg_gemm_fp8(const void* a8_dev, const void* w8_dev, const float* a_s
                         const float* bias_dev, void* out_dev, int M, int N, int K, int epi, void* stream);
 
 /* LN-folded linear layers (tower ABI 3, csrc/gemm.hpp), kernel by kernel:
- *   cast_stats    x f32 [M][W] -> xb = bf16(x * gamma), stats [M][2] = (mean, rstd)            (W % 256 == 0, <= 1024)
- *   gemm_ln       out bf16 = [quick_gelu] (rstd * (xb w^T - mean * colsum) + cb); epi 5 | 6, bits 8-9 force a kernel
- *   gemm_resid_ln x += a w^T + bias (f32, in place), xb = bf16(x * gamma), stats of the new rows; part = scratch
- *                 [M][N/256][2]; algo 3 = the persistent kernel's fused store pass, else residual GEMM + cast_stats */
-int clipmi_dbg_cast_stats(const float* x_dev, const float* gamma_dev, void* xb_dev, float* stats_dev, int M, int W,
-                          void* stream);
-int clipmi_dbg_gemm_ln(const void* xb_dev, const void* w_dev, const float* cb_dev, const float* colsum_dev,
-                       const float* stats_dev, void* out_dev, int M, int N, int K, int epi, void* stream);
-int clipmi_dbg_gemm_resid_ln(const void* a_dev, const void* w_dev, const float* bias_dev, float* x_dev,
-                             const float* gamma_dev, void* xb_dev, float* part_dev, float* stats_dev, int M, int N, int K,
-                             int algo, void* stream);
+ *   split_stats   rows = add ? x + (hi + lo) : x (f32 [M][W]) -> hi = bf16(rows), lo = bf16(rows - hi), part [M][W/256][2]
+ *                 = per-256-column (sum, sum of squares)                                           (W % 256 == 0, <= 1024)
+ *   gemm_ln       out bf16 = [quick_gelu] (rstd * (xhi wg^T - mean * colsum) + cb), (mean, rstd) from part; epi 5 | 6,
+ *                 bits 8-9 force a kernel
+ *   gemm_resid_ln (xhi, xlo) += a w^T + bias, part of the new rows; tmp = f32 [M][N] scratch; algo 3 = the persistent
+ *                 kernel's fused store pass, else GEMM into tmp + split_stats(add) */
+int clipmi_dbg_split_stats(const float* x_dev, int add, void* xhi_dev, void* xlo_dev, float* part_dev, int M, int W,
+                           void* stream);
+int clipmi_dbg_gemm_ln(const void* xhi_dev, const void* wg_dev, const float* cb_dev, const float* colsum_dev,
+                       const float* part_dev, void* out_dev, int M, int N, int K, int epi, void* stream);
+int clipmi_dbg_gemm_resid_ln(const void* a_dev, const void* w_dev, const float* bias_dev, void* xhi_dev, void* xlo_dev,
+                             float* part_dev, float* tmp_dev, int M, int N, int K, int algo, void* stream);
 
 /* clipmi_encode_image `reps` times with HIP events around every launch of the GEMM whose
  * epilogue is `probe_epi` (1 = MLP c_fc + QuickGELU), on `stream`; synchronises;

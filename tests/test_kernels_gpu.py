@@ -295,7 +295,8 @@ def test_gemm256p_rejects(clipmi, gpu):
     assert L.clipmi_dbg_gemm_bf16(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 256, 256, 128, 3 | (3 << 8), None) == 1
 
 
-# ---- LN-folded linear layers (csrc/gemm.hpp): LayerNorm folded into the GEMM that consumes it -----------------------
+# ---- LN-folded linear layers (csrc/gemm.hpp): LayerNorm folded into the GEMM that consumes it, residual stream kept
+# ---- split as hi + lo (two bf16 arrays) -------------------------------------------------------------------------------
 def _ln_fold_case(gpu, M, W, N, seed):
     g = torch.Generator(device="cpu"); g.manual_seed(seed)
     x = torch.randn(M, W, generator=g) * 2 + 0.3
@@ -304,57 +305,77 @@ def _ln_fold_case(gpu, M, W, N, seed):
     beta = 0.1 * torch.randn(W, generator=g)
     w = _bf16(torch.randn(N, W, generator=g) * W ** -0.5)
     bias = 0.1 * torch.randn(N, generator=g)
-    return x.to(gpu), gamma.to(gpu), beta.to(gpu), w.to(gpu), bias.to(gpu)
+    return x.to(gpu), gamma, beta, w, bias
+
+
+def _split(clipmi, L, x, add=None, hi=None, lo=None):
+    M, W = x.shape
+    if hi is None:
+        hi = torch.empty(2, M, W, dtype=torch.bfloat16, device=x.device)
+        hi, lo = hi[0], hi[1]
+    part = torch.full((M, W // 256, 2), float("nan"), dtype=torch.float32, device=x.device)
+    clipmi._lib.check(L.clipmi_dbg_split_stats(x.data_ptr(), 1 if add else 0, hi.data_ptr(), lo.data_ptr(), part.data_ptr(), M, W, None),
+                      "split_stats")
+    torch.cuda.synchronize()
+    return hi, lo, part
+
+
+def _check_split(x, hi, lo, part):
+    """hi = bf16(x), lo = bf16(x - hi); part = per-256-column (sum, sum of squares); hi + lo within 2^-16 of x."""
+    W = x.shape[1]
+    assert torch.equal(hi, x.to(torch.bfloat16))
+    assert torch.equal(lo, (x - hi.float()).to(torch.bfloat16))
+    assert ((hi.float() + lo.float()) - x).abs().max().item() <= 2.0 ** -16 * x.abs().max().item()
+    xs = x.double().reshape(x.shape[0], W // 256, 256)
+    assert (part[..., 0].double() - xs.sum(-1)).abs().max().item() <= 3e-6 * xs.abs().sum(-1).max().item()
+    assert ((part[..., 1].double() - (xs * xs).sum(-1)) / (xs * xs).sum(-1)).abs().max().item() <= 3e-6
 
 
 @pytest.mark.parametrize("M,W", [(1, 768), (7, 512), (1003, 768), (33, 1024), (260, 256)])
-def test_cast_stats(clipmi, gpu, M, W):
-    """xb = bf16(x * gamma) exactly; (mean, rstd) = torch's LayerNorm statistics of the f32 row."""
+def test_split_stats(clipmi, gpu, M, W):
     L = clipmi._lib.lib()
-    x, gamma, _, _, _ = _ln_fold_case(gpu, M, W, 256, M + W)
-    xb = torch.empty(M, W, dtype=torch.bfloat16, device=gpu)
-    st = torch.empty(M, 2, dtype=torch.float32, device=gpu)
-    clipmi._lib.check(L.clipmi_dbg_cast_stats(x.data_ptr(), gamma.data_ptr(), xb.data_ptr(), st.data_ptr(), M, W, None), "cast_stats")
-    torch.cuda.synchronize()
-    assert torch.equal(xb, (x * gamma).to(torch.bfloat16))
-    mean = x.double().mean(dim=1)
-    rstd = (x.double().var(dim=1, unbiased=False) + 1e-5).rsqrt()
-    assert (st[:, 0].double() - mean).abs().max().item() <= 2e-6 * x.abs().max().item()
-    assert ((st[:, 1].double() - rstd) / rstd).abs().max().item() <= 2e-5
+    x, _, _, _, _ = _ln_fold_case(gpu, M, W, 256, M + W)
+    hi, lo, part = _split(clipmi, L, x)
+    _check_split(x, hi, lo, part)
+    # add form: rows = add + (hi + lo), in place
+    g = torch.Generator(device="cpu"); g.manual_seed(M)
+    add = torch.randn(M, W, generator=g).to(gpu)
+    want = add + (hi.float() + lo.float())
+    hi2, lo2, part2 = _split(clipmi, L, add, add=True, hi=hi.clone(), lo=lo.clone())
+    _check_split(want, hi2, lo2, part2)
 
 
 @pytest.mark.parametrize("M,W,N", [(1, 768, 2304), (77, 512, 1536), (6400, 768, 3072), (6401, 768, 2304), (300, 1024, 4096),
-                                   (70000, 768, 2304)])
+                                   (70000, 768, 2304), (30000, 1024, 3072)])
 @pytest.mark.parametrize("epi", [5, 6])
 def test_gemm_ln_folded_consumer(clipmi, gpu, M, W, N, epi):
-    """out = [quick_gelu](LayerNorm(x; gamma, beta) W^T + bias) through cast_stats + the LN-folded epilogue, against
-    torch fp32 on the bf16-rounded weights; every kernel that can run the shape returns the SAME bits (batch-size
-    invariance of the encoder rests on that)."""
+    """out = [quick_gelu](LayerNorm(x; gamma, beta) W^T + bias) through split_stats + the LN-folded epilogue with the
+    packer's folded weights, against torch fp32 on the bf16-rounded plain weights; every kernel that can run the shape
+    returns the SAME bits (batch-size invariance of the encoder rests on that)."""
     L = clipmi._lib.lib()
     x, gamma, beta, w, bias = _ln_fold_case(gpu, M, W, N, M + W + N + epi)
-    colsum, cb = clipmi.weights.ln_fold_terms(w.float().cpu(), bias.cpu(), gamma.cpu(), beta.cpu())
-    colsum, cb = colsum.to(gpu), cb.to(gpu)
-    xb = torch.empty(M, W, dtype=torch.bfloat16, device=gpu)
-    st = torch.empty(M, 2, dtype=torch.float32, device=gpu)
-    clipmi._lib.check(L.clipmi_dbg_cast_stats(x.data_ptr(), gamma.data_ptr(), xb.data_ptr(), st.data_ptr(), M, W, None), "cast_stats")
-    ref = torch.nn.functional.layer_norm(x, (W,), gamma, beta, 1e-5) @ w.float().t() + bias
+    wg, colsum, cb = clipmi.weights.ln_fold_terms(w.float(), bias, gamma, beta)
+    wg, colsum, cb = wg.to(gpu), colsum.to(gpu), cb.to(gpu)
+    hi, lo, part = _split(clipmi, L, x)
+    ref = torch.nn.functional.layer_norm(x, (W,), gamma.to(gpu), beta.to(gpu), 1e-5) @ w.float().to(gpu).t() + bias.to(gpu)
     if epi == 6:
         ref = _qgelu(ref)
     outs = {}
     for algo in (0, 1, 2, 3):
         out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=gpu)
-        rc = L.clipmi_dbg_gemm_ln(xb.data_ptr(), w.data_ptr(), cb.data_ptr(), colsum.data_ptr(), st.data_ptr(), out.data_ptr(),
+        rc = L.clipmi_dbg_gemm_ln(hi.data_ptr(), wg.data_ptr(), cb.data_ptr(), colsum.data_ptr(), part.data_ptr(), out.data_ptr(),
                                   M, N, W, epi | (algo << 8), None)
         if rc != 0 and algo == 3:
-            assert N > 3840                         # the persistent form keeps bias + colsum rows in LDS
+            assert N > 3840 or (N == 3072 and W == 1024 and False)       # bias + colsum rows + the tile's partials must fit LDS
             continue
         clipmi._lib.check(rc, f"gemm_ln algo {algo}")
         torch.cuda.synchronize()
         outs[algo] = out
     scale = ref.abs().max().item()
-    # the A operand is bf16(x * gamma) (one rounding of the un-normalised value): 2^-8 of the output scale covers it
+    # the A operand is bf16(x) (one rounding of the un-normalised value) and the folded weights are rounded once more:
+    # 2^-8 of the output scale each
     err = (outs[0].float() - ref).abs().max().item()
-    assert torch.isfinite(outs[0].float()).all() and err <= 2.5 * (2.0 ** -8) * scale, f"err {err} scale {scale}"
+    assert torch.isfinite(outs[0].float()).all() and err <= 3.0 * (2.0 ** -8) * scale, f"err {err} scale {scale}"
     for algo, out in outs.items():
         assert torch.equal(out, outs[0]), f"algo {algo} differs from the default kernel's bits"
 
@@ -362,39 +383,36 @@ def test_gemm_ln_folded_consumer(clipmi, gpu, M, W, N, epi):
 @pytest.mark.parametrize("M,N,K", [(1, 768, 768), (300, 512, 2048), (6400, 768, 768), (6401, 768, 3072), (70000, 768, 768),
                                    (43500, 768, 3072), (1000, 1024, 1024)])
 def test_gemm_resid_ln_producer(clipmi, gpu, M, N, K):
-    """x += a W^T + bias (f32), xb = bf16(x * gamma), stats of the new rows: the persistent kernel's fused store pass
-    (algo 3) and residual GEMM + cast_stats (algos 1, 2) give identical bits in all three outputs, and x matches the
-    plain residual epilogue and torch."""
+    """(hi, lo) += a W^T + bias with the statistics partials of the new rows: the persistent kernel's fused store pass
+    (algo 3) and GEMM-into-scratch + split_stats (algos 1, 2) give identical bits in all three outputs; the new rows
+    equal torch's to f32 GEMM accuracy + the 2^-16 of the split."""
     L = clipmi._lib.lib()
     g = torch.Generator(device="cpu"); g.manual_seed(M + N + K)
     a = _bf16(torch.randn(M, K, generator=g)).to(gpu)
     w = _bf16(torch.randn(N, K, generator=g) * K ** -0.5).to(gpu)
     bias = torch.randn(N, generator=g).to(gpu)
-    gamma = (1 + 0.1 * torch.randn(N, generator=g)).to(gpu)
     x0 = (torch.randn(M, N, generator=g) * 2).to(gpu)
     x0[:, 7] += 30.0
+    hi0, lo0, _ = _split(clipmi, L, x0)
+    xold = hi0.float() + lo0.float()
     res = {}
     for algo in (1, 2, 3):
-        x = x0.clone()
-        xb = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=gpu)
+        buf = torch.empty(2, M, N, dtype=torch.bfloat16, device=gpu)
+        buf[0].copy_(hi0); buf[1].copy_(lo0)
         part = torch.full((M, N // 256, 2), float("nan"), dtype=torch.float32, device=gpu)
-        st = torch.full((M, 2), float("nan"), dtype=torch.float32, device=gpu)
-        clipmi._lib.check(L.clipmi_dbg_gemm_resid_ln(a.data_ptr(), w.data_ptr(), bias.data_ptr(), x.data_ptr(), gamma.data_ptr(),
-                                                     xb.data_ptr(), part.data_ptr(), st.data_ptr(), M, N, K, algo, None),
+        tmp = torch.empty(M, N, dtype=torch.float32, device=gpu)
+        clipmi._lib.check(L.clipmi_dbg_gemm_resid_ln(a.data_ptr(), w.data_ptr(), bias.data_ptr(), buf[0].data_ptr(), buf[1].data_ptr(),
+                                                     part.data_ptr(), tmp.data_ptr(), M, N, K, algo, None),
                           f"gemm_resid_ln algo {algo}")
         torch.cuda.synchronize()
-        res[algo] = (x, xb, st)
-    plain = x0.clone()
-    clipmi._lib.check(L.clipmi_dbg_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), plain.data_ptr(), M, N, K, 2, None), "gemm")
-    torch.cuda.synchronize()
-    ref = a.float() @ w.float().t() + bias + x0
-    x3, xb3, st3 = res[3]
-    assert torch.equal(x3, plain) and (x3 - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
-    assert torch.equal(xb3, (x3 * gamma).to(torch.bfloat16))
-    mean = x3.double().mean(dim=1)
-    rstd = (x3.double().var(dim=1, unbiased=False) + 1e-5).rsqrt()
-    assert (st3[:, 0].double() - mean).abs().max().item() <= 2e-6 * x3.abs().max().item()
-    assert ((st3[:, 1].double() - rstd) / rstd).abs().max().item() <= 2e-5
+        res[algo] = (buf[0].clone(), buf[1].clone(), part)
+    ref = a.float() @ w.float().t() + bias + xold
+    hi3, lo3, part3 = res[3]
+    new = hi3.float() + lo3.float()
+    assert (new - ref).abs().max().item() <= (2e-4 + 2.0 ** -15) * ref.abs().max().item()
+    assert torch.equal(lo3, (new - hi3.float()).to(torch.bfloat16)) or (lo3.float() - (new - hi3.float())).abs().max().item() < 1e-6
+    xs = new.double().reshape(M, N // 256, 256)
+    assert (part3[..., 0].double() - xs.sum(-1)).abs().max().item() <= 1e-4 * xs.abs().sum(-1).max().item()
     for algo in (1, 2):
-        for got, want, what in zip(res[algo], res[3], ("x", "xb", "stats")):
+        for got, want, what in zip(res[algo], res[3], ("hi", "lo", "part")):
             assert torch.equal(got, want), f"algo {algo} vs the fused store pass: {what} differs"
