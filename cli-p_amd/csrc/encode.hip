@@ -119,7 +119,8 @@ int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int 
             g.xhi = w.xhi; g.xlo = w.xlo; g.ln_part = w.ln_part; g.tmp_f32 = w.x;
             return launch_gemm_algo(g, EPI_BIAS_RESID_LN_F32, 0, st, probe);
         };
-        if (int rc = launch_split_stats(w.x, false, w.xhi, w.xlo, w.ln_part, M, W, st)) return rc;
+        // (the caller left the embedded rows split: ln_pre writes hi / lo / partials itself; the text tower, which has no
+        //  LayerNorm in front of the blocks, runs split_stats_kernel over its embedded rows)
         for (int l = 0; l < t->layers; ++l) {
             const uint64_t lb = lb_of(l);
             if (int rc = ln_linear(lb + t->lo_qkv_w, lb + t->lo_qkv_cb, lb + t->lo_qkv_colsum, 3 * W, EPI_LN_BIAS_BF16)) return rc;
@@ -201,7 +202,8 @@ static int encode_image_impl(const clipmi_tower* t, const void* blob_dev, const 
                        at<float>(blob_dev, t->off_cls), at<float>(blob_dev, t->off_pos), B, L, W);
     CLIPMI_CHECK_LAUNCH("cls_rows_kernel");
     LnArgs ln{w.x, at<float>(blob_dev, t->off_ln_pre_w), at<float>(blob_dev, t->off_ln_pre_b), w.x, nullptr, 1, B * L, W, 0};
-    if (int rc = launch_layernorm(ln, st)) return rc;       // ln_pre, in place (each wave owns its row)
+    if (t->ln_fold) { ln.out_hi = w.xhi; ln.out_lo = w.xlo; ln.out_part = w.ln_part; }     // straight into the split residual
+    if (int rc = launch_layernorm(ln, st)) return rc;       // ln_pre (ln_fold 0: in place, each wave owns its row)
     if (int rc = run_layers(t, blob_dev, w, B, 0, st, probe)) return rc;
     return run_head(t, blob_dev, w, B, nullptr, L, out_dev, normalize, st);
 }
@@ -234,6 +236,8 @@ extern "C" int clipmi_encode_text(const clipmi_tower* t, const void* blob_dev, c
     CLIPMI_CHECK_LAUNCH("text_embed_kernel");
     hipLaunchKernelGGL(eot_rows_kernel, dim3((Q + 63) / 64), dim3(64), 0, st, ids_dev, w.rowidx, Q, L);
     CLIPMI_CHECK_LAUNCH("eot_rows_kernel");
+    if (t->ln_fold)
+        if (int rc = launch_split_stats(w.x, false, w.xhi, w.xlo, w.ln_part, Q * L, W, st)) return rc;
     if (int rc = run_layers(t, blob_dev, w, Q, 1, st, nullptr)) return rc;
     return run_head(t, blob_dev, w, Q, w.rowidx, 1, out_dev, normalize, st);
 }

@@ -7,6 +7,7 @@ namespace clipmi {
 int launch_layernorm(const LnArgs& a, hipStream_t st) {
     if (a.M < 1) return 0;
     if (a.W % 4 != 0 || a.W > 1024) return set_err(CLIPMI_EINVAL, "layernorm: W=%d (need W %% 4 == 0, W <= 1024)", a.W);
+    if (a.out_hi && (a.W % 256 != 0 || !a.out_lo || !a.out_part)) return set_err(CLIPMI_EINVAL, "layernorm: split output needs W %% 256 == 0");
     hipLaunchKernelGGL(layernorm_kernel, dim3((a.M + 3) / 4), dim3(256), 0, st, a);
     CLIPMI_CHECK_LAUNCH("layernorm_kernel");
     return 0;
@@ -95,6 +96,11 @@ int launch_quantize_rows_fp8(const unsigned short* in, unsigned char* out, float
 }
 
 int launch_patchify(const PatchArgs& a, hipStream_t st) {
+    if (a.dtype == CLIPMI_U8 && a.P % 16 == 0 && a.R % 16 == 0 && a.patch_k == 3 * a.P * a.P && a.P * a.R <= 48 * 1024) {
+        hipLaunchKernelGGL(patchify_strip_u8_kernel, dim3((unsigned)((long long)a.B * 3 * a.grid)), dim3(256), (size_t)a.P * a.R + 512, st, a);
+        CLIPMI_CHECK_LAUNCH("patchify_strip_u8_kernel");
+        return 0;
+    }
     const long long total = (long long)a.B * a.np * (a.patch_k / 8);
     hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
     CLIPMI_CHECK_LAUNCH("patchify_kernel");

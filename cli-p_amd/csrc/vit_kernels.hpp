@@ -86,6 +86,46 @@ static __global__ void __launch_bounds__(256) patchify_kernel(PatchArgs a) {
     *reinterpret_cast<uint4*>(a.out + ((size_t)bp * a.patch_k + k8 * 8)) = o;
 }
 
+// u8 fast path of patchify_kernel for P % 16 == 0, R % 16 == 0 and patch_k == 3 P^2 (ViT-B/32, ViT-B/16): one workgroup
+// per (image, channel, patch row) stages that strip - P image rows = P*R CONTIGUOUS bytes, whole lines - in LDS and writes
+// the strip's patches in OUTPUT order, 16 bytes per lane, 1 KiB contiguous per wave-instruction. patchify_kernel maps
+// threads along the output without staging: a wave then reads sixteen 32-byte pieces from sixteen lines whose other 96
+// bytes belong to other workgroups (2.8 TB/s of useful bytes at B = 870); mapping threads along the input instead makes
+// the stores the scattered side (3.5 TB/s).
+static __global__ void __launch_bounds__(256) patchify_strip_u8_kernel(PatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int gy = blockIdx.x % a.grid;
+    const int c = (blockIdx.x / a.grid) % 3;
+    const int b = blockIdx.x / (3 * a.grid);
+    const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
+    const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+    const float m = mean[c], sd = stdv[c];
+    const unsigned char* src = static_cast<const unsigned char*>(a.pix) + (((size_t)b * 3 + c) * a.R + (size_t)gy * a.P) * a.R;
+    // the value of a pixel depends on (byte, channel) only: 256 results of patchify_kernel's expression per workgroup, then
+    // one 2-byte LDS lookup per pixel (the two f32 divisions per pixel made the pass VALU-bound: ~30 instructions each)
+    unsigned short* lut = reinterpret_cast<unsigned short*>(smem + a.P * a.R);
+    lut[threadIdx.x] = (unsigned short)(pack_bf16x2(((float)threadIdx.x / 255.0f - m) / sd, 0.f) & 0xffffu);
+    const int nchunk = (a.P * a.R) >> 4;
+    for (int j = threadIdx.x; j < nchunk; j += 256)
+        *reinterpret_cast<uint4*>(smem + j * 16) = *reinterpret_cast<const uint4*>(src + (size_t)j * 16);
+    __syncthreads();
+    const int per_patch = (a.P * a.P) >> 3, per_row = a.P >> 3;          // 8-pixel output pieces
+    for (int o = threadIdx.x; o < a.grid * per_patch; o += 256) {
+        const int gx = o / per_patch, rem = o - gx * per_patch;
+        const int y = rem / per_row, px = (rem - y * per_row) << 3;
+        const uint2 raw = *reinterpret_cast<const uint2*>(smem + y * a.R + gx * a.P + px);
+        unsigned w4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned word = k < 2 ? raw.x : raw.y;
+            const unsigned b0 = (word >> (16 * (k & 1))) & 0xffu, b1 = (word >> (16 * (k & 1) + 8)) & 0xffu;
+            w4[k] = (unsigned)lut[b0] | ((unsigned)lut[b1] << 16);
+        }
+        unsigned short* dst = a.out + ((size_t)b * a.np + gy * a.grid + gx) * a.patch_k + c * a.P * a.P + y * a.P + px;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+    }
+}
+
 // x[b*L + 0][:] = class_embedding + positional_embedding[0]
 static __global__ void __launch_bounds__(256) cls_rows_kernel(float* x, const float* cls, const float* pos, int B, int L, int W) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -141,6 +181,11 @@ struct LnArgs {
     // split-residual input (gemm.hpp): when x == nullptr the source rows are xhi + xlo (bf16 each)
     const unsigned short* xhi;
     const unsigned short* xlo;
+    // split-residual OUTPUT (ln_pre of an LN-folded tower): when out_hi is set the normalised row leaves as hi / lo
+    // bf16 halves plus its canonical statistics partials [M][W/256][2] (what split_stats_kernel would make of it)
+    unsigned short* out_hi;
+    unsigned short* out_lo;
+    float* out_part;
 };
 
 static __global__ void __launch_bounds__(256) layernorm_kernel(LnArgs a) {
@@ -207,6 +252,26 @@ static __global__ void __launch_bounds__(256) layernorm_kernel(LnArgs a) {
             }
         }
         if (lane == 0) a.scale8[r] = sc;
+        return;
+    }
+    if (a.out_hi) {              // W % 256 == 0 (checked by the launcher): segment i = columns 256 i .. 256 i + 255
+        const int nseg = a.W >> 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < nseg) {
+                const int c = i * 256 + lane * 4;
+                const f32x4 g = *reinterpret_cast<const f32x4*>(a.w + c);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(a.b + c);
+                const f32x4 y = (v[i] - mean) * rstd * g + bb;
+                uint2 nh, nl;
+                split_make(y, nh, nl);
+                *reinterpret_cast<uint2*>(a.out_hi + (size_t)r * a.W + c) = nh;
+                *reinterpret_cast<uint2*>(a.out_lo + (size_t)r * a.W + c) = nl;
+                const float sa = ln_wave_sum(ln_lane_sum(y));
+                const float sq = ln_wave_sum(ln_lane_sumsq(y));
+                if (lane == 0) *reinterpret_cast<f32x2*>(a.out_part + ((size_t)r * nseg + i) * 2) = f32x2{sa, sq};
+            }
+        }
         return;
     }
 #pragma unroll
@@ -713,12 +778,33 @@ static __global__ void __launch_bounds__(256, 8) attention52x4_kernel(const unsi
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, t), pf, o[dt], 0, 0, 0);
         }
     }
+    // Output row qi, columns 16 dt + 4 fg .. + 3 per accumulator tile: as they stand that is four 8-byte stores per lane,
+    // 32 contiguous bytes per row and instruction (store-issue-bound tail: the one-wave and the four-wave form took the
+    // same 90 us from cold caches). Lanes fg and fg ^ 1 (lane ^ 16) swap halves - the even one gives away tiles 1, 3 and
+    // receives the partner's 0, 2 - so that every lane owns 8 consecutive columns of two tiles: two 16-byte stores, 64
+    // contiguous bytes per row and instruction.
     const int qi = wave * 16 + fr;
-    if (qi < L) {
-        unsigned short* dst = out + ((size_t)b * L + qi) * W + h * 64 + 4 * fg;
+    uint2 pk[4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-            *reinterpret_cast<uint2*>(dst + dt * 16) = make_uint2(pack_bf16x2(o[dt].x, o[dt].y), pack_bf16x2(o[dt].z, o[dt].w));
+    for (int dt = 0; dt < 4; ++dt) pk[dt] = make_uint2(pack_bf16x2(o[dt].x, o[dt].y), pack_bf16x2(o[dt].z, o[dt].w));
+    const bool odd = fg & 1;
+    uint2 mine[2], theirs[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint2 give = odd ? pk[2 * j] : pk[2 * j + 1];
+        mine[j] = odd ? pk[2 * j + 1] : pk[2 * j];
+        theirs[j] = make_uint2(__shfl_xor(give.x, 16), __shfl_xor(give.y, 16));
+    }
+    if (qi < L) {
+        // even fg: tiles 0, 2 at columns 16 dt + 4 fg .. + 7 (own 4, then the partner's); odd fg: tiles 1, 3 at 16 dt + 4 (fg - 1)
+        unsigned short* dst = out + ((size_t)b * L + qi) * W + h * 64 + 4 * (fg & ~1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int dt = 2 * j + (odd ? 1 : 0);
+            const uint4 v = odd ? make_uint4(theirs[j].x, theirs[j].y, mine[j].x, mine[j].y)
+                                : make_uint4(mine[j].x, mine[j].y, theirs[j].x, theirs[j].y);
+            *reinterpret_cast<uint4*>(dst + dt * 16) = v;
+        }
     }
 }
 
