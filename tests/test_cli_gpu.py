@@ -92,6 +92,44 @@ def test_sharded_search_rccl_single_rank(tmp_path):
     assert (tmp_path / "ok").read_text() == "1"
 
 
+def _nccl_worker2(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import clipmi
+    from conftest import TopkOracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ranks = clipmi.ranks.Ranks("cuda", rank=rank, world=world, local=rank).init()
+    try:
+        rng = np.random.default_rng(6)                    # the same rows on every rank; each keeps its shard
+        N = 200_003
+        db = unit_rows(rng, N, 512)
+        db[N - 1] = db[7]                                  # duplicate across the shard boundary
+        q = unit_rows(rng, 70, 512)
+        lo, hi = clipmi.shard_bounds(N, world, rank)
+        idx = clipmi.IndexFlatIP(512, device=ranks.device, coarse="int8")
+        idx.add(db[lo:hi])
+        sh = clipmi.ShardedFlatIP(idx, N, group=ranks.data)
+        D, I = sh.search(q, 51)
+        if rank == 0:
+            Ds, Is = TopkOracle().topk(db, q, 51)
+            ok = np.array_equal(I, Is) and np.array_equal(D.view(np.uint32), Ds.view(np.uint32))
+            open(os.path.join(tmp, "ok2"), "w").write("1" if ok else "0")
+    finally:
+        ranks.close()
+
+
+def test_sharded_search_rccl_two_ranks(tmp_path):
+    """Two ranks on two GPUs: per-shard exact top-K, ONE RCCL all-gather over xGMI, the merge kernel — bit-exact against the
+    oracle over the whole matrix. Needs >= 2 GPUs: skipped (and reported as skipped) on the one-GPU boxes."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (the N > 1 host logic runs on gloo in tests/test_host_logic.py)")
+    import torch.multiprocessing as mp
+    mp.spawn(_nccl_worker2, args=(2, 29500 + (os.getpid() + 29) % 2000, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok2").read_text() == "1"
+
+
 BENCH_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "search")
 
