@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
                                                                  int K, long long id_base, float* out_s,
                                                                  long long* out_i, float* thr_out,
                                                                  const unsigned* run_if, unsigned* m_out = nullptr,
-                                                                 int keep = 0) {
+                                                                 int keep = 0, int stage_cap = -1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (run_if && *run_if == 0) return;
     unsigned long long* red = reinterpret_cast<unsigned long long*>(smem);   // [16] min, [16] max
@@ -385,7 +385,8 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
     if (M > cap) M = cap;
     const uint2* src = cand + (size_t)q * cap;
     const int need = (int)(M < K ? M : K);
-    const bool staged = M <= sel_stage_entries(K);
+    // stage_cap: entries of LDS the launch reserved behind the K-entry result buffer (-1: the most K leaves room for)
+    const bool staged = M <= (stage_cap < 0 ? sel_stage_entries(K) : stage_cap);
     if (staged) {
         for (long long e0 = tid; e0 < M; e0 += 4 * SEL_THREADS) {
             uint2 v[4];
@@ -1276,8 +1277,11 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(12, qa), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
                                static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, COARSE_CAP);
             CLIPMI_CHECK_LAUNCH("rescore_pairs_kernel");
-            hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, w.cand_c, w.gcnt_c, COARSE_CAP, K,
-                               idb, os, oi, thr_out, (const unsigned*)nullptr, m_out, keep);
+            // 4096 staged entries (32 KiB of LDS) cover these lists; a select block then fits on a CU beside a scan
+            // workgroup of ANOTHER batch in flight (114 KiB), which the 96-KiB staging of the sample select does not
+            const int scap = sel_stage_entries(K) < 4096 ? sel_stage_entries(K) : 4096;
+            hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), SEL_FIXED + (size_t)K * 8 + (size_t)scap * 8, st,
+                               w.cand_c, w.gcnt_c, COARSE_CAP, K, idb, os, oi, thr_out, (const unsigned*)nullptr, m_out, keep, scap);
             CLIPMI_CHECK_LAUNCH("select_topk_kernel(coarse)");
             return 0;
         };

@@ -63,7 +63,9 @@ int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int 
     if (L >= 49 && L <= 52 && !causal && tr == 1 && use52 == 2) {
         // one workgroup per (image, head), one query tile per wave
         const long long items = (long long)B * heads;
-        hipLaunchKernelGGL(attention52x4_kernel, dim3((unsigned)items), dim3(256), 64 * 128 + 52 * 128, st, qkv, out, B, L, heads);
+        const long long resident = (long long)NUM_CU * 5;               // 5 workgroups (20 waves, <= 96 VGPRs) per CU
+        hipLaunchKernelGGL(attention52x4_kernel, dim3((unsigned)(items < resident ? items : resident)), dim3(256),
+                           64 * 128 + 52 * 128, st, qkv, out, B, L, heads);
         CLIPMI_CHECK_LAUNCH("attention52x4_kernel");
         return 0;
     }

@@ -669,7 +669,7 @@ static __global__ void __launch_bounds__(256, 6) attention52_kernel(const unsign
 // attention52_kernel's query-tile loop: same MFMA sequence, same softmax: bit-identical output, a quarter of the serial
 // chain. 14.5 KiB of LDS per workgroup, 8 workgroups (32 waves) per CU.
 // ---------------------------------------------------------------------------------------------
-static __global__ void __launch_bounds__(256, 8) attention52x4_kernel(const unsigned short* __restrict__ qkv,
+static __global__ void __launch_bounds__(256, 5) attention52x4_kernel(const unsigned short* __restrict__ qkv,
                                                                       unsigned short* __restrict__ out, int B, int L,
                                                                       int heads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -678,37 +678,52 @@ static __global__ void __launch_bounds__(256, 8) attention52x4_kernel(const unsi
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     const int W = heads * 64;
-    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
-    const unsigned short* base = qkv + (size_t)b * L * 3 * W + h * 64;
     const size_t rs = (size_t)3 * W;
     char* kt_ = smem;                       // K: 64 rows x 128 B, swizzled
     char* vt = smem + 64 * 128;             // V: 52 rows x 128 B
-
-    // ---- this wave's Q fragments first (longest consumer chain), then its share of the K / V staging loads
-    int qrow = wave * 16 + fr;
-    qrow = qrow < L ? qrow : L - 1;
-    const unsigned short* qp = base + (size_t)qrow * rs + fg * 8;
-    const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(qp);
-    const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(qp + 32);
-    uint4 kd[2], vd[2];
     const int srow = lane >> 3, sch = lane & 7;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int row = (wave * 2 + i) * 8 + srow;                            // K rows 0..63
-        row = row < L ? row : L - 1;
-        kd[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * rs + W + sch * 8);
-        int vrow = (wave * 2 + i) * 8 + srow;                           // V rows 0..55 (52..55 dropped)
-        vrow = vrow < L ? vrow : L - 1;                                 // rows L..51: finite filler, weight 0
-        vd[i] = *reinterpret_cast<const uint4*>(base + (size_t)vrow * rs + 2 * W + sch * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 8 + srow;
-        *reinterpret_cast<uint4*>(kt_ + row * 128 + ((sch ^ (row & 7)) << 4)) = kd[i];
-        if (row < ROWS) *reinterpret_cast<uint4*>(vt + row * 128 + sch * 16) = vd[i];
-    }
-    __syncthreads();
-    if (wave * 16 >= L) return;             // (L >= 49: never; keeps the tail generic)
+    const int items = B * heads;
+
+    // A workgroup walks items blockIdx.x, + gridDim.x, ... (the grid is sized to the chip's residency): the NEXT item's six
+    // loads per lane (Q fragments, K / V staging pieces) are issued before the current item's math, so that the HBM round
+    // trip of item i + 1 runs under the MFMA / softmax / LDS work of item i instead of in front of it.
+    // (a macro, not a lambda: by-reference captures of the register arrays put them in scratch)
+    bf16x8 q0n, q1n;
+    uint4 kdn0, kdn1, vdn0, vdn1;
+#define ATT52_FETCH(IT)                                                                                  \
+    do {                                                                                                 \
+        const int b_ = (IT) / heads, h_ = (IT) - b_ * heads;                                             \
+        const unsigned short* base_ = qkv + (size_t)b_ * L * 3 * W + h_ * 64;                            \
+        int qrow_ = wave * 16 + fr;                                                                      \
+        qrow_ = qrow_ < L ? qrow_ : L - 1;                                                               \
+        const unsigned short* qp_ = base_ + (size_t)qrow_ * rs + fg * 8;                                 \
+        q0n = *reinterpret_cast<const bf16x8*>(qp_);                                                     \
+        q1n = *reinterpret_cast<const bf16x8*>(qp_ + 32);                                                \
+        int r0_ = (wave * 2) * 8 + srow, r1_ = (wave * 2 + 1) * 8 + srow;   /* K rows 0..63, V rows 0..55 */ \
+        r0_ = r0_ < L ? r0_ : L - 1;                                        /* rows >= L: finite filler */ \
+        r1_ = r1_ < L ? r1_ : L - 1;                                                                     \
+        kdn0 = *reinterpret_cast<const uint4*>(base_ + (size_t)r0_ * rs + W + sch * 8);                  \
+        vdn0 = *reinterpret_cast<const uint4*>(base_ + (size_t)r0_ * rs + 2 * W + sch * 8);              \
+        kdn1 = *reinterpret_cast<const uint4*>(base_ + (size_t)r1_ * rs + W + sch * 8);                  \
+        vdn1 = *reinterpret_cast<const uint4*>(base_ + (size_t)r1_ * rs + 2 * W + sch * 8);              \
+    } while (0)
+    int item = blockIdx.x;
+    if (item >= items) return;
+    ATT52_FETCH(item);
+    for (;;) {
+        const int b = item / heads, h = item - b * heads;
+        const bf16x8 q0 = q0n, q1 = q1n;
+        {
+            const int row0 = (wave * 2) * 8 + srow, row1 = row0 + 8;
+            *reinterpret_cast<uint4*>(kt_ + row0 * 128 + ((sch ^ (row0 & 7)) << 4)) = kdn0;
+            *reinterpret_cast<uint4*>(kt_ + row1 * 128 + ((sch ^ (row1 & 7)) << 4)) = kdn1;
+            if (row0 < ROWS) *reinterpret_cast<uint4*>(vt + row0 * 128 + sch * 16) = vdn0;
+            if (row1 < ROWS) *reinterpret_cast<uint4*>(vt + row1 * 128 + sch * 16) = vdn1;
+        }
+        const int nxt = item + gridDim.x;
+        const bool has_next = nxt < items;
+        if (has_next) ATT52_FETCH(nxt);
+        __syncthreads();
 
     // K fragments of all four key tiles out of LDS: row t*16 + fr, logical chunks fg and 4 + fg
     bf16x8 kf[NT][2];
@@ -806,6 +821,11 @@ static __global__ void __launch_bounds__(256, 8) attention52x4_kernel(const unsi
             *reinterpret_cast<uint4*>(dst + dt * 16) = v;
         }
     }
+        if (!has_next) break;
+        item = nxt;
+        __syncthreads();                    // every wave is done with this item's K / V tiles
+    }
+#undef ATT52_FETCH
 }
 
 // ---------------------------------------------------------------------------------------------
