@@ -72,7 +72,9 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     unsigned avoff[2][4];                // [A half][piece], bytes from the tile's first A row
     auto tile_origin = [&](int vv, int& mm, int& nn) {
         int bm, bn;
-        gemm_tile_coords(vv, ntiles, mtiles, ntn, 8, 4, bm, bn);
+        // (dbg bits 8-15 / 16-23: supertile shape GM x GN of the XCD-local tile order, development A/B; default 8 x 4)
+        const int gm_ = (g.dbg >> 8) & 0xff, gn_ = (g.dbg >> 16) & 0xff;
+        gemm_tile_coords(vv, ntiles, mtiles, ntn, gm_ ? gm_ : 8, gn_ ? gn_ : 4, bm, bn);
         mm = bm << 8;
         nn = bn << 8;
     };
@@ -532,11 +534,19 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                                 const int i = 4 * hgrp + i4;
                                 const f32x4 o = xs[i4] + split_join(hs[i4], ls[i4]);
                                 const int m = m0 + lr0 + i;
+                                // lanes l and l ^ 1 trade halves (two DPP quad_perm moves, no LDS traffic): the even one ends
+                                // with hi of 8 columns, the odd one with lo of the same 8: ONE 16-byte store per lane and row,
+                                // as the plain residual form issues, instead of two 8-byte ones
+                                uint2 nh, nl;
+                                split_make(o, nh, nl);
+                                const uint2 give = (lane & 1) ? nh : nl;
+                                uint2 got;
+                                got.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)give.x, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+                                got.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)give.y, 0xB1, 0xf, 0xf, false);
                                 if (m < g.M && !(g.dbg & 1)) {
-                                    uint2 nh, nl;
-                                    split_make(o, nh, nl);
-                                    *reinterpret_cast<uint2*>(g.xhi + (size_t)m * g.N + n0 + lane * 4) = nh;
-                                    *reinterpret_cast<uint2*>(g.xlo + (size_t)m * g.N + n0 + lane * 4) = nl;
+                                    unsigned short* dst = ((lane & 1) ? g.xlo : g.xhi) + (size_t)m * g.N + n0 + (lane & ~1) * 4;
+                                    *reinterpret_cast<uint4*>(dst) = (lane & 1) ? make_uint4(got.x, got.y, nl.x, nl.y)
+                                                                                : make_uint4(nh.x, nh.y, got.x, got.y);
                                 }
                                 sa[i] = ln_lane_sum(o);
                                 sq[i] = ln_lane_sumsq(o);
