@@ -60,13 +60,12 @@ static int persist_mode() {
     return mode;
 }
 
-// LDS beyond the two K-tile buffers: bias[N]; a second [N] row for FP8 (w_scale) and the LN-folded consumers (colsum);
-// the tile's 256 row values (FP8: a_scale, 1 KiB; LN consumer: K/256 statistics pairs per row, + 8 B where the 4-pair
-// read of the last row runs past them)
+// LDS beyond the two K-tile buffers: bias[N]; FP8: w_scale[N] + the tile's 256 a_scale values (1 KiB); LN consumer: the
+// tile's 256 colsum values (1 KiB) + K/256 statistics pairs per row (+ 8 B where the 4-pair read of the last row runs
+// past them)
 constexpr int g256p_lds(int epi, bool fp8, int N, int K, int dbg) {
-    const bool two = fp8 || epi_is_ln(epi);
     const int nseg = K >> 8;
-    return G256_LDS + N * 4 * (two ? 2 : 1) + (fp8 ? 1024 : epi_is_ln(epi) ? 256 * nseg * 8 + (nseg < 4 ? 8 : 0) : 0) +
+    return G256_LDS + N * 4 * (fp8 ? 2 : 1) + (fp8 ? 1024 : epi_is_ln(epi) ? 1024 + 256 * nseg * 8 + (nseg < 4 ? 8 : 0) : 0) +
            ((dbg & 12) ? 8192 + 2048 : 0);
 }
 

@@ -263,17 +263,20 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     P_ISSUE(1, 0, 0);
     float* sbias = reinterpret_cast<float*>(smem + G256_LDS);
     for (int i = tid; i < g.N; i += 512) sbias[i] = g.bias ? g.bias[i] : 0.f;
-    float* sws = sbias + g.N;                          // FP8: per-output-channel weight scales [N]; LNC: colsum[N]
-    float* sas = sws + ((FP8 || LNC) ? g.N : 0);       // FP8: the current tile's 256 activation-row scales;
+    float* sws = sbias + g.N;                          // FP8: per-output-channel weight scales [N];
+                                                       // LNC: colsum of the CURRENT tile's 256 columns (by LDS-DMA per tile:
+                                                       // a whole-N row beside bias[N] would not fit for N = 4096)
+    float* sas = sws + (FP8 ? g.N : LNC ? 256 : 0);    // FP8: the current tile's 256 activation-row scales;
                                                        // LNC: its 256 x nseg (sum, sum of squares) statistics partials
     if (FP8)
         for (int i = tid; i < g.N; i += 512) sws[i] = g.w_scale[i];
-    if (LNC)
-        for (int i = tid; i < g.N; i += 512) sws[i] = g.colsum[i];
     const int nseg_in = K >> 8;                        // LNC: 256-column segments of the rows A came from
-    __amdgpu_buffer_rsrc_t rsS;
+    __amdgpu_buffer_rsrc_t rsS, rsC;
     if (FP8) rsS = __builtin_amdgcn_make_buffer_rsrc((void*)g.a_scale, 0, (unsigned)g.M * 4u, 0x00020000);
-    if (LNC) rsS = __builtin_amdgcn_make_buffer_rsrc((void*)g.ln_part_in, 0, (unsigned)g.M * (unsigned)nseg_in * 8u, 0x00020000);
+    if (LNC) {
+        rsS = __builtin_amdgcn_make_buffer_rsrc((void*)g.ln_part_in, 0, (unsigned)g.M * (unsigned)nseg_in * 8u, 0x00020000);
+        rsC = __builtin_amdgcn_make_buffer_rsrc((void*)g.colsum, 0, (unsigned)g.N * 4u, 0x00020000);
+    }
     // (the compiler's wait for these loads also retires the loaders' DMA above; harmless, once per launch.
     //  The tile-start barrier below publishes sbias: every wave reaches it after its ds_write + lgkmcnt(0).)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -283,7 +286,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     unsigned short* const outp = static_cast<unsigned short*>(g.out);
 
     // development stamps (dbg & 4): [wave][tile][stamp] 100 MHz wall-clock ticks in LDS, dumped at the end
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + G256_LDS + g.N * 4 * ((FP8 || LNC) ? 2 : 1) + (FP8 ? 1024 : LNC ? 8192 : 0));
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + G256_LDS + g.N * 4 * (FP8 ? 2 : 1) + (FP8 ? 1024 : LNC ? 1024 + 8200 : 0));
     int tile_i = 0;
     unsigned long long kst[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define P_STAMP(k)                                                                                   \
@@ -337,6 +340,9 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                     for (int pc = 0; pc < 2 * nseg_in; ++pc)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) char*)sas + pc * 1024, 16,
                                                                  src0, (unsigned)pc * 1024u, 0, 0);
+                    // colsum[n0 .. n0 + 255] -> sws (one piece)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsC, (__attribute__((address_space(3))) char*)sws, 16,
+                                                             (unsigned)n0 * 4u + lo_ * 16u, 0, 0, 0);
                 }
             }
             P_KTILE(cur, 1, ktn, nb, 8, 8, 8);
@@ -408,11 +414,11 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                 : "memory");
         }
         if constexpr (LNC) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    wsv[b][nt] = *reinterpret_cast<const f32x4*>(sws + n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg);
+            // the tile's colsum values of this lane's columns (asm reads: sws is an LDS-DMA destination)
+            const unsigned ca_ = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sws + (unsigned)(wn * 32 + 4 * fg) * 4u;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:512\n\t"
+                         "ds_read_b128 %3, %4 offset:576\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(wsv[0][0]), "=&v"(wsv[0][1]), "=&v"(wsv[1][0]), "=&v"(wsv[1][1]) : "v"(ca_) : "memory");
         }
         // bias (and the FP8 scales / the LN-folded correction) are folded into the accumulators in place, before the
         // staging passes: the per-column / per-row factors are dead by the time the passes need registers for their LDS traffic
