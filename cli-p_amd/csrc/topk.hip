@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
                                                                  int K, long long id_base, float* out_s,
                                                                  long long* out_i, float* thr_out,
                                                                  const unsigned* run_if, unsigned* m_out = nullptr,
-                                                                 int keep = 0, int stage_cap = -1) {
+                                                                 int keep = 0, int stage_cap = -1, float* qmeta = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (run_if && *run_if == 0) return;
     unsigned long long* red = reinterpret_cast<unsigned long long*>(smem);   // [16] min, [16] max
@@ -494,6 +494,8 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
                 out_i[(size_t)q * K + rank] = id_base + (long long)me.y;
             }
             if (thr_out && rank == K - 1) thr_out[q] = __uint_as_float(me.x);
+            // coarse search: the next segment's scan threshold, (tau - margin) / t_q (coarse_prep_kernel's qmeta)
+            if (qmeta && rank == K - 1) qmeta[128 + q] = (__uint_as_float(me.x) - qmeta[192 + q]) * qmeta[q];
         }
         if (out_s)
             for (int e = need + tid; e < K; e += SEL_THREADS) {
@@ -501,6 +503,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
                 out_i[(size_t)q * K + e] = -1;
             }
         if (thr_out && need < K && tid == 0) thr_out[q] = -INFINITY;
+        if (qmeta && need < K && tid == 0) qmeta[128 + q] = -INFINITY;
     };
     if (staged) passes([&](long long e) -> uint2 { return lent[e]; });
     else passes([&](long long e) -> uint2 { return src[e]; });
@@ -593,23 +596,6 @@ __device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, r);
 }
 
-// tauc[q] = thr0[q] - 0.0041 * rmax * ||q||   (one wave per query)
-__global__ void __launch_bounds__(256) coarse_thresholds_kernel(const float* thr0, const float* __restrict__ q,
-                                                                int E, float rmax, int QA, float* tauc) {
-    const int lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (qi >= QA) return;
-    float ss = 0.f;
-    for (int k = lane; k < E; k += 64) { const float v = q[(size_t)qi * E + k]; ss = fmaf(v, v, ss); }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
-    if (lane == 0) {
-        const float margin = 0.0041f * rmax * sqrtf(ss) * 1.001f;
-        const float t = thr0[qi];
-        tauc[qi] = (t == -INFINITY || !(margin == margin)) ? -INFINITY : t - margin;
-    }
-}
-
 // ---- int8 coarse copy (clipmi_quantize_rows_i8 / clipmi_topk_ip_coarse_i8) -------------------------------
 // Row r: s_r = max|x_rk| / 127, q_rk = rint(x_rk / s_r) in [-127, 127], a_r = 1.001 * ||x_r - s_r q_r||_2.
 // Query: t_q, p_qk the same way, f_q = y - t_q p_q. The int8 MFMA gives the EXACT integer D = q_r . p_q
@@ -657,43 +643,86 @@ __global__ void __launch_bounds__(256) quantize_rows_i8_kernel(const float* __re
     if (lane == 0) meta[r] = make_float2(s, sqrtf(ee) * 1.001f);
 }
 
-// one wave per query: t_q, ||y||, ||f_q|| and the three per-query constants of the int8 scan
-__global__ void __launch_bounds__(256) coarse_thresholds_i8_kernel(const float* thr0, const float* __restrict__ q, int E,
-                                                                   float rmax, float amax, int QA, float* qmeta) {
+// Per-query constants of a coarse search, once per group of <= 64 queries (one wave per query), qmeta [4][64]:
+//   [0]   1 / t_q (int8; t_q = max|y| / 127)            or 1 (bf16)
+//   [64]  1.001 ||y|| / t_q (int8)                       or 0
+//   [128] the value the scan compares against, (tau - margin) * [0] - written by select_topk_kernel each time a new exact
+//         K-th best tau is known (-inf until then)
+//   [192] margin: 1.001 (R_max + A_max) ||f_q|| + 1e-4 R_max ||y|| (int8, f_q = y - t_q p_q) or 1.001 * 0.0041 R_max ||q||
+//         (bf16); +inf when it is not a number (the threshold then stays -inf: everything survives, the result stays exact)
+// and the query image the scan kernels copy into LDS (entry [(qg*KS + s)*64 + lane] = 16 bytes of query 16 qg + (lane & 15):
+// bf16 k = 32 s + 8 g .. + 7, or int8 k = 64 s + 16 g .. + 15, g = lane >> 4; zero for queries >= QA). Block 0 also clears
+// the call's control words (candidate counters, overflow flag): no memset node.
+template <bool I8>
+__global__ void __launch_bounds__(256) coarse_prep_kernel(const float* __restrict__ q, int E, float rmax, float amax, int QA,
+                                                          float* qmeta, uint4* qimage, unsigned* ctl, int nctl) {
+    constexpr int KS = 512 / (I8 ? 64 : 32);
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (qi >= QA) return;
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < nctl; i += 256) ctl[i] = 0u;
+    const int qg = qi >> 4, col = qi & 15;
+    if (qi >= QA) {                                            // padding query of a used 16-query group: zero image
+        if (lane < KS * 4) qimage[(qg * KS + (lane >> 2)) * 64 + (lane & 3) * 16 + col] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
     const float* y = q + (size_t)qi * E;
     float mx = 0.f, ss = 0.f;
     for (int k = lane; k < E; k += 64) { const float v = y[k]; mx = fmaxf(mx, fabsf(v)); ss = fmaf(v, v, ss); }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); ss += __shfl_xor(ss, o); }
     const float t = mx > 0.f ? mx / 127.0f : 1.0f;
-    const float inv = 1.0f / t;
+    const float inv = I8 ? 1.0f / t : 1.0f;
     float ff = 0.f;
-    for (int k = lane; k < E; k += 64) {
-        const float v = y[k];
-        const float p = fminf(fmaxf(rintf(v * inv), -127.f), 127.f);     // the scan's query image uses the same expression
-        const float f = v - t * p;
-        ff = fmaf(f, f, ff);
-    }
+    if (I8) {
+        for (int k = lane; k < E; k += 64) {
+            const float v = y[k];
+            const float p = fminf(fmaxf(rintf(v * inv), -127.f), 127.f);     // the query image below uses the same expression
+            const float f = v - t * p;
+            ff = fmaf(f, f, ff);
+        }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) ff += __shfl_xor(ff, o);
+        for (int o = 32; o >= 1; o >>= 1) ff += __shfl_xor(ff, o);
+    }
     if (lane == 0) {
         const float Y = sqrtf(ss), F = sqrtf(ff) * 1.001f;
-        const float tau = thr0[qi];
-        const float margin = 1.001f * (rmax + amax) * F + 1e-4f * rmax * Y;
-        const bool bad = tau == -INFINITY || !(margin == margin) || !(Y == Y);
+        float margin = I8 ? 1.001f * (rmax + amax) * F + 1e-4f * rmax * Y : 0.0041f * rmax * Y * 1.001f;
+        if (!(margin == margin) || !(Y == Y)) margin = INFINITY;
         qmeta[qi] = inv;
-        qmeta[64 + qi] = 1.001f * Y * inv;
-        qmeta[128 + qi] = bad ? -INFINITY : (tau - margin) * inv;
+        qmeta[64 + qi] = I8 ? 1.001f * Y * inv : 0.f;
+        qmeta[128 + qi] = -INFINITY;
+        qmeta[192 + qi] = margin;
+    }
+    if (lane < KS * 4) {
+        const int s_ = lane >> 2, g_ = lane & 3;
+        uint4 v;
+        if (I8) {
+            const float* p = y + 64 * s_ + 16 * g_;
+            unsigned w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned pk = 0;
+#pragma unroll
+                for (int b_ = 0; b_ < 4; ++b_) {
+                    const float pq = fminf(fmaxf(rintf(p[4 * j + b_] * inv), -127.f), 127.f);
+                    pk |= ((unsigned)(int)pq & 0xffu) << (8 * b_);
+                }
+                w[j] = pk;
+            }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            const float* p = y + 32 * s_ + 8 * g_;
+            v = make_uint4(pack2_bf16(p[0], p[1]), pack2_bf16(p[2], p[3]), pack2_bf16(p[4], p[5]), pack2_bf16(p[6], p[7]));
+        }
+        qimage[(qg * KS + s_) * 64 + g_ * 16 + col] = v;
     }
 }
 
 struct CoarseArgs {
     const void* dbc;             // coarse copy of the matrix: bf16 [nrows][E] or int8 [nrows][E]
     const float2* rmeta;         // int8 only: per row (scale s_r, error norm a_r >= ||x_r - s_r q_r||), padded to 32 rows
-    const float* qmeta;          // int8 only: [3][64]: 1/t_q | 1.001 ||y|| / t_q | threshold / t_q
+    const float* qmeta;          // [4][64], see coarse_prep_kernel: 1/t_q | 1.001 ||y|| / t_q | scaled threshold | margin
+    const uint4* qimage;         // the query image in the scan's LDS layout (coarse_prep_kernel)
     long long row0;              // this launch scans rows [row0, row0 + nrows) of the copy; row0 % 32 == 0 (ids stay global)
     long long nrows;
     const float* q;              // f32 [QA][E]
@@ -730,35 +759,20 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
     const int nwaves = blockDim.x >> 6;
     const int col = lane & 15, g = lane >> 4;
 
-    // query image: entry [(qg*KS + s)*64 + lane] = 16 bytes of query 16qg + col: bf16 k = 32s + 8g .. +7, or
-    // int8 k = 64s + 16g .. +15 (quantised exactly as coarse_thresholds_i8_kernel does)
+    // query image: built once per search by coarse_prep_kernel (each of 256 workgroups x 3 launches used to read the 128 KiB
+    // of f32 queries and quantise them again); here it is a 16-byte-per-lane copy, 8 loads in flight
     uint4* qimg = reinterpret_cast<uint4*>(smem);
-    for (int idx = tid; idx < QG * KS * 64; idx += blockDim.x) {
-        const int l = idx & 63, s_ = (idx >> 6) % KS, qg = (idx >> 6) / KS;
-        const int c_ = qg * 16 + (l & 15), g_ = l >> 4;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (c_ < a.QA) {
-            if (I8) {
-                const float* p = a.q + (size_t)c_ * E + 64 * s_ + 16 * g_;
-                const float inv = a.qmeta[c_];
-                unsigned w[4];
+    {
+        constexpr int NIMG = QG * KS * 64;
+        static_assert(NIMG % (8 * 256) == 0 || NIMG < 8 * 256, "image copy loop");
+        for (int base = tid; base < NIMG; base += 8 * 256) {
+            uint4 v[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    unsigned pk = 0;
+            for (int j = 0; j < 8; ++j) v[j] = base + j * 256 < NIMG ? a.qimage[base + j * 256] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-                    for (int b_ = 0; b_ < 4; ++b_) {
-                        const float pq = fminf(fmaxf(rintf(p[4 * j + b_] * inv), -127.f), 127.f);
-                        pk |= ((unsigned)(int)pq & 0xffu) << (8 * b_);
-                    }
-                    w[j] = pk;
-                }
-                v = make_uint4(w[0], w[1], w[2], w[3]);
-            } else {
-                const float* p = a.q + (size_t)c_ * E + 32 * s_ + 8 * g_;
-                v = make_uint4(pack2_bf16(p[0], p[1]), pack2_bf16(p[2], p[3]), pack2_bf16(p[4], p[5]), pack2_bf16(p[6], p[7]));
-            }
+            for (int j = 0; j < 8; ++j)
+                if (base + j * 256 < NIMG) qimg[base + j * 256] = v[j];
         }
-        qimg[idx] = v;
     }
     uint2* list = reinterpret_cast<uint2*>(smem + QG * KS * 1024 + (size_t)wave * coarse_wave_bytes(QG));
     int* lcnt = reinterpret_cast<int*>(list + COARSE_LIST);
@@ -770,7 +784,7 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
         active[qg] = qg * 16 + col < a.QA;
-        tau[qg] = active[qg] ? (I8 ? a.qmeta[128 + qg * 16 + col] : a.tauc[qg * 16 + col]) : INFINITY;
+        tau[qg] = active[qg] ? a.qmeta[128 + qg * 16 + col] : INFINITY;
         yt[qg] = (I8 && active[qg]) ? a.qmeta[64 + qg * 16 + col] : 0.f;
     }
     auto flush = [&]() {
@@ -1189,7 +1203,7 @@ int launch_coarse(const CoarseArgs& a, long long nsteps, hipStream_t st, hipEven
 
 struct CoarseWs {
     uint2* cand_e; uint2* cand_c; unsigned* gcnt_e; unsigned* gcnt_c; float* thr0; float* tauc; unsigned* flag;
-    unsigned* last_m; float* qmeta;
+    unsigned* last_m; float* qmeta; uint4* qimage;
 };
 
 size_t carve_coarse(const Plan& p, void* base, size_t cap, CoarseWs* w) {
@@ -1203,7 +1217,8 @@ size_t carve_coarse(const Plan& p, void* base, size_t cap, CoarseWs* w) {
     x.thr0 = ar.take<float>(COARSE_Q);
     x.tauc = ar.take<float>(COARSE_Q);
     x.last_m = ar.take<unsigned>(COARSE_Q);
-    x.qmeta = ar.take<float>(3 * 64);
+    x.qmeta = ar.take<float>(4 * 64);
+    x.qimage = ar.take<uint4>(4 * 16 * 64);            // 64 KiB: the bf16 image of 64 queries (int8: half of it)
     if (w) *w = x;
     return ar.off + 256;
 }
@@ -1232,8 +1247,18 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
     for (int q0 = 0; q0 < Q; q0 += COARSE_Q) {
         const int qa = (Q - q0) < COARSE_Q ? (Q - q0) : COARSE_Q;
         const float* qg = q_dev + (size_t)q0 * E;
-        // counters + overflow flag: one memset per 64-query group; selects re-zero what they consume
-        if (hipMemsetAsync(w.gcnt_e, 0, (32 + COARSE_Q + 4) * 4, st) != hipSuccess) return set_err(CLIPMI_EHIP, "hipMemsetAsync");
+        // per-query constants, the query image the scans copy, and the cleared counters + overflow flag (selects re-zero
+        // what they consume): one launch per 64-query group
+        {
+            const int nq = (qa + 15) / 16 * 16;
+            if (i8)
+                hipLaunchKernelGGL(coarse_prep_kernel<true>, dim3(nq / 4), dim3(256), 0, st, qg, E, rmax, amax, qa, w.qmeta, w.qimage,
+                                   w.gcnt_e, 32 + COARSE_Q + 4);
+            else
+                hipLaunchKernelGGL(coarse_prep_kernel<false>, dim3(nq / 4), dim3(256), 0, st, qg, E, rmax, amax, qa, w.qmeta, w.qimage,
+                                   w.gcnt_e, 32 + COARSE_Q + 4);
+            CLIPMI_CHECK_LAUNCH("coarse_prep_kernel");
+        }
         ScanArgs a;
         a.db = static_cast<const float*>(db_dev);
         a.K = K; a.C = p.C; a.wave_bytes = p.wave_bytes;
@@ -1253,7 +1278,7 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
         //  than the level-1 scan + select they replace)
         const bool two_level = S2 > S1;
         CoarseArgs c;
-        c.dbc = dbh_dev; c.rmeta = rmeta; c.qmeta = w.qmeta; c.q = qg; c.QA = qa; c.tauc = w.tauc; c.row0 = 0;
+        c.dbc = dbh_dev; c.rmeta = rmeta; c.qmeta = w.qmeta; c.qimage = w.qimage; c.q = qg; c.QA = qa; c.tauc = w.tauc; c.row0 = 0;
         c.cand = w.cand_c; c.gcnt = w.gcnt_c; c.cap = COARSE_CAP; c.overflow = w.flag;
         // rows [r0, r1) of the copy through the coarse machinery: scan -> exact re-scoring of the survivors -> select.
         // keep & 1: the K best so far stay at the head of the candidate lists (gcnt = K) and the next segment appends behind
@@ -1281,7 +1306,8 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             // workgroup of ANOTHER batch in flight (114 KiB), which the 96-KiB staging of the sample select does not
             const int scap = sel_stage_entries(K) < 4096 ? sel_stage_entries(K) : 4096;
             hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), SEL_FIXED + (size_t)K * 8 + (size_t)scap * 8, st,
-                               w.cand_c, w.gcnt_c, COARSE_CAP, K, idb, os, oi, thr_out, (const unsigned*)nullptr, m_out, keep, scap);
+                               w.cand_c, w.gcnt_c, COARSE_CAP, K, idb, os, oi, thr_out, (const unsigned*)nullptr, m_out, keep, scap,
+                               thr_out ? w.qmeta : (float*)nullptr);
             CLIPMI_CHECK_LAUNCH("select_topk_kernel(coarse)");
             return 0;
         };
@@ -1296,21 +1322,10 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
                                rows1, qg, qa, w.cand_c, (long long)COARSE_CAP, w.gcnt_c);
             CLIPMI_CHECK_LAUNCH("sample_scores_kernel");
             hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, w.cand_c, w.gcnt_c, COARSE_CAP, K,
-                               (long long)0, (float*)nullptr, (long long*)nullptr, two_level ? w.tauc : w.thr0,
-                               (const unsigned*)nullptr);
+                               (long long)0, (float*)nullptr, (long long*)nullptr, w.thr0, (const unsigned*)nullptr,
+                               (unsigned*)nullptr, 0, -1, w.qmeta);
             CLIPMI_CHECK_LAUNCH("select_topk_kernel(sample 1)");
         }
-        // level 2 (S2 rows): the coarse machinery itself, all queries at once, filtered by level 1's bound;
-        // its exact re-scored K-th best is thr0
-        auto thresholds = [&](const float* thr_in) -> int {
-            if (i8)
-                hipLaunchKernelGGL(coarse_thresholds_i8_kernel, dim3((qa + 3) / 4), dim3(256), 0, st, thr_in, qg, E, rmax, amax, qa,
-                                   w.qmeta);
-            else
-                hipLaunchKernelGGL(coarse_thresholds_kernel, dim3((qa + 3) / 4), dim3(256), 0, st, thr_in, qg, E, rmax, qa, w.tauc);
-            CLIPMI_CHECK_LAUNCH("coarse_thresholds_kernel");
-            return 0;
-        };
         // Segments of the copy, each scanned ONCE: [0, S2) (level 2 of the pre-pass, threshold from level 1), then
         // [S2, N1) and [N1, N) with N1 ~ N/4. After every segment the exact K-th best of all rows seen so far is the
         // next segment's threshold: the last 75 % of the rows are filtered by the K-th best of the first 25 % (about 100
@@ -1321,19 +1336,16 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
         long long* oi_final = (long long*)out_id_dev + (size_t)q0 * K;
         long long r_done = 0;
         if (two_level) {
-            if (int rc = thresholds(w.tauc)) return rc;
             if (int rc = coarse_pass(0, S2, true, w.thr0, nullptr, nullptr, 0, scan_ev ? scan_ev + 2 : nullptr, w.last_m, 1)) return rc;
             r_done = S2;
             long long N1 = (N / 4) & ~31ll;
             if (N1 < 4 * S2) N1 = 4 * S2;
             if (N1 + 65536 <= N) {
-                if (int rc = thresholds(w.thr0)) return rc;
                 if (int rc = coarse_pass(r_done, N1, true, w.thr0, nullptr, nullptr, 0, scan_ev ? scan_ev + 4 : nullptr, w.last_m, 3)) return rc;
                 r_done = N1;
             }
         }
-        // last segment: coarse thresholds from the latest bound, scan, exact re-scoring, select into the result
-        if (int rc = thresholds(w.thr0)) return rc;
+        // last segment (its threshold was written by the previous select): scan, exact re-scoring, select into the result
         if (int rc = coarse_pass(r_done, N, false, nullptr, os_final, oi_final, (long long)id_base, scan_ev, w.last_m, two_level ? 2 : 0))
             return rc;
         // 6. fallback: exact scan + select, exiting at once unless a coarse list overflowed
