@@ -125,6 +125,27 @@ def test_encode_image_vit_l14_336_full_size(clipmi, gpu):
     assert I[0, 0] == 0 and abs(D[0, 0] - 1.0) < 1e-3
 
 
+def test_encode_text_vit_l14_text_tower(clipmi, gpu):
+    """The ViT-L/14 text tower (width 768, 12 heads, 77 tokens): the LN-folded path on a width the ViT-B/32 towers do not
+    have on the text side (3 statistics segments, causal attention), three prompts against the oracle."""
+    sd = clipmi.weights.random_state_dict("ViT-L/14", seed=4)
+    d = clipmi.weights.infer_dims(sd)
+    g = torch.Generator(device="cpu"); g.manual_seed(12)
+    ids = torch.zeros(3, d["ctx"], dtype=torch.int64)
+    for r, eot in enumerate((4, 33, d["ctx"] - 1)):
+        ids[r, 0] = d["vocab"] - 2
+        ids[r, 1:eot] = torch.randint(1, d["vocab"] - 2, (eot - 1,), generator=g)
+        ids[r, eot] = d["vocab"] - 1
+    model = clipmi.CLIP(sd, device=gpu)
+    assert model.text.width == 768 and model.text.ln_fold == 1
+    got = model.encode_text(ids).cpu()
+    ref, noise = _tolerances(clipmi, sd, clip_oracle.encode_text, ids)
+    err = (got - ref).abs().max().item()
+    cos = _cos(got, ref).min().item()
+    print(f"ViT-L/14 text: err {err:.4g} (bf16-emulation noise {noise:.4g}), min cosine {cos:.6f}")
+    assert err <= 3 * noise + 1e-3 and cos >= 0.9995
+
+
 def test_encode_image_batch_invariance_and_dtypes(clipmi, gpu):
     """Rows do not depend on their batch neighbours or on the batch size (M-tail handling), and
     uint8 input with the fused transform tail equals pre-normalised f32 input."""

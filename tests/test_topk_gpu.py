@@ -364,6 +364,35 @@ def test_coarse_anisotropic_db_exact_and_survivors(clipmi, gpu, topk_oracle, kin
           f"anisotropic {report['anisotropic']:.0f}; fallback not taken in either case")
 
 
+def test_two_search_batches_in_flight_on_two_streams(clipmi, gpu, topk_oracle):
+    """Two search batches enqueued back to back on two HIP streams (what bench.py does for throughput): every stream owns
+    its workspace and result buffers, so both return the oracle's bits."""
+    rng = np.random.default_rng(909)
+    N, K = 120_000, 51
+    db = unit_rows(rng, N, 512)
+    qa, qb = unit_rows(rng, 64, 512), unit_rows(rng, 40, 512)
+    idx = clipmi.IndexFlatIP(512, device=gpu, coarse="int8")
+    idx.add(db)
+    idx.matrix_i8()
+    ta, tb = torch.from_numpy(qa).to(gpu), torch.from_numpy(qb).to(gpu)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(device=gpu), torch.cuda.Stream(device=gpu)
+    outs = []
+    for rep in range(3):
+        with torch.cuda.stream(s1):
+            ra = idx.search_device(ta, K)
+        with torch.cuda.stream(s2):
+            rb = idx.search_device(tb, K)
+        outs.append((ra, rb))
+    torch.cuda.synchronize()
+    Da, Ia = topk_oracle.topk(db, qa, K)
+    Db, Ib = topk_oracle.topk(db, qb, K)
+    for ra, rb in outs:
+        _assert_exact(ra[0].cpu().numpy(), ra[1].cpu().numpy(), Da, Ia, "stream 1")
+        _assert_exact(rb[0].cpu().numpy(), rb[1].cpu().numpy(), Db, Ib, "stream 2")
+    assert len(idx._ws) >= 2
+
+
 def test_quantize_rows_i8_matches_numpy(clipmi, gpu):
     """clipmi_quantize_rows_i8: scale = max|x| / 127, q = rint(x / scale) (round half to even), error norm >= the
     true one and within 0.2 % of it."""
