@@ -281,7 +281,7 @@ def scan_probe(L, idx, q, Qp, K, dev, kind):
                                                               ws.data_ptr(), ws.numel(), clipmi._lib.stream_ptr(dev), 10,
                                                               C.byref(scan_ms), C.byref(survivors)), "coarse_i8_scan_ms")
         return (scan_ms.value, survivors.value / Qp, n_local * (512 + 8),     # int8 row + its (scale, error norm) pair
-                f"scan_coarse_kernel<512,{qg},false,true>", "scan_coarse_i8_bytes_per_launch")
+                f"scan_coarse_kernel<512,{qg},*,true> (three launches stream the copy once)", "scan_coarse_i8_bytes_per_pass")
     if kind == "bf16":
         dbh, rmax = idx.matrix_bf16()
         ws = torch.empty(L.clipmi_topk_ip_coarse_workspace_bytes(n_local, 512, Qp, K), dtype=torch.uint8, device=dev)

@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LABELS = (
     ("scan", r"scan_topk_f32_kernel<512, false"),
     ("scan_coarse", r"scan_coarse_kernel<512, 4, false, false>"),
-    ("scan_coarse_i8", r"scan_coarse_kernel<512, 4, false, true>"),
+    ("scan_coarse_i8", r"scan_coarse_kernel<512, 4, false, true>"),          # the last segment (75 % of the rows)
+    ("scan_coarse_i8_pre", r"scan_coarse_kernel<512, 4, true, true>"),       # the two earlier segments of the same pass
     ("rescore", r"rescore_pairs_kernel"),
     ("gemm_c_fc", r"gemm256p_bf16_nt_kernel<(1|6), ?false>"),
     ("gemm_qkv", r"gemm256p_bf16_nt_kernel<(0|5), ?false>"),
@@ -31,7 +32,7 @@ LABELS = (
     ("layernorm", r"layernorm_kernel"),
     ("cast_stats", r"cast_stats_kernel"),
 )
-OPTIONAL = {"scan", "scan_coarse", "gemm128_c_fc", "gemm128_resid", "layernorm", "cast_stats"}   # not on every bench path
+OPTIONAL = {"scan", "scan_coarse", "scan_coarse_i8_pre", "gemm128_c_fc", "gemm128_resid", "layernorm", "cast_stats"}   # not on every bench path
 
 
 def per_kernel(d, counter):
@@ -79,6 +80,9 @@ def main():
         res[f"{label}_write_bytes_per_launch"] = wr
         res[f"{label}_bytes_per_launch"] = rd + wr
         res[f"{label}_launches_seen"] = max(nf, nw)
+    # one coarse PASS streams the copy once in three launches: the last segment + two earlier ones
+    if "scan_coarse_i8_bytes_per_launch" in res and "scan_coarse_i8_pre_bytes_per_launch" in res:
+        res["scan_coarse_i8_bytes_per_pass"] = res["scan_coarse_i8_bytes_per_launch"] + 2 * res["scan_coarse_i8_pre_bytes_per_launch"]
     # all clipmi encode kernels summed: counter bytes per launch x launches, for the per-step traffic figure
     tot_r = sum(sum(vs) for k, vs in fetch.items() if "clipmi::" in k and "scan" not in k and "rescore" not in k
                 and "select" not in k and "quantize_rows_i8" not in k and "coarse" not in k) * 1024 * 2
