@@ -30,9 +30,9 @@ LABELS = (
     ("gemm128_resid", r"gemm_bf16_nt_kernel<(2|7)>"),
     ("attention", r"attention"),
     ("layernorm", r"layernorm_kernel"),
-    ("cast_stats", r"cast_stats_kernel"),
+    ("split_stats", r"split_stats_kernel"),
 )
-OPTIONAL = {"scan", "scan_coarse", "scan_coarse_i8_pre", "gemm128_c_fc", "gemm128_resid", "layernorm", "cast_stats"}   # not on every bench path
+OPTIONAL = {"scan", "scan_coarse", "scan_coarse_i8_pre", "gemm128_c_fc", "gemm128_resid", "layernorm", "split_stats"}   # not on every bench path
 
 
 def per_kernel(d, counter):
