@@ -279,3 +279,27 @@ def test_sharded_query_repl_gloo_world2(clipmi, tmp_path, topk_oracle):
     assert I[0][0] == 5 and I[0][1] == 2999                   # the cross-shard duplicate ranks right behind the query row
     assert "Not found." in lines and "Set to probe 40 subsets." in lines
     assert all(l.split()[2] == f"/lib/img_{int(l.split()[1]):05d}.jpg" for l in res)
+
+
+def test_bench_refuses_missing_gpus_and_stale_traffic(tmp_path):
+    """bench.py on a box without the GPUs it is asked for: a JSON error record and a non-zero exit (no traceback, no GPU
+    touched); and the roofline `traffic` figure is only taken from a profile summary whose recorded library digest equals the
+    library in the tree."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--quick"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 2, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "error" in rec and rec["n_gpus"] == 64 and rec["value"] is None
+    sys.path.insert(0, ROOT)
+    import bench
+    import clipmi
+    val, src = bench.pmc_traffic("gemm_c_fc_bytes_per_launch")
+    newest = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))[-1]
+    rec = json.load(open(os.path.join(ROOT, "profiles", newest)))
+    if rec.get("lib_digest") == clipmi.build.source_digest():
+        assert val == rec["gemm_c_fc_bytes_per_launch"] and newest in src
+    else:
+        assert val is None and "stale" in src
