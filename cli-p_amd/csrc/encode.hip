@@ -3,8 +3,14 @@
 // model.encode_text + normalize (query-index.py:108, 13-17). Op order follows SURVEY.md §2.1.
 //
 // Activation layout in HBM (all row-major, token row t = b*L + l):
-//   x    f32  [B*L][W]     residual stream (f32 so that 12-24 residual adds do not round to bf16)
-//   h    bf16 [B*L][W]     LayerNorm output / attention output (GEMM A operands)
+//   ln_fold towers (bf16 weights, W % 256 == 0: every real CLIP tower; gemm.hpp "LN-folded linear layers"):
+//     xhi, xlo bf16 [B*L][W]   the residual stream, split: x = hi + lo (hi = bf16(x), lo = bf16(x - hi)); hi is the A
+//                              operand of the LN-folded qkv / c_fc GEMMs, so 12-24 residual adds keep ~2^-17 relative
+//     ln_part f32 [B*L][W/256][2]  row statistics of x as per-256-column (sum, sum of squares)
+//     x    f32  [B*L][W]       embedding-stage output only (and scratch of non-persistent residual GEMMs)
+//   other towers (FP8 weights, toy widths):
+//     x    f32  [B*L][W]       residual stream;  h also receives the LayerNorm outputs
+//   h    bf16 [B*L][W]     attention output (GEMM A operand)
 //   big  bf16 [B*L][4W]    qkv ([..][3W]) and, later in the layer, the MLP hidden ([..][4W])
 //   patches bf16 [B*np][patch_k] (vision), pooled bf16 [B][W]
 #include "vit_kernels.hpp"

@@ -40,9 +40,9 @@ template <int EPI, bool FP8 = false>
 __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_RESID_F32 || epi_is_ln(EPI) ||
                       EPI == EPI_BIAS_RESID_LN_F32, "store-only epilogues");
-    // LN-folded forms (gemm.hpp "LN-folded linear layers"): LNC = consumer epilogue (row statistics of the tile by
-    // LDS-DMA under the last K-tile, colsum[N] in LDS beside the bias row), RLN = residual producer (the storers also
-    // write xb = bf16(x * gamma) and the tile's 256-column row-statistics partials)
+    // LN-folded forms (gemm.hpp "LN-folded linear layers"): LNC = consumer epilogue (the tile's row-statistics partials
+    // and its 256 colsum values by LDS-DMA under the last K-tile), RLN = residual producer (the storers also
+    // update the split residual hi / lo and write the tile's 256-column row-statistics partials)
     constexpr bool LNC = epi_is_ln(EPI);
     constexpr bool RESID = EPI == EPI_BIAS_RESID_F32 || EPI == EPI_BIAS_RESID_LN_F32;
     constexpr bool RLN = EPI == EPI_BIAS_RESID_LN_F32;
