@@ -352,31 +352,42 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) stamps[128 + wave * 9 + i] = kst[i];     // after the 4 x 8 x 4 tile stamps
         }
+        if constexpr (LNC) {
+            // The tile's statistics partials (256 rows x nseg (sum, sumsq) pairs, DMA'd by wave 0 under the last K-tile and
+            // retired by its own counted waits) are folded IN PLACE into 256 (mean, rstd) pairs by wave 0 alone, four rows
+            // per lane in two halves (rows l, l + 64, then l + 128, l + 192: a half's writes land on partials that half has
+            // already read), BEFORE the barrier that ends the K-loop: wave group 1 is still in its last MFMA slot then, so
+            // the fold costs no extra barrier and next to no time (a 256-thread fold behind two extra barriers cost c_fc
+            // 3 us per launch; per-lane folding of the lane's own 8 rows cost 16-32 registers beside the 128 accumulators
+            // and pushed the storers' store addresses into scratch). asm accesses throughout (a compiler-visible access
+            // to an LDS-DMA destination waits vmcnt(0)); always 4 pairs are read: for nseg < 4 the extra ones belong to the
+            // next row and are ignored.
+            if (wave == 0) {
+                const unsigned sas0_ = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sas;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    f32x2 p0, p1, p2, p3, p4, p5, p6, p7;
+                    const unsigned r0_ = (unsigned)(hf * 128 + lane), r1_ = r0_ + 64u;
+                    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:8\n\tds_read_b64 %2, %8 offset:16\n\t"
+                                 "ds_read_b64 %3, %8 offset:24\n\tds_read_b64 %4, %9\n\tds_read_b64 %5, %9 offset:8\n\t"
+                                 "ds_read_b64 %6, %9 offset:16\n\tds_read_b64 %7, %9 offset:24\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5), "=&v"(p6), "=&v"(p7)
+                                 : "v"(sas0_ + r0_ * (unsigned)nseg_in * 8u), "v"(sas0_ + r1_ * (unsigned)nseg_in * 8u)
+                                 : "memory");
+                    const float pa[8] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
+                    const float pb[8] = {p4.x, p4.y, p5.x, p5.y, p6.x, p6.y, p7.x, p7.y};
+                    const f32x2 ma = ln_row_stats(pa, nseg_in, K), mb = ln_row_stats(pb, nseg_in, K);
+                    asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                                 ::"v"(sas0_ + r0_ * 8u), "v"(sas0_ + r1_ * 8u), "v"(ma), "v"(mb) : "memory");
+                }
+            }
+        }
         if (wm == 0) __builtin_amdgcn_s_barrier();     // balance the stagger; all reads of buffer 1 are done
 
         // ---- epilogue through buffer 1: two passes of 128 rows x 512 B
         f32x2 lst[2][4];         // LNC: (mean, rstd) of the lane's 8 accumulator rows
         if constexpr (LNC) {
-            // The tile's statistics partials (256 rows x nseg (sum, sumsq) pairs, DMA'd under the last K-tile) are folded
-            // IN PLACE into 256 (mean, rstd) pairs by threads 0..255, one row each: read, barrier, write, barrier. Doing
-            // the fold per lane for its 8 rows costs 16-32 registers of pairs beside the 128 accumulators and pushed the
-            // storers' store addresses into scratch (a reload = vmcnt(0) = every store so far). asm accesses throughout
-            // (a compiler-visible access to an LDS-DMA destination waits vmcnt(0)); always 4 pairs are read: for nseg < 4
-            // the extra ones belong to the next row and are ignored.
             const unsigned sas_ = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sas;
-            f32x2 mr = {0.f, 0.f};
-            if (tid < 256) {
-                f32x2 p0, p1, p2, p3;
-                const unsigned ra_ = sas_ + (unsigned)tid * (unsigned)nseg_in * 8u;
-                asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\t"
-                             "ds_read_b64 %3, %4 offset:24\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3) : "v"(ra_) : "memory");
-                const float pp[8] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
-                mr = ln_row_stats(pp, nseg_in, K);
-            }
-            __builtin_amdgcn_s_barrier();
-            if (tid < 256) asm volatile("ds_write_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(sas_ + (unsigned)tid * 8u), "v"(mr) : "memory");
-            __builtin_amdgcn_s_barrier();
             const unsigned sa_ = sas_ + (wm * 64 + fr) * 8;
             asm volatile(
                 "ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:128\n\tds_read_b64 %2, %8 offset:256\n\tds_read_b64 %3, %8 offset:384\n\t"
