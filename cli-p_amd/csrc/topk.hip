@@ -1266,8 +1266,11 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
         // 1. exact two-level pre-pass: thr0[q] = exact K-th best score of the first S2 rows (S2 ~ N*K/2048,
         //    so that only ~2-3 k rows per query survive the coarse pass; every survivor costs a 2-KB row
         //    read in the re-scoring pass). Level 1 (S1 rows, no threshold) only feeds level 2's filter.
-        long long S2 = 32768;
-        while (S2 < N / 8 && S2 * 2048 < N * (long long)K) S2 *= 2;
+        // (not rounded up to a power of two: at 12.5 M rows that made the first segment 524 k rows instead of 311 k and its
+        //  re-scoring, filtered only by level 1's weak bound, the largest of the three)
+        long long S2 = (N * (long long)K / 2048 + 31) & ~31ll;
+        if (S2 > ((N / 8) & ~31ll)) S2 = (N / 8) & ~31ll;
+        if (S2 < 32768) S2 = 32768;
         // level 1 only has to thin level 2's candidates (S2*K/S1 per query): 8 k rows are enough, and its
         // select then ranks 8 k entries per query instead of 32 k
         // (12288 = what the select keeps in LDS; N >= 65536 here)
