@@ -129,7 +129,10 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmP
         use256 = tiles * 100 >= rounds * NUM_CU * pct;
         // more than one round of tiles: the persistent kernel overlaps each tile's write-out with the next
         // tile's K-loop
-        use256p = use256 && ok256p && tiles > NUM_CU && persist_mode() != 0;
+        // (the split-residual producer also at <= one round: its fused store pass saves the whole split_stats pass that
+        //  the other kernels need behind them; CLIPMI_GEMM_PERSIST=2 keeps the old rule for A/B runs)
+        use256p = use256 && ok256p && persist_mode() != 0 &&
+                  (tiles > NUM_CU || (epi == EPI_BIAS_RESID_LN_F32 && persist_mode() != 2));
     }
     if (g.M < 1 || !g.A || !g.W || (!g.out && epi != EPI_BIAS_RESID_LN_F32)) return set_err(CLIPMI_EINVAL, "gemm: bad arguments");
     if (epi == EPI_BIAS_RESID_LN_F32 && !use256p) {
