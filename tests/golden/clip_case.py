@@ -19,6 +19,8 @@ CASES = {
     # 101 tokens (flash attention), and ViT-B/16 (16-px patches, 197 tokens)
     "toyl14_seed3": ("toy-l14", 3, False),
     "vitb16_seed2": ("ViT-B/16", 2, False),
+    # ViT-L/14 (width 1024, 16 heads, 24 layers, 257 tokens; text width 768, 12 heads): two images, three prompts
+    "vitl14_seed4": ("ViT-L/14", 4, False),
 }
 
 
@@ -42,7 +44,7 @@ def inputs(name):
     a = clipmi.weights.ARCHS[arch]
     g = torch.Generator(device="cpu")
     g.manual_seed(1234)
-    images = torch.randn(4, 3, a["res"], a["res"], generator=g, dtype=torch.float32)
+    images = torch.randn(2 if arch.startswith("ViT-L") else 4, 3, a["res"], a["res"], generator=g, dtype=torch.float32)
     ctx, vocab = a["ctx"], a["vocab"]
     ids = torch.zeros(3, ctx, dtype=torch.int64)
     for r, eot in enumerate((5, min(20, ctx - 2), ctx - 1)):
