@@ -841,12 +841,15 @@ static __global__ void __launch_bounds__(256, 5) attention52x4_kernel(const unsi
 // K tile rows are 128 B with 16-byte chunks XOR-swizzled by row & 7 (conflict-free ds_read_b128 fragments);
 // the V tile is row-major for ds_read_b64_tr_b16.
 // ---------------------------------------------------------------------------------------------
-template <int WPB>
-__global__ void __launch_bounds__(WPB * 64, 2) attention_flash_kernel(const unsigned short* __restrict__ qkv,
+// QT = 16-query tiles per wave: 4 (64 queries; ~220 VGPRs, two waves per SIMD) or 2 (32 queries; ~120 VGPRs, four waves
+// per SIMD: with K/V staged once per workgroup either way, the smaller wave tile buys 2.5x the resident waves to overlap
+// one wave's softmax with another's MFMAs)
+template <int WPB, int QT>
+__global__ void __launch_bounds__(WPB * 64, QT == 2 ? 4 : 2) attention_flash_kernel(const unsigned short* __restrict__ qkv,
                                                                     unsigned short* __restrict__ out, int B, int L,
                                                                     int heads, int qgroups) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 x [K 8 KiB | V 8 KiB]
-    constexpr int NT = 4;
+    constexpr int NT = 4;          // key tiles of 16 per 64-key block
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -857,26 +860,26 @@ __global__ void __launch_bounds__(WPB * 64, 2) attention_flash_kernel(const unsi
     const int b = bh / heads, h = bh - b * heads;
     const unsigned short* base = qkv + (size_t)b * L * 3 * W + h * 64;
     const size_t rs = (size_t)3 * W;
-    const int q0 = (qgi * WPB + wave) * 64;
+    const int q0 = (qgi * WPB + wave) * (16 * QT);
     const bool wave_active = q0 < L;                  // idle waves still stage tiles and hit barriers
 
-    bf16x8 qf[NT][2];
+    bf16x8 qf[QT][2];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < QT; ++t) {
         int row = q0 + t * 16 + fr;
         row = row < L ? row : L - 1;
         const unsigned short* pr = base + (size_t)row * rs + fg * 8;
         qf[t][0] = *reinterpret_cast<const bf16x8*>(pr);
         qf[t][1] = *reinterpret_cast<const bf16x8*>(pr + 32);
     }
-    f32x4 o[4][NT];
+    f32x4 o[4][QT];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int qt = 0; qt < NT; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run[NT], l_run[NT];
+        for (int qt = 0; qt < QT; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int qt = 0; qt < NT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.f; }
+    for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.f; }
 
     // staging by LDS-DMA (no VGPRs): a K/V block is 16 pieces of 1 KiB (8 rows x 128 B); pieces 0..7 are
     // K (16-byte chunks XOR-swizzled with row & 7 — applied on the SOURCE address, the DMA destination is
@@ -908,14 +911,14 @@ __global__ void __launch_bounds__(WPB * 64, 2) attention_flash_kernel(const unsi
         const char* kb = smem + (j & 1) * 16384;
         const char* vt = kb + 8192;
         if (wave_active) {
-            f32x4 s[NT][NT];
+            f32x4 s[NT][QT];
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
                 const int row = kt * 16 + fr;
                 const bf16x8 k0f = *reinterpret_cast<const bf16x8*>(kb + row * 128 + (((0 + fg) ^ (row & 7)) << 4));
                 const bf16x8 k1f = *reinterpret_cast<const bf16x8*>(kb + row * 128 + (((4 + fg) ^ (row & 7)) << 4));
 #pragma unroll
-                for (int qt = 0; qt < NT; ++qt) {
+                for (int qt = 0; qt < QT; ++qt) {
                     f32x4 a = {0.f, 0.f, 0.f, 0.f};
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0f, qf[qt][0], a, 0, 0, 0);
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1f, qf[qt][1], a, 0, 0, 0);
@@ -924,7 +927,7 @@ __global__ void __launch_bounds__(WPB * 64, 2) attention_flash_kernel(const unsi
             }
             const bool tail = k0 + 64 > L;            // only the last block can hold masked keys
 #pragma unroll
-            for (int qt = 0; qt < NT; ++qt) {
+            for (int qt = 0; qt < QT; ++qt) {
                 float mx = -INFINITY;
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt)
@@ -958,9 +961,9 @@ __global__ void __launch_bounds__(WPB * 64, 2) attention_flash_kernel(const unsi
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 pf[NT];
+                bf16x8 pf[QT];
 #pragma unroll
-                for (int qt = 0; qt < NT; ++qt) {
+                for (int qt = 0; qt < QT; ++qt) {
                     const f32x4 lo = s[2 * ks][qt], hi = s[2 * ks + 1][qt];
                     const uint4 u = make_uint4(pack_bf16x2(lo.x, lo.y), pack_bf16x2(lo.z, lo.w), pack_bf16x2(hi.x, hi.y),
                                                pack_bf16x2(hi.z, hi.w));
@@ -976,7 +979,7 @@ __global__ void __launch_bounds__(WPB * 64, 2) attention_flash_kernel(const unsi
                     const s16x8 t = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
                     const bf16x8 vf = __builtin_bit_cast(bf16x8, t);
 #pragma unroll
-                    for (int qt = 0; qt < NT; ++qt)
+                    for (int qt = 0; qt < QT; ++qt)
                         o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[dt][qt], 0, 0, 0);
                 }
             }
@@ -985,7 +988,7 @@ __global__ void __launch_bounds__(WPB * 64, 2) attention_flash_kernel(const unsi
 
     if (!wave_active) return;
 #pragma unroll
-    for (int qt = 0; qt < NT; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         const int qi = q0 + qt * 16 + fr;
         if (qi >= L) continue;
         const float inv = 1.0f / l_run[qt];
