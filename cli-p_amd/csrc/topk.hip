@@ -75,6 +75,8 @@ struct ScanArgs {
     unsigned* gcnt;         // [32] entries used per query; zeroed on the stream before the launch
     long long cap;
     const unsigned* run_if; // optional device flag: the kernel exits at once when *run_if == 0
+    int q_total;            // gridDim.y > 1 only: queries over all groups; group y takes queries [y*QA, y*QA + QA) and
+                            // the matching slices of q, thr_in, cand, gcnt
 };
 
 // PREPASS only changes the kernel's NAME (profilers average per name; the threshold pre-pass over
@@ -89,6 +91,14 @@ __global__ void __launch_bounds__(256) scan_topk_f32_kernel(ScanArgs a) {
     constexpr int NT = E / 16;      // float4 per lane per 16-row tile
     constexpr int NCH = NT / 8;     // chunks of 8 float4
     if (a.run_if && *a.run_if == 0) return;       // fallback launch that is not needed (uniform)
+    if (gridDim.y > 1) {                          // the coarse path's fallback: all query groups in one launch
+        const int y = blockIdx.y, left = a.q_total - y * a.QA;
+        a.q += (size_t)y * a.QA * E;
+        a.cand += (size_t)y * a.QA * a.cap;
+        a.gcnt += y * a.QA;
+        if (a.thr_in) a.thr_in += y * a.QA;
+        a.QA = left < a.QA ? left : a.QA;
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -257,33 +267,36 @@ __global__ void __launch_bounds__(256) scan_topk_f32_kernel(ScanArgs a) {
 // Level 1 of the coarse path's pre-pass: exact scores of the first `nrows` rows (a few thousand) for up to 64 queries
 // in ONE launch, written out unfiltered as candidate entries cand[q][row] = (score bits, row) for the radix select to
 // take the K-th best of. Same MFMA sequence per (row, query) as scan_topk_f32_kernel (score order of this file's
-// header); with no candidate buffers to keep, the 128-KiB image of 64 queries fits LDS, which the filtering kernel's
-// 32-query passes (two scans + two selects) could not. A NaN score is stored as -inf ("never ranks").
+// header). blockIdx.y picks 16 of the queries (a 32-KiB f32 image): the 25 MB of sample rows are read up to four times
+// (from L2 after the first), and in exchange a workgroup fits on a CU - LDS and registers - beside a coarse scan
+// workgroup of another batch in flight; with the 128-KiB image of all 64 queries this launch waited for that whole scan
+// to drain, and its row tile + 16 accumulators spilled 252 B. A NaN score is stored as -inf.
 template <int E>
 __global__ void __launch_bounds__(256) sample_scores_kernel(const float* __restrict__ db, long long nrows,
                                                             const float* __restrict__ q, int QA, uint2* __restrict__ cand,
                                                             long long cap, unsigned* __restrict__ gcnt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = E / 16, QG = 4;
+    constexpr int NT = E / 16, QG = 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, g = lane >> 4;
+    const int qbase = blockIdx.y * 16 * QG;
     f32x4* qimg = reinterpret_cast<f32x4*>(smem);
-    // QG*NT*64 = 8192 entries over 256 threads, 8 loads in flight per thread (one at a time cost ~10 us per block)
+    // QG*NT*64 = 2048 entries over 256 threads, 8 loads in flight per thread (one at a time cost ~10 us per block)
     for (int base = tid; base < QG * NT * 64; base += 8 * 256) {
         f32x4 v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int idx = base + j * 256;
             const int l = idx & 63, t = (idx >> 6) % NT, qg = (idx >> 6) / NT;
-            const int c_ = qg * 16 + (l & 15), g_ = l >> 4;
+            const int c_ = qbase + qg * 16 + (l & 15), g_ = l >> 4;
             v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (c_ < QA) v[j] = *reinterpret_cast<const f32x4*>(q + (size_t)c_ * E + 16 * t + 4 * g_);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) qimg[base + j * 256] = v[j];
     }
-    if (blockIdx.x == 0 && tid < QA) gcnt[tid] = (unsigned)nrows;
+    if (blockIdx.x == 0 && tid < 16 * QG && qbase + tid < QA) gcnt[qbase + tid] = (unsigned)nrows;
     __syncthreads();
     const long long ntiles = (nrows + 15) >> 4;
     const long long last_row = nrows - 1;
@@ -315,7 +328,7 @@ __global__ void __launch_bounds__(256) sample_scores_kernel(const float* __restr
         // 32 contiguous bytes of that query's list (two 16-byte stores; the four lane groups complete the 128-byte line)
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) {
-            const int qi = qg * 16 + col;
+            const int qi = qbase + qg * 16 + col;
             const long long row = tile * 16 + 4 * g;
             unsigned sb[4];
 #pragma unroll
@@ -352,9 +365,9 @@ constexpr int SEL_THREADS = 512;
 constexpr int SEL_STAGE = 12288;      // candidate entries a select block keeps in LDS (96 KiB); longer lists stream from L2
 constexpr int SEL_FIXED = 32 * 8 + (256 + 8 + 8) * 4;
 // large K leaves less room beside the K-entry result buffer; host (LDS size) and device (staging test) share this
-__host__ __device__ constexpr int sel_stage_entries(int K) {
-    return (LDS_LIMIT - SEL_FIXED - K * 8) / 8 < SEL_STAGE ? ((LDS_LIMIT - SEL_FIXED - K * 8) / 8 < 0 ? 0 : (LDS_LIMIT - SEL_FIXED - K * 8) / 8)
-                                                           : SEL_STAGE;
+__host__ __device__ constexpr int sel_stage_entries(int K, int limit = LDS_LIMIT) {
+    return (limit - SEL_FIXED - K * 8) / 8 < SEL_STAGE ? ((limit - SEL_FIXED - K * 8) / 8 < 0 ? 0 : (limit - SEL_FIXED - K * 8) / 8)
+                                                       : SEL_STAGE;
 }
 
 // One block per query: exact top-K of a dense, unsorted candidate list by MSB-first radix
@@ -606,6 +619,9 @@ __device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
 //      s_r t_q D + a_r * 1.001 ||y|| >= tau_q - 1.001 (R_max + A_max) ||f_q|| - 1e-4 R_max ||y||
 // (the last term covers f32 rounding of both sides and of the exact kernel's fmaf chain: < 512 * 2^-23 relative).
 // Divided by t_q > 0 so that the kernel's test is one convert + one multiply + one fma + one compare per pair.
+// (A second int8 digit of the query - y = t p + u p' + f', a second MFMA chain per row tile - removes the query half of
+//  the margin and was measured: 45 % fewer rows reach the exact re-scoring pass (-30 us per 64 queries at 10 M rows), but
+//  with 128 MFMAs per 32-row step the one wave per SIMD is MFMA/VALU-bound in the early segments: scans +75 us. Rejected.)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256) quantize_rows_i8_kernel(const float* __restrict__ db, long long N, int E,
@@ -734,12 +750,30 @@ struct CoarseArgs {
     unsigned* overflow;          // set to 1 when a list would exceed cap
 };
 
-// Per-wave (query, row) list in LDS. One 32-row step appends at most 2 row tiles x QG x 4 rows x 64 lanes =
-// 512*QG pairs and the flush test runs once per step, so the list holds COARSE_FLUSH + 512*QG entries: it cannot
-// overrun by construction (and the append is bound-checked all the same: a miss arms the exact fallback).
+// Per-wave (query, row) list in LDS. One (row tile, query group) block of a step appends at most 4 rows x 64 lanes =
+// 256 pairs and the flush test runs after every such block, so the list holds COARSE_FLUSH + 256 entries: it cannot
+// overrun by construction (and the append is bound-checked all the same: a miss arms the exact fallback). 6 KiB per
+// wave keeps a 64-query int8 scan workgroup at 56 KiB of LDS, so the small kernels of ANOTHER batch in flight (exact
+// re-scoring 72 KiB, selects, the sample scan 64 KiB) fit on the same CU instead of waiting for the scan to drain.
 constexpr int COARSE_FLUSH = 512;       // flush when more than this many are pending
-constexpr int coarse_list_entries(int QG) { return COARSE_FLUSH + 512 * QG; }
-constexpr size_t coarse_wave_bytes(int QG) { return (size_t)coarse_list_entries(QG) * 8 + 16; }
+constexpr int COARSE_LIST = COARSE_FLUSH + 256;
+constexpr size_t COARSE_WAVE_BYTES = (size_t)COARSE_LIST * 8 + 16;
+
+// publish a wave's pending pairs: one global atomic per pair (rare path: ~1 pair in 10^4 passes the threshold)
+__device__ __noinline__ void coarse_flush(uint2* list, int* lcnt, unsigned* gcnt, uint2* cand, long long cap, unsigned* overflow) {
+    const int lane = threadIdx.x & 63;
+    wave_lds_sync();
+    const int n = *lcnt < COARSE_LIST ? *lcnt : COARSE_LIST;
+    for (int e = lane; e < n; e += 64) {
+        const uint2 c = list[e];
+        const unsigned pos = atomicAdd(&gcnt[c.x], 1u);
+        if ((long long)pos < cap) cand[(size_t)c.x * cap + pos] = make_uint2(0u, c.y);
+        else *overflow = 1u;
+    }
+    wave_lds_sync();
+    if (lane == 0) *lcnt = 0;
+    wave_lds_sync();
+}
 
 // PREPASS only changes the kernel's NAME (the level-2 pre-pass over S2 rows must not dilute the profiler's
 // per-name average of the main scan).
@@ -749,9 +783,9 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
     constexpr int KS = E / (I8 ? 64 : 32);   // MFMA k-steps per 16-row tile (16 bytes per lane and step either way)
     constexpr int ROWB = I8 ? E : 2 * E;     // bytes per row of the coarse copy
     constexpr int SLOTS = 2 * KS;       // one step = two row tiles (32 rows): SLOTS 16-byte fragments per lane
-    constexpr int NCH = SLOTS / 8;
-    constexpr int COARSE_LIST = coarse_list_entries(QG);
-    static_assert(COARSE_LIST >= COARSE_FLUSH + 2 * QG * 4 * 64, "a step's appends must fit behind a pending flush");
+    constexpr int NIMG = QG * KS * 64;                  // 16-byte entries of one query image
+    constexpr int IMG_BYTES = NIMG * 16;
+    static_assert(COARSE_LIST >= COARSE_FLUSH + 4 * 64, "a block's appends must fit behind a pending flush");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -763,7 +797,6 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
     // of f32 queries and quantise them again); here it is a 16-byte-per-lane copy, 8 loads in flight
     uint4* qimg = reinterpret_cast<uint4*>(smem);
     {
-        constexpr int NIMG = QG * KS * 64;
         static_assert(NIMG % (8 * 256) == 0 || NIMG < 8 * 256, "image copy loop");
         for (int base = tid; base < NIMG; base += 8 * 256) {
             uint4 v[8];
@@ -774,7 +807,7 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
                 if (base + j * 256 < NIMG) qimg[base + j * 256] = v[j];
         }
     }
-    uint2* list = reinterpret_cast<uint2*>(smem + QG * KS * 1024 + (size_t)wave * coarse_wave_bytes(QG));
+    uint2* list = reinterpret_cast<uint2*>(smem + IMG_BYTES + (size_t)wave * COARSE_WAVE_BYTES);
     int* lcnt = reinterpret_cast<int*>(list + COARSE_LIST);
     if (lane == 0) *lcnt = 0;
     __syncthreads();
@@ -787,19 +820,6 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
         tau[qg] = active[qg] ? a.qmeta[128 + qg * 16 + col] : INFINITY;
         yt[qg] = (I8 && active[qg]) ? a.qmeta[64 + qg * 16 + col] : 0.f;
     }
-    auto flush = [&]() {
-        wave_lds_sync();
-        const int n = *lcnt;
-        for (int e = lane; e < n; e += 64) {
-            const uint2 c = list[e];
-            const unsigned pos = atomicAdd(&a.gcnt[c.x], 1u);
-            if ((long long)pos < a.cap) a.cand[(size_t)c.x * a.cap + pos] = make_uint2(0u, c.y);
-            else *a.overflow = 1u;
-        }
-        wave_lds_sync();
-        if (lane == 0) *lcnt = 0;
-        wave_lds_sync();
-    };
 
     // steps are counted from row 0 of the copy (row0 % 32 == 0), so row = 32 step + ... is the global row id
     const long long step0 = a.row0 >> 5;
@@ -851,36 +871,47 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int qg = 0; qg < QG; ++qg) acc[rt][qg] = AccT{0, 0, 0, 0};
+            // One slot at a time: the LDS reads of the NEXT slot's query fragments, this slot's MFMAs, then the refill of
+            // this slot's register with the next step's fragment. A load can only be issued once the MFMAs reading its
+            // register have been, and its data is needed one step later, so a step lasts (HBM latency + the MFMA time
+            // between two refills): refilling after every slot instead of every 8 (the first version) keeps that second
+            // term at QG MFMAs - main scan 629-648 -> 619 us at 10 M rows. The sched_group_barriers state the order; no
+            // fake dependency on the accumulators is needed.
+            uint4 B[2][QG];
+            auto load_b = [&](int s_, uint4* b) {
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
+                for (int qg = 0; qg < QG; ++qg) b[qg] = qimg[(qg * KS + s_) * 64 + lane];
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(0, B[0]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int slot = 8 * c + j;
-                    const int rt = slot / KS, s_ = slot % KS;
+            for (int slot = 0; slot < SLOTS; ++slot) {
+                const int rt = slot / KS;
+                // the second row tile re-reads the fragments from LDS (left to itself the compiler keeps all of the first
+                // tile's in registers: up to 128 more VGPRs, and no other kernel's wave fits on the SIMD any more)
+                if (slot + 1 == KS) asm volatile("" ::: "memory");
+                if (slot + 1 < SLOTS) load_b((slot + 1) % KS, B[(slot + 1) & 1]);
+                const uint4* b = B[slot & 1];
 #pragma unroll
-                    for (int qg = 0; qg < QG; ++qg) {
-                        const uint4 bq = qimg[(qg * KS + s_) * 64 + lane];
-                        if constexpr (I8)
-                            acc[rt][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, T[slot]),
-                                                                                __builtin_bit_cast(i32x4, bq), acc[rt][qg], 0, 0, 0);
-                        else
-                            acc[rt][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, T[slot]),
-                                                                                  __builtin_bit_cast(bf16x8, bq), acc[rt][qg], 0, 0, 0);
-                    }
+                for (int qg = 0; qg < QG; ++qg) {
+                    if constexpr (I8)
+                        acc[rt][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, T[slot]),
+                                                                            __builtin_bit_cast(i32x4, b[qg]), acc[rt][qg], 0, 0, 0);
+                    else
+                        acc[rt][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, T[slot]),
+                                                                              __builtin_bit_cast(bf16x8, b[qg]), acc[rt][qg], 0, 0, 0);
                 }
-                // keep the refill of this chunk's registers behind its last MFMA (see scan_topk_f32_kernel)
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int qg = 0; qg < QG; ++qg) asm volatile("" : "+v"(acc[rt][qg]) : : "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int slot = 8 * c + j;
-                    T[slot] = *reinterpret_cast<const uint4*>(pn[slot / KS] + 64 * (slot % KS));
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                T[slot] = *reinterpret_cast<const uint4*>(pn[rt] + 64 * (slot % KS));
             }
+            constexpr int NBQ = QG;
+            __builtin_amdgcn_sched_group_barrier(0x100, NBQ, 0);               // slot 0's fragments
+#pragma unroll
+            for (int slot = 0; slot < SLOTS; ++slot) {
+                if (slot + 1 < SLOTS) __builtin_amdgcn_sched_group_barrier(0x100, NBQ, 0);   // DS reads: next slot's fragments
+                __builtin_amdgcn_sched_group_barrier(0x008, NBQ, 0);                         // MFMAs of this slot
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                           // VMEM read: the refill
+            }
+            __builtin_amdgcn_sched_barrier(0);
 
             // value compared with tau[qg]: the bf16 score itself, or (int8) D * s_r + a_r * 1.001 ||y|| / t_q
             float val[2][QG][4];
@@ -908,7 +939,7 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                    for (int qg = 0; qg < QG; ++qg)
+                    for (int qg = 0; qg < QG; ++qg) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const long long row = step * 32 + rt * 16 + 4 * g + r;
@@ -918,8 +949,9 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
                                 else *a.overflow = 1u;       // unreachable (static_assert above); never write past the list
                             }
                         }
-                wave_lds_sync();
-                if (*lcnt > COARSE_FLUSH) flush();
+                        wave_lds_sync();
+                        if (*lcnt > COARSE_FLUSH) coarse_flush(list, lcnt, a.gcnt, a.cand, a.cap, a.overflow);
+                    }
             }
             if (!has_next) break;
             step = nxt;
@@ -1013,14 +1045,16 @@ __global__ void __launch_bounds__(256) rescore_pairs_kernel(const float* __restr
 }
 
 struct Plan {
-    int C, waves, QA, QG, grid, grid_sample, wave_bytes;
+    int C, waves, QA, QG, grid, grid_sample, wave_bytes, stage;
     size_t lds_scan, lds_sel;
     long long NL, NL_sample, cap, sample_rows;
     bool sample;
 };
 
 // Shared by workspace sizing and launch so both always agree.
-bool make_plan(long long N, int E, int Q, int K, Plan& p) {
+// lds_limit: what a workgroup of the exact scan or a select may take (the coarse path asks for COARSE_SIDE_LDS so its
+// side kernels fit on a CU beside a coarse scan workgroup of another batch in flight)
+bool make_plan(long long N, int E, int Q, int K, Plan& p, int lds_limit = LDS_LIMIT) {
     if (N < 0 || Q < 1 || K < 1 || (E != 512 && E != 768)) return false;
     p.C = (int)align_up((size_t)K + 16, 16);
     p.waves = 0;
@@ -1028,7 +1062,7 @@ bool make_plan(long long N, int E, int Q, int K, Plan& p) {
     for (int w = 4; w >= 1 && p.waves == 0; w >>= 1)
         for (int qg = (Q > 16 ? 2 : 1); qg >= 1; --qg) {
             const int qimg = qg * (E / 16) * 1024;
-            const long long per_wave = (LDS_LIMIT - qimg) / w - 256;
+            const long long per_wave = (lds_limit - qimg) / w - 256;
             const long long fit = per_wave / ((long long)p.C * 8) - 1;     // queries that fit beside scratch
             const int qwant = Q < 16 * qg ? Q : 16 * qg;
             if (fit >= qwant || (qg == 1 && fit >= 1)) {
@@ -1037,9 +1071,10 @@ bool make_plan(long long N, int E, int Q, int K, Plan& p) {
             }
         }
     if (p.waves == 0) return false;
-    if (SEL_FIXED + (long long)K * 8 > LDS_LIMIT) return false;
-    p.lds_sel = SEL_FIXED + (size_t)K * 8 + (size_t)sel_stage_entries(K) * 8;
-    if (p.lds_sel > (size_t)LDS_LIMIT) return false;
+    if (SEL_FIXED + (long long)K * 8 > lds_limit) return false;
+    p.stage = sel_stage_entries(K, lds_limit);
+    p.lds_sel = SEL_FIXED + (size_t)K * 8 + (size_t)p.stage * 8;
+    if (p.lds_sel > (size_t)lds_limit) return false;
     const int qimg = p.QG * (E / 16) * 1024;
     p.wave_bytes = (p.QA + 1) * p.C * 8 + 256;
     p.lds_scan = (size_t)qimg + (size_t)p.waves * p.wave_bytes;
@@ -1070,24 +1105,25 @@ int opt_in_lds(const void* fn, size_t bytes) {
 }
 
 template <int E, bool PREPASS, int QG>
-int launch_scan_t(const ScanArgs& a, int grid, int waves, size_t lds, hipStream_t st, hipEvent_t* ev) {
+int launch_scan_t(const ScanArgs& a, int grid, int waves, size_t lds, hipStream_t st, hipEvent_t* ev, int ny) {
     const void* fn = (const void*)scan_topk_f32_kernel<E, PREPASS, QG>;
     if (int rc = opt_in_lds(fn, lds)) return rc;
     // measurement: plain event records around the launch (for a millisecond-scale kernel they agree
     // with rocprofv3's dispatch time to <1 %; hipExtLaunchKernel's start/stop events read ~7 % long here)
     if (ev) (void)hipEventRecord(ev[0], st);
-    hipLaunchKernelGGL((scan_topk_f32_kernel<E, PREPASS, QG>), dim3(grid), dim3(waves * 64), lds, st, a);
+    hipLaunchKernelGGL((scan_topk_f32_kernel<E, PREPASS, QG>), dim3(grid, ny), dim3(waves * 64), lds, st, a);
     if (ev) (void)hipEventRecord(ev[1], st);
     CLIPMI_CHECK_LAUNCH("scan_topk_f32_kernel");
     return 0;
 }
 
 template <bool PREPASS>
-int launch_scan(int E, int QG, const ScanArgs& a, int grid, int waves, size_t lds, hipStream_t st, hipEvent_t* ev = nullptr) {
-    if (E == 512) return QG == 2 ? launch_scan_t<512, PREPASS, 2>(a, grid, waves, lds, st, ev)
-                                 : launch_scan_t<512, PREPASS, 1>(a, grid, waves, lds, st, ev);
-    return QG == 2 ? launch_scan_t<768, PREPASS, 2>(a, grid, waves, lds, st, ev)
-                   : launch_scan_t<768, PREPASS, 1>(a, grid, waves, lds, st, ev);
+int launch_scan(int E, int QG, const ScanArgs& a, int grid, int waves, size_t lds, hipStream_t st, hipEvent_t* ev = nullptr,
+                int ny = 1) {
+    if (E == 512) return QG == 2 ? launch_scan_t<512, PREPASS, 2>(a, grid, waves, lds, st, ev, ny)
+                                 : launch_scan_t<512, PREPASS, 1>(a, grid, waves, lds, st, ev, ny);
+    return QG == 2 ? launch_scan_t<768, PREPASS, 2>(a, grid, waves, lds, st, ev, ny)
+                   : launch_scan_t<768, PREPASS, 1>(a, grid, waves, lds, st, ev, ny);
 }
 
 }  // namespace
@@ -1148,6 +1184,7 @@ static int topk_ip_impl(const void* db_dev, int db_dtype, int64_t N, int E, cons
         a.cap = p.cap;
         a.thr_in = nullptr;
         a.run_if = nullptr;
+        a.q_total = 0;
         if (p.sample) {
             // pre-pass: exact K-th best score of the first S rows = a valid lower bound for the
             // K-th best of all rows; the main pass then only buffers scores >= that bound
@@ -1180,6 +1217,10 @@ extern "C" int clipmi_topk_ip(const void* db_dev, int db_dtype, int64_t N, int E
 namespace clipmi {
 namespace {
 constexpr long long COARSE_CAP = 1ll << 18;      // candidate slots per query of the coarse pass
+constexpr int COARSE_SIDE_LDS = 100 * 1024;      // LDS of every kernel of the coarse path other than the scans: a 64-query
+                                                 // int8 scan workgroup of an early segment takes 56 KiB, so one of these
+                                                 // (from another batch in flight) fits beside it
+constexpr int COARSE_MAIN_LDS = 104 * 1024;      // LDS the last segment's scan reserves, see launch_coarse
 constexpr int COARSE_Q = 64;                     // queries per coarse pass. (128 per pass was tried: its 128-KiB query image
                                                  // leaves LDS for only 2 waves per CU = 2 of 4 SIMDs, and the pass turns
                                                  // MFMA-bound: 5.29 ms per 128 queries vs 2 x 2.21 ms)
@@ -1189,7 +1230,14 @@ int launch_coarse(const CoarseArgs& a, long long nsteps, hipStream_t st, hipEven
     static_assert(QG <= 4, "64 queries per pass at most");
     constexpr int WAVES = 4;
     // the final publication reuses the head of the query image for 3 * 16 QG counters: keep >= 1 KiB
-    const size_t lds = (size_t)QG * (512 / (I8 ? 64 : 32)) * 1024 + WAVES * coarse_wave_bytes(QG);
+    size_t lds = (size_t)QG * (512 / (I8 ? 64 : 32)) * 1024 + WAVES * COARSE_WAVE_BYTES;
+    // The LAST segment's scan (3/4 of the rows) reserves COARSE_MAIN_LDS although it uses 56-88 KiB: with two batches in
+    // flight on two streams, two such scans then cannot share a CU. Sharing halves each one's bandwidth, both finish
+    // together and both batches run their latency-bound side kernels at the same time with HBM idle (1.06-1.08 ms per 64
+    // queries at 10 M rows); kept apart the streams settle half a batch out of phase - one scans while the other runs
+    // its pre-pass, early segments, re-scoring and selects, which DO fit beside the early segments' unpadded scans - and a
+    // batch takes 0.97-1.00 ms. (Padding every scan, i.e. the 114 KiB all of them used to need: 1.02-1.04 ms.)
+    if (!PREPASS && lds < (size_t)COARSE_MAIN_LDS) lds = COARSE_MAIN_LDS;
     if (lds > (size_t)LDS_LIMIT) return set_err(CLIPMI_EUNSUPPORTED, "scan_coarse: %zu B of LDS", lds);
     if (int rc = opt_in_lds((const void*)scan_coarse_kernel<512, QG, PREPASS, I8>, lds)) return rc;
     long long g_ = (nsteps + WAVES - 1) / WAVES;
@@ -1201,19 +1249,26 @@ int launch_coarse(const CoarseArgs& a, long long nsteps, hipStream_t st, hipEven
     return 0;
 }
 
+constexpr int COARSE_CTL = 2 * COARSE_Q + 4;      // fallback counters | coarse counters | overflow flag
 struct CoarseWs {
     uint2* cand_e; uint2* cand_c; unsigned* gcnt_e; unsigned* gcnt_c; float* thr0; float* tauc; unsigned* flag;
     unsigned* last_m; float* qmeta; uint4* qimage;
 };
 
+// the plan of the coarse path's side kernels (sample select, fallback scan + select): within COARSE_SIDE_LDS when K allows
+bool coarse_plan(long long N, int E, int Q, int K, Plan& p) {
+    const int q = Q > 32 ? 32 : Q;
+    return make_plan(N, E, q, K, p, COARSE_SIDE_LDS) || make_plan(N, E, q, K, p);
+}
+
 size_t carve_coarse(const Plan& p, void* base, size_t cap, CoarseWs* w) {
     Arena ar(base ? base : reinterpret_cast<void*>(256), cap);
     CoarseWs x;
-    x.cand_e = ar.take<uint2>((size_t)p.QA * p.cap);
+    x.cand_e = ar.take<uint2>((size_t)COARSE_Q * p.cap);   // the fallback's lists, all query groups side by side
     x.cand_c = ar.take<uint2>((size_t)COARSE_Q * COARSE_CAP);
-    x.gcnt_e = ar.take<unsigned>(32 + COARSE_Q + 4);   // one control block, cleared by ONE memset per call
-    x.gcnt_c = x.gcnt_e + 32;
-    x.flag = x.gcnt_e + 32 + COARSE_Q;
+    x.gcnt_e = ar.take<unsigned>(COARSE_CTL);          // one control block, cleared by coarse_prep_kernel
+    x.gcnt_c = x.gcnt_e + COARSE_Q;
+    x.flag = x.gcnt_e + 2 * COARSE_Q;
     x.thr0 = ar.take<float>(COARSE_Q);
     x.tauc = ar.take<float>(COARSE_Q);
     x.last_m = ar.take<unsigned>(COARSE_Q);
@@ -1235,7 +1290,7 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
     if (E != 512 || N < SAMPLE_MIN_N) return set_err(CLIPMI_EUNSUPPORTED, "topk_ip_coarse: needs E = 512 and N >= %d", SAMPLE_MIN_N);
     if (!(rmax > 0.f) || N >= (1ll << 32) - 1) return set_err(CLIPMI_EINVAL, "topk_ip_coarse: rmax=%g N=%lld", rmax, (long long)N);
     Plan p;
-    if (!make_plan(N, E, Q > 32 ? 32 : Q, K, p)) return set_err(CLIPMI_EINVAL, "topk_ip_coarse: unsupported Q=%d K=%d", Q, K);
+    if (!coarse_plan(N, E, Q, K, p)) return set_err(CLIPMI_EINVAL, "topk_ip_coarse: unsupported Q=%d K=%d", Q, K);
     if (ws_bytes < carve_coarse(p, nullptr, ~(size_t)0, nullptr))
         return set_err(CLIPMI_EWORKSPACE, "topk_ip_coarse: workspace %zu too small", ws_bytes);
     CoarseWs w;
@@ -1253,10 +1308,10 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             const int nq = (qa + 15) / 16 * 16;
             if (i8)
                 hipLaunchKernelGGL(coarse_prep_kernel<true>, dim3(nq / 4), dim3(256), 0, st, qg, E, rmax, amax, qa, w.qmeta, w.qimage,
-                                   w.gcnt_e, 32 + COARSE_Q + 4);
+                                   w.gcnt_e, COARSE_CTL);
             else
                 hipLaunchKernelGGL(coarse_prep_kernel<false>, dim3(nq / 4), dim3(256), 0, st, qg, E, rmax, amax, qa, w.qmeta, w.qimage,
-                                   w.gcnt_e, 32 + COARSE_Q + 4);
+                                   w.gcnt_e, COARSE_CTL);
             CLIPMI_CHECK_LAUNCH("coarse_prep_kernel");
         }
         ScanArgs a;
@@ -1274,7 +1329,7 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
         // level 1 only has to thin level 2's candidates (S2*K/S1 per query): 8 k rows are enough, and its
         // select then ranks 8 k entries per query instead of 32 k
         // (12288 = what the select keeps in LDS; N >= 65536 here)
-        long long S1 = sel_stage_entries(K) < 4096 ? 4096 : (sel_stage_entries(K) / 16) * 16;
+        long long S1 = p.stage < 4096 ? 4096 : (p.stage / 16) * 16;
         if (S1 > 12288) S1 = 12288;
         if (S2 < S1) S2 = S1;
         // (one unfiltered scan of S2 rows was tried for small shards: its 32 k-entry selects cost more
@@ -1305,9 +1360,9 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(12, qa), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
                                static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, COARSE_CAP);
             CLIPMI_CHECK_LAUNCH("rescore_pairs_kernel");
-            // 4096 staged entries (32 KiB of LDS) cover these lists; a select block then fits on a CU beside a scan
-            // workgroup of ANOTHER batch in flight (114 KiB), which the 96-KiB staging of the sample select does not
-            const int scap = sel_stage_entries(K) < 4096 ? sel_stage_entries(K) : 4096;
+            // 4096 staged entries (32 KiB of LDS) cover these lists; a select block then fits on a CU even beside the
+            // last segment's scan of ANOTHER batch in flight (104 KiB), which the 96-KiB staging of the sample select does not
+            const int scap = p.stage < 4096 ? p.stage : 4096;
             hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), SEL_FIXED + (size_t)K * 8 + (size_t)scap * 8, st,
                                w.cand_c, w.gcnt_c, COARSE_CAP, K, idb, os, oi, thr_out, (const unsigned*)nullptr, m_out, keep, scap,
                                thr_out ? w.qmeta : (float*)nullptr);
@@ -1317,16 +1372,16 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
         // level 1 (exact, unfiltered, all <= 64 queries in one launch): scores of the first rows -> K-th best per query
         {
             const long long rows1 = two_level ? S1 : S2;
-            const size_t lds1 = (size_t)4 * (512 / 16) * 1024;
+            const size_t lds1 = (size_t)(512 / 16) * 1024;
             if (int rc = opt_in_lds((const void*)sample_scores_kernel<512>, lds1)) return rc;
             long long gs = ((rows1 + 15) / 16 + 3) / 4;
             if (gs > NUM_CU) gs = NUM_CU;
-            hipLaunchKernelGGL(sample_scores_kernel<512>, dim3((unsigned)gs), dim3(256), lds1, st, static_cast<const float*>(db_dev),
+            hipLaunchKernelGGL(sample_scores_kernel<512>, dim3((unsigned)gs, (unsigned)((qa + 15) / 16)), dim3(256), lds1, st, static_cast<const float*>(db_dev),
                                rows1, qg, qa, w.cand_c, (long long)COARSE_CAP, w.gcnt_c);
             CLIPMI_CHECK_LAUNCH("sample_scores_kernel");
             hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, w.cand_c, w.gcnt_c, COARSE_CAP, K,
                                (long long)0, (float*)nullptr, (long long*)nullptr, w.thr0, (const unsigned*)nullptr,
-                               (unsigned*)nullptr, 0, -1, w.qmeta);
+                               (unsigned*)nullptr, 0, p.stage, w.qmeta);
             CLIPMI_CHECK_LAUNCH("select_topk_kernel(sample 1)");
         }
         // Segments of the copy, each scanned ONCE: [0, S2) (level 2 of the pre-pass, threshold from level 1), then
@@ -1352,13 +1407,14 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
         if (int rc = coarse_pass(r_done, N, false, nullptr, os_final, oi_final, (long long)id_base, scan_ev, w.last_m, two_level ? 2 : 0))
             return rc;
         // 6. fallback: exact scan + select, exiting at once unless a coarse list overflowed
-        for (int sub = 0; sub < qa; sub += p.QA) {
-            const int qs = (qa - sub) < p.QA ? (qa - sub) : p.QA;
-            a.q = qg + (size_t)sub * E; a.QA = qs; a.nrows = N; a.thr_in = w.thr0 + sub; a.run_if = w.flag;
-            if (int rc2 = launch_scan<false>(E, p.QG, a, p.grid, p.waves, p.lds_scan, st)) return rc2;
-            hipLaunchKernelGGL(select_topk_kernel, dim3(qs), dim3(SEL_THREADS), p.lds_sel, st, w.cand_e, w.gcnt_e, p.cap, K,
-                               (long long)id_base, out_score_dev + (size_t)(q0 + sub) * K,
-                               (long long*)out_id_dev + (size_t)(q0 + sub) * K, (float*)nullptr, (const unsigned*)w.flag);
+        //    (two launches: the exact scan takes its groups of p.QA queries as blockIdx.y, each with its own lists)
+        {
+            const int ny = (qa + p.QA - 1) / p.QA;
+            a.q = qg; a.QA = qa < p.QA ? qa : p.QA; a.q_total = qa; a.nrows = N; a.thr_in = w.thr0; a.run_if = w.flag;
+            if (int rc2 = launch_scan<false>(E, p.QG, a, p.grid, p.waves, p.lds_scan, st, nullptr, ny)) return rc2;
+            hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, w.cand_e, w.gcnt_e, p.cap, K,
+                               (long long)id_base, os_final, oi_final, (float*)nullptr, (const unsigned*)w.flag,
+                               (unsigned*)nullptr, 0, p.stage, (float*)nullptr);
             CLIPMI_CHECK_LAUNCH("select_topk_kernel(fallback)");
         }
     }
@@ -1369,7 +1425,7 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
 
 extern "C" size_t clipmi_topk_ip_coarse_workspace_bytes(int64_t N, int E, int Q, int K) {
     Plan p;
-    if (E != 512 || N < SAMPLE_MIN_N || !make_plan(N, E, Q > 32 ? 32 : Q, K, p)) {
+    if (E != 512 || N < SAMPLE_MIN_N || !coarse_plan(N, E, Q, K, p)) {
         set_err(CLIPMI_EUNSUPPORTED, "topk_ip_coarse: needs E = 512, N >= %d and a supported K", SAMPLE_MIN_N);
         return 0;
     }
@@ -1450,7 +1506,7 @@ static int dbg_coarse_scan_ms(const void* db_dev, const void* db_bf16_dev, bool 
     if (rc == 0 && survivors) {       // rows that survived the coarse pass, summed over the Q queries of the last call
         Plan p;
         CoarseWs w;
-        make_plan(N, E, Q > 32 ? 32 : Q, K, p);
+        coarse_plan(N, E, Q, K, p);
         carve_coarse(p, ws_dev, ws_bytes, &w);
         unsigned host[COARSE_Q];
         if (hipStreamSynchronize(as_stream(stream)) != hipSuccess ||
