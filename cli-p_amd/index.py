@@ -176,6 +176,8 @@ class IndexFlatIP:
         elif coarse:
             dbh, rmax = self.matrix_bf16()
             coarse = rmax > 0.0 and np.isfinite(rmax)
+        if coarse and Q >= 2 * self.PASS_Q and self.batches_in_flight > 1 and not self._in_pipeline:
+            return self._search_pipelined(q, K, out)
         need = (L.clipmi_topk_ip_coarse_workspace_bytes if coarse else L.clipmi_topk_ip_workspace_bytes)(N, self.d, Q, K)
         if need == 0:
             raise _lib.ClipmiError("topk_ip: " + _lib.last_error())
@@ -206,6 +208,40 @@ class IndexFlatIP:
                               out_s.data_ptr(), out_i.data_ptr(), ws.data_ptr(), ws.numel(),
                               _lib.stream_ptr(self.device))
         _lib.check(rc, "clipmi_topk_ip")
+        return out_s, out_i
+
+    PASS_Q = 64                   # queries of one coarse pass (csrc/topk.hip COARSE_Q)
+    batches_in_flight = 2         # 64-query passes of ONE large search kept in flight on internal streams (1 = off)
+    _in_pipeline = False
+
+    def _search_pipelined(self, q, K, out):
+        """A search of >= 128 queries on the coarse path: its 64-query passes alternate between two internal HIP streams
+        (each with its own workspace), so one pass's latency-bound side kernels run beside the other's HBM-bound scan -
+        what bench.py measures as "two batches in flight" (0.97-1.03 vs 1.09-1.10 ms per pass at 10 M rows). Same calls,
+        same results; the caller's stream waits for both before anything after the search runs."""
+        Q = q.shape[0]
+        if out is None:
+            out_s = torch.empty((Q, K), dtype=torch.float32, device=self.device)
+            out_i = torch.empty((Q, K), dtype=torch.int64, device=self.device)
+        else:
+            out_s, out_i = out
+        cur = torch.cuda.current_stream(self.device)
+        pool = self.__dict__.setdefault("_side_streams", {})
+        side = pool.get(cur.cuda_stream)
+        if side is None:
+            side = pool[cur.cuda_stream] = [torch.cuda.Stream(device=self.device) for _ in range(self.batches_in_flight)]
+        for s_ in side:
+            s_.wait_stream(cur)                       # q, the outputs and the index copies are ready
+        self._in_pipeline = True
+        try:
+            for gi, lo in enumerate(range(0, Q, self.PASS_Q)):
+                hi = min(Q, lo + self.PASS_Q)
+                with torch.cuda.stream(side[gi % len(side)]):
+                    self.search_device(q[lo:hi], K, out=(out_s[lo:hi], out_i[lo:hi]))
+        finally:
+            self._in_pipeline = False
+        for s_ in side:
+            cur.wait_stream(s_)
         return out_s, out_i
 
     def search(self, x, K):

@@ -393,6 +393,34 @@ def test_two_search_batches_in_flight_on_two_streams(clipmi, gpu, topk_oracle):
     assert len(idx._ws) >= 2
 
 
+@pytest.mark.parametrize("kind", ["int8", "bf16"])
+def test_large_query_batch_is_pipelined_and_exact(clipmi, gpu, topk_oracle, kind):
+    """A search of >= 128 queries runs its 64-query passes alternately on two internal streams (index.py
+    _search_pipelined): the oracle's bits, the same bits as the one-stream form, and usable back to back."""
+    rng = np.random.default_rng(4242)
+    N, Q, K = 90_000, 200, 51
+    db = unit_rows(rng, N, 512)
+    q = unit_rows(rng, Q, 512)
+    idx = clipmi.IndexFlatIP(512, device=gpu, coarse=kind)
+    idx.add(db)
+    tq = torch.from_numpy(q).to(gpu)
+    assert idx.batches_in_flight == 2
+    outs = [idx.search_device(tq, K) for _ in range(3)]
+    outs = [(s.clone(), i.clone()) for s, i in outs]
+    assert len(idx._side_streams) == 1 and len(idx._ws) >= 2
+    idx.batches_in_flight = 1
+    s1, i1 = idx.search_device(tq, K)
+    torch.cuda.synchronize()
+    D, I = topk_oracle.topk(db, q, K)
+    _assert_exact(s1.cpu().numpy(), i1.cpu().numpy(), D, I, "one stream")
+    for s, i in outs:
+        _assert_exact(s.cpu().numpy(), i.cpu().numpy(), D, I, "pipelined")
+    # numpy front end (query-index.py:111's call) goes the same way
+    idx.batches_in_flight = 2
+    Dn, In = idx.search(q, K)
+    _assert_exact(Dn, In, D, I, "search()")
+
+
 def test_quantize_rows_i8_matches_numpy(clipmi, gpu):
     """clipmi_quantize_rows_i8: scale = max|x| / 127, q = rint(x / scale) (round half to even), error norm >= the
     true one and within 0.2 % of it."""
