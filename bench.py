@@ -299,7 +299,7 @@ def scan_probe(L, idx, q, Qp, K, dev, kind):
             "scan_bytes_per_launch")
 
 
-def search_leg(L, a, dev, dist, world, rank, rows_total, n_local, seed, steps, warmup):
+def search_leg(L, a, dev, dist, world, rank, rows_total, n_local, seed, steps, warmup, large_q=0):
     """One search measurement: this rank's `n_local` rows of a `rows_total`-row index, Q queries, K = k + 1."""
     K, Q = a.k + 1, a.queries
     db = unit_rows_device(n_local, dev, seed + rank)          # every shard its own rows (no cross-shard duplicates)
@@ -356,6 +356,19 @@ def search_leg(L, a, dev, dist, world, rank, rows_total, n_local, seed, steps, w
                         "coarse_survivors_per_query": surv,
                         "whole_call_gbs_per_gpu": scan_bytes * passes * steps / dt_s / 1e9,
                         "whole_call_frac": scan_bytes * passes * steps / dt_s / 1e9 / PEAK_HBM_GBS}}
+    # ONE search call of 1024 queries: the product's own pipelining of 64-query passes (IndexFlatIP._search_pipelined) -
+    # what a caller with many queries gets without managing streams. Reported beside the 64-query number, never as it.
+    if coarse and large_q > 0:
+        gq.manual_seed(3)
+        qL = torch.randn((large_q, 512), generator=gq, device=dev)
+        qL = qL / qL.norm(dim=1, keepdim=True)
+
+        def big_step():
+            res[0] = searcher.search_device(qL, K)
+        dt_big = timed(big_step, 3, 1, dist, world)
+        out["one_call_many_queries"] = {"queries": large_q, "value": large_q * 3 / dt_big, "unit": "queries/s",
+                                        "ms_per_call": dt_big / 3 * 1e3,
+                                        "passes_in_flight": getattr(idx, "batches_in_flight", 1)}
     del searcher, idx, db
     torch.cuda.empty_cache()
     return out
@@ -470,7 +483,7 @@ def main():
 
     # ---------------- search: 10M x 512 f32 split over the ranks, Q queries, K = k + 1 -----------
     lo, hi = clipmi.shard_bounds(a.rows, world, rank)
-    search = search_leg(L, a, dev, dist, world, rank, a.rows, hi - lo, 1000, a.steps, a.warmup)
+    search = search_leg(L, a, dev, dist, world, rank, a.rows, hi - lo, 1000, a.steps, a.warmup, large_q=0 if a.quick else 1024)
     search["metric"] = f"queries/sec top-{a.k} over {a.rows}x512 flat IP (exact results, f32 scores)"
     search["scaling"] = "strong"
     # configs[4] search half: 12.5 M rows on every rank (weak): at N = 8 a 100 M x 512 DB

@@ -215,28 +215,33 @@ class IndexFlatIP:
     _in_pipeline = False
 
     def _search_pipelined(self, q, K, out):
-        """A search of >= 128 queries on the coarse path: its 64-query passes alternate between two internal HIP streams
-        (each with its own workspace), so one pass's latency-bound side kernels run beside the other's HBM-bound scan -
+        """A search of >= 128 queries on the coarse path: its 64-query passes alternate between the caller's stream and an
+        internal HIP stream (each with its own workspace), so one pass's latency-bound side kernels run beside the other's
+        HBM-bound scan -
         what bench.py measures as "two batches in flight" (0.97-1.03 vs 1.09-1.10 ms per pass at 10 M rows). Same calls,
-        same results; the caller's stream waits for both before anything after the search runs."""
+        same results; the caller's stream waits for the side stream before anything after the search runs."""
         Q = q.shape[0]
         if out is None:
             out_s = torch.empty((Q, K), dtype=torch.float32, device=self.device)
             out_i = torch.empty((Q, K), dtype=torch.int64, device=self.device)
         else:
             out_s, out_i = out
+        # lanes = the caller's stream + (batches_in_flight - 1) side streams. (Not two side streams: this ROCm gives only
+        # the first three streams of a process their own hardware queue and every later one shares the fourth, so two
+        # side streams created after a caller's own two ran on ONE queue, back to back - rocprofv3 Queue_Id.)
         cur = torch.cuda.current_stream(self.device)
         pool = self.__dict__.setdefault("_side_streams", {})
         side = pool.get(cur.cuda_stream)
         if side is None:
-            side = pool[cur.cuda_stream] = [torch.cuda.Stream(device=self.device) for _ in range(self.batches_in_flight)]
+            side = pool[cur.cuda_stream] = [torch.cuda.Stream(device=self.device) for _ in range(self.batches_in_flight - 1)]
+        lanes = [cur] + side
         for s_ in side:
             s_.wait_stream(cur)                       # q, the outputs and the index copies are ready
         self._in_pipeline = True
         try:
             for gi, lo in enumerate(range(0, Q, self.PASS_Q)):
                 hi = min(Q, lo + self.PASS_Q)
-                with torch.cuda.stream(side[gi % len(side)]):
+                with torch.cuda.stream(lanes[gi % len(lanes)]):
                     self.search_device(q[lo:hi], K, out=(out_s[lo:hi], out_i[lo:hi]))
         finally:
             self._in_pipeline = False

@@ -13,6 +13,13 @@ for lo in range(0, N, 1 << 20):
     x = torch.randn((min(1 << 20, N - lo), 512), generator=g, device=dev); x /= x.norm(dim=1, keepdim=True)
     idx.add(x)
 q = torch.randn((Q, 512), generator=g, device=dev); q /= q.norm(dim=1, keepdim=True)
+if os.environ.get("LQ_PRE"):          # what bench.py does first: 64-query batches on two streams of its own
+    q64 = q[:64].contiguous()
+    st = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    for i in range(8):
+        with torch.cuda.stream(st[i % 2]):
+            idx.search_device(q64, 51)
+    torch.cuda.synchronize()
 ref = None
 for rep in range(2):
     for nfl in (1, 2):
