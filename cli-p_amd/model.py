@@ -46,7 +46,7 @@ class CLIP:
         self.context_length = self.dims["ctx"]
         self.embed_dim = self.dims["embed"]
         self._ws = {}                # workspace per (HIP stream, tower): concurrent encoders never share one
-        self.max_batch = 1024        # images per kernel sequence; larger inputs are chunked
+        self.max_batch = 1024        # images per kernel sequence; larger inputs are chunked (see image_chunk)
 
     def eval(self):
         return self
@@ -66,6 +66,21 @@ class CLIP:
     def _require_gpu(self, what):
         if self.device.type != "cuda":
             raise _lib.ClipmiError(f"{what} needs the HIP path (device {self.device} is not a GPU); no CPU fallback")
+
+    def image_chunk(self):
+        """Images per kernel sequence when an input is larger than max_batch: the largest count <= max_batch whose
+        tokens fill whole rounds of 256 x 256 output tiles on the 256 CUs for the narrowest GEMM (N = width) - 870 for
+        ViT-B/32 (two rounds; 1024 would be 2.34 rounds of work in 3 rounds of time: 1740 images went 95.5 k -> 102.9 k
+        images/s with 870 + 870 instead of 1024 + 716)."""
+        W, Lv = self.dims["v_width"], self.dims["v_tokens"]
+        cols = max(1, W // 256)
+        best = 0
+        for rounds in range(1, 4096):
+            imgs = (rounds * 256 // cols) * 256 // Lv
+            if imgs > self.max_batch:
+                break
+            best = imgs
+        return best if best > 0 else self.max_batch
 
     def encode_image(self, image, normalize=False, out=None, stream=None):
         """image: [B,3,R,R] f32/bf16 (output of `transform`, already normalised) or uint8 raw RGB
@@ -88,8 +103,9 @@ class CLIP:
             out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=self.device)
         import ctypes as _C
         sp = _lib.stream_ptr(self.device) if stream is None else _C.c_void_p(int(stream))
-        for lo in range(0, B, self.max_batch):
-            hi = min(B, lo + self.max_batch)
+        step = self.max_batch if B <= self.max_batch else self.image_chunk()
+        for lo in range(0, B, step):
+            hi = min(B, lo + step)
             need = L.clipmi_encode_image_workspace_bytes(self.vision, hi - lo)
             if need == 0:
                 raise _lib.ClipmiError("encode_image: " + _lib.last_error())

@@ -11,6 +11,20 @@ import torch
 from conftest import ROOT, unit_rows
 
 
+def test_image_chunk_fills_whole_tile_rounds(clipmi):
+    """Inputs larger than max_batch are encoded in chunks whose token rows fill whole rounds of 256 x 256 tiles on 256 CUs
+    for the narrowest GEMM (model.py image_chunk): 870 images for ViT-B/32, never more than max_batch."""
+    for (W, Lv), want in {(768, 50): 870, (768, 197): 998, (1024, 577): 1022}.items():
+        m = clipmi.CLIP.__new__(clipmi.CLIP)
+        m.dims, m.max_batch = {"v_width": W, "v_tokens": Lv}, 1024
+        c = m.image_chunk()
+        assert c == want and c <= m.max_batch
+        tiles = (c * Lv + 255) // 256 * (W // 256)                    # 256 x 256 output tiles of the N = W GEMMs
+        assert tiles / ((tiles + 255) // 256 * 256) > 0.99           # the last round of 256 CUs is full too
+    m.max_batch = 10                                   # smaller than one round: falls back to max_batch-sized chunks
+    assert 0 < m.image_chunk() <= 10
+
+
 def test_shard_bounds_cover_exactly(clipmi):
     for n in (0, 1, 7, 8, 10_000_000):
         for w in (1, 2, 3, 8):
