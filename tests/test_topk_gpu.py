@@ -326,7 +326,7 @@ def test_coarse_anisotropic_db_exact_and_survivors(clipmi, gpu, topk_oracle, kin
     whether the exact fallback had to run (a list reaching its 2^18 capacity), next to the isotropic case."""
     import ctypes as C
     L = clipmi._lib.lib()
-    N, Q, K = 300_000, 64, 51
+    N, Q, K = 200_000, 64, 51
     report = {}
     for name, gen in (("isotropic", unit_rows), ("anisotropic", lambda r, n, d: _anisotropic_rows(r, n, d))):
         rng = np.random.default_rng(4242)
