@@ -46,7 +46,8 @@ class CLIP:
         self.context_length = self.dims["ctx"]
         self.embed_dim = self.dims["embed"]
         self._ws = {}                # workspace per (HIP stream, tower): concurrent encoders never share one
-        self.max_batch = 1024        # images per kernel sequence; larger inputs are chunked (see image_chunk)
+        self.max_batch = 1024        # images per kernel sequence at most (see image_chunks)
+        self.round_chunks = True     # cut inputs at whole rounds of GEMM tiles (False: max_batch-sized chunks)
 
     def eval(self):
         return self
@@ -67,20 +68,37 @@ class CLIP:
         if self.device.type != "cuda":
             raise _lib.ClipmiError(f"{what} needs the HIP path (device {self.device} is not a GPU); no CPU fallback")
 
-    def image_chunk(self):
-        """Images per kernel sequence when an input is larger than max_batch: the largest count <= max_batch whose
-        tokens fill whole rounds of 256 x 256 output tiles on the 256 CUs for the narrowest GEMM (N = width) - 870 for
-        ViT-B/32 (two rounds; 1024 would be 2.34 rounds of work in 3 rounds of time: 1740 images went 95.5 k -> 102.9 k
-        images/s with 870 + 870 instead of 1024 + 716)."""
+    def image_chunk(self, limit=None):
+        """The largest image count <= limit (default max_batch) whose tokens fill whole rounds of 256 x 256 output tiles
+        on the 256 CUs for the narrowest GEMM (N = width): 435 / 870 for ViT-B/32 (one / two rounds). 0 if even one round
+        is more than `limit` images."""
+        limit = self.max_batch if limit is None else limit
         W, Lv = self.dims["v_width"], self.dims["v_tokens"]
         cols = max(1, W // 256)
         best = 0
         for rounds in range(1, 4096):
             imgs = (rounds * 256 // cols) * 256 // Lv
-            if imgs > self.max_batch:
+            if imgs > limit:
                 break
             best = imgs
-        return best if best > 0 else self.max_batch
+        return best
+
+    def image_chunks(self, B):
+        """How encode_image cuts B images into kernel sequences: one sequence up to max_batch; above it whole-round
+        chunks first and the remainder last (1740 = 870 + 870: 95.5 k -> 102.9 k images/s, 1305 = 870 + 435: 88 k -> 101 k;
+        they used to be 1024 + rest). Cutting inputs BELOW max_batch at round boundaries was measured too
+        (tools/chunk_sweep.py): +10 % at 436 images, -9 % at 700 - the kernel choice per GEMM already handles a ragged last
+        round, so those stay whole. Results do not depend on the cut (test_encode_image_batch_invariance_and_dtypes)."""
+        if B <= self.max_batch:
+            return [B] if B > 0 else []
+        step = (self.image_chunk() if self.round_chunks else 0) or self.max_batch
+        out, left = [], B
+        while left > self.max_batch:
+            out.append(step)
+            left -= step
+        if left > 0:
+            out.append(left)
+        return out
 
     def encode_image(self, image, normalize=False, out=None, stream=None):
         """image: [B,3,R,R] f32/bf16 (output of `transform`, already normalised) or uint8 raw RGB
@@ -103,9 +121,9 @@ class CLIP:
             out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=self.device)
         import ctypes as _C
         sp = _lib.stream_ptr(self.device) if stream is None else _C.c_void_p(int(stream))
-        step = self.max_batch if B <= self.max_batch else self.image_chunk()
-        for lo in range(0, B, step):
-            hi = min(B, lo + step)
+        lo = 0
+        for n_ in self.image_chunks(B):
+            hi = lo + n_
             need = L.clipmi_encode_image_workspace_bytes(self.vision, hi - lo)
             if need == 0:
                 raise _lib.ClipmiError("encode_image: " + _lib.last_error())
@@ -114,6 +132,7 @@ class CLIP:
                                        _DTYPES[image.dtype], hi - lo, out[lo:hi].data_ptr(), int(bool(normalize)),
                                        ws.data_ptr(), ws.numel(), sp)
             _lib.check(rc, "clipmi_encode_image")
+            lo = hi
         return out
 
     def encode_text(self, text, normalize=False):

@@ -21,8 +21,11 @@ def test_image_chunk_fills_whole_tile_rounds(clipmi):
         assert c == want and c <= m.max_batch
         tiles = (c * Lv + 255) // 256 * (W // 256)                    # 256 x 256 output tiles of the N = W GEMMs
         assert tiles / ((tiles + 255) // 256 * 256) > 0.99           # the last round of 256 CUs is full too
-    m.max_batch = 10                                   # smaller than one round: falls back to max_batch-sized chunks
-    assert 0 < m.image_chunk() <= 10
+    m.dims, m.max_batch, m.round_chunks = {"v_width": 768, "v_tokens": 50}, 1024, True
+    assert m.image_chunks(512) == [512] and m.image_chunks(1024) == [1024]          # up to max_batch: one sequence
+    assert m.image_chunks(1740) == [870, 870] and m.image_chunks(1305) == [870, 435] and m.image_chunks(2000) == [870, 870, 260]
+    m.max_batch = 10                                   # smaller than one round of tiles: max_batch-sized chunks
+    assert m.image_chunk() == 0 and m.image_chunks(25) == [10, 10, 5]
 
 
 def test_shard_bounds_cover_exactly(clipmi):
