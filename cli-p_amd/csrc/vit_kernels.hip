@@ -41,30 +41,13 @@ int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int 
     if (L < 1) return set_err(CLIPMI_EINVAL, "attention: L=%d", L);
     if (L > 80) {
         if (causal) return set_err(CLIPMI_EUNSUPPORTED, "attention: causal mask with L=%d > 80", L);
-        // Default: four waves of 32 queries per workgroup (128 queries share a staged K/V block; ~120 VGPRs = four waves per
-        // SIMD, five workgroups = 20 waves per CU by LDS). CLIPMI_FLASH_QT=4 keeps round 1's 64-query waves (2 or 4 per
-        // workgroup, chosen by wasted wave slots) for A/B runs.
-        static const int qt_env = [] { const char* e = getenv("CLIPMI_FLASH_QT"); return e ? atoi(e) : 2; }();
-        if (qt_env == 2) {
-            const int qblocks = (L + 31) / 32;
-            const int g4 = (qblocks + 3) / 4;
-            const long long groups = (long long)B * heads * g4;
-            hipLaunchKernelGGL((attention_flash_kernel<4, 2>), dim3((unsigned)groups), dim3(256), 2 * 16384, st, qkv, out, B, L, heads, g4);
-            CLIPMI_CHECK_LAUNCH("attention_flash_kernel");
-            return 0;
-        }
-        // waves per workgroup (each wave = 64 queries): 4 share a staged K/V block, unless that
-        // leaves the last workgroup mostly idle (L = 577: 10 query blocks = 5 groups of 2, not 3 of 4)
-        const int qblocks = (L + 63) / 64;
-        const int g4 = (qblocks + 3) / 4, g2 = (qblocks + 1) / 2;
-        const bool use2 = g2 * 2 * 10 < g4 * 4 * 9;          // 2-wave groups waste >10 % fewer wave slots
-        const long long groups = (long long)B * heads * (use2 ? g2 : g4);
-        if (use2)
-            hipLaunchKernelGGL((attention_flash_kernel<2, 4>), dim3((unsigned)groups), dim3(128), 2 * 16384, st, qkv, out, B, L,
-                               heads, g2);
-        else
-            hipLaunchKernelGGL((attention_flash_kernel<4, 4>), dim3((unsigned)groups), dim3(256), 2 * 16384, st, qkv, out, B, L,
-                               heads, g4);
+        // four waves of 32 queries per workgroup (128 queries share a staged K/V block; 128 VGPRs = four waves per SIMD,
+        // five workgroups = 20 waves per CU by LDS). Round 1's 64-query waves (two per SIMD): 804 us per ViT-L/14@336
+        // layer at B = 266 against 741 for this shape before its VALU diet, removed.
+        const int qblocks = (L + 31) / 32;
+        const int g4 = (qblocks + 3) / 4;
+        const long long groups = (long long)B * heads * g4;
+        hipLaunchKernelGGL((attention_flash_kernel<4, 2>), dim3((unsigned)groups), dim3(256), 2 * 16384, st, qkv, out, B, L, heads, g4);
         CLIPMI_CHECK_LAUNCH("attention_flash_kernel");
         return 0;
     }

@@ -841,9 +841,11 @@ static __global__ void __launch_bounds__(256, 5) attention52x4_kernel(const unsi
 // K tile rows are 128 B with 16-byte chunks XOR-swizzled by row & 7 (conflict-free ds_read_b128 fragments);
 // the V tile is row-major for ds_read_b64_tr_b16.
 // ---------------------------------------------------------------------------------------------
-// QT = 16-query tiles per wave: 4 (64 queries; ~220 VGPRs, two waves per SIMD) or 2 (32 queries; ~120 VGPRs, four waves
-// per SIMD: with K/V staged once per workgroup either way, the smaller wave tile buys 2.5x the resident waves to overlap
-// one wave's softmax with another's MFMAs)
+// QT = 16-query tiles per wave: 2 (32 queries; 128 VGPRs, four waves per SIMD: with K/V staged once per workgroup either
+// way, the smaller wave tile buys twice the resident waves of round 1's QT = 4 to overlap one wave's softmax with
+// another's MFMAs). The block loop is VALU-bound (34 v_exp_f32 per 32 MFMAs per wave), so everything else was taken out
+// of it: per-element masking selects (the last block is a separate instantiation), the staging addresses' integer
+// multiplies (one per-lane base + uniform offsets), and the dependent MFMA pairs of S^T: 731 -> 437 instructions per block.
 template <int WPB, int QT>
 __global__ void __launch_bounds__(WPB * 64, QT == 2 ? 4 : 2) attention_flash_kernel(const unsigned short* __restrict__ qkv,
                                                                     unsigned short* __restrict__ out, int B, int L,
@@ -884,26 +886,45 @@ __global__ void __launch_bounds__(WPB * 64, QT == 2 ? 4 : 2) attention_flash_ker
     // staging by LDS-DMA (no VGPRs): a K/V block is 16 pieces of 1 KiB (8 rows x 128 B); pieces 0..7 are
     // K (16-byte chunks XOR-swizzled with row & 7 — applied on the SOURCE address, the DMA destination is
     // lane-linear), pieces 8..15 are V (plain rows). Wave w issues pieces [w*PPW, (w+1)*PPW).
+    // Source addresses: each lane keeps the address of its 16 bytes of every piece for key block 0 and adds the block's
+    // offset (one 64-bit add per piece); only a block that reaches past row L - 1 recomputes clamped rows. (Recomputing
+    // row * row_stride per piece and block cost 20 quarter-rate integer multiplies per block: with the masking selects
+    // below, ~900 of the ~2900 VALU cycles of a block against 512 MFMA cycles.)
     constexpr int PPW = 16 / WPB;
+    static_assert(PPW <= 8, "a wave's pieces are all K or all V");
+    // this lane's 16 bytes of the wave's FIRST piece for key block 0; piece i is 8 rows further (row & 7 and with it the
+    // swizzle stay the same), block k0 is k0 rows further
+    const int pc0 = wave * PPW, isv0 = pc0 >> 3;
+    const int row0 = (pc0 & 7) * 8 + (lane >> 3);
+    const unsigned short* const src0 = base + (size_t)row0 * rs + (1 + isv0) * W + (isv0 ? (lane & 7) : ((lane & 7) ^ (row0 & 7))) * 8;
     auto issue_tiles = [&](int k0, int buf) {
+        if (k0 + 64 <= L) {                                   // wave-uniform: every row of the block exists
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int pc = wave * PPW + i;
-            const int isv = pc >> 3;
-            const int row = (pc & 7) * 8 + (lane >> 3);
-            const int ch = lane & 7;
-            const int srcch = isv ? ch : (ch ^ (row & 7));
-            const int srcrow = k0 + row < L ? k0 + row : L - 1;
-            const unsigned short* src = base + (size_t)srcrow * rs + (1 + isv) * W + srcch * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(smem + buf * 16384 + pc * 1024), 16, 0, 0);
+            for (int i = 0; i < PPW; ++i) {
+                const size_t uoff = (size_t)((unsigned)(k0 + 8 * i) * (unsigned)rs);      // uniform: scalar unit
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + uoff),
+                                                 (__attribute__((address_space(3))) void*)(smem + buf * 16384 + (pc0 + i) * 1024), 16, 0, 0);
+            }
+        } else {
+            asm volatile("" ::: "memory");                    // keep the clamped form out of the common path
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                int row = k0 + row0 + 8 * i;
+                row = row < L ? row : L - 1;                  // rows past the last one read the last one (masked below)
+                const unsigned short* src = src0 + (size_t)((unsigned)(row - row0) * (unsigned)rs);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(smem + buf * 16384 + (pc0 + i) * 1024), 16, 0, 0);
+            }
         }
     };
     issue_tiles(0, 0);
 
     const float c = 0.125f * 1.4426950408889634f;     // 1/sqrt(64) * log2(e)
     const int nb = (L + 63) >> 6;
-    for (int j = 0; j < nb; ++j) {
+    // one 64-key block; MASK (compile time) = the block reaches past key L - 1: only the last block can, so the loop over
+    // the others carries no per-element selects (if-converted, they were 67 VALU instructions per block)
+    auto block = [&](auto mask_tag, int j) {
+        constexpr bool MASK = decltype(mask_tag)::value;
         const int k0 = j << 6;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of block j have landed
         __syncthreads();                                      // ... everyone's have; block j-1 is fully consumed
@@ -911,33 +932,36 @@ __global__ void __launch_bounds__(WPB * 64, QT == 2 ? 4 : 2) attention_flash_ker
         const char* kb = smem + (j & 1) * 16384;
         const char* vt = kb + 8192;
         if (wave_active) {
+            // S^T tiles: the first halves (head dims 0..31) of all NT x QT accumulators, then the second halves, so that
+            // no MFMA waits for the one before it (the two halves of one accumulator back to back did)
             f32x4 s[NT][QT];
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt) {
-                const int row = kt * 16 + fr;
-                const bf16x8 k0f = *reinterpret_cast<const bf16x8*>(kb + row * 128 + (((0 + fg) ^ (row & 7)) << 4));
-                const bf16x8 k1f = *reinterpret_cast<const bf16x8*>(kb + row * 128 + (((4 + fg) ^ (row & 7)) << 4));
+            for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt) {
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0f, qf[qt][0], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1f, qf[qt][1], a, 0, 0, 0);
-                    s[kt][qt] = a;
+                for (int kt = 0; kt < NT; ++kt) {
+                    const int row = kt * 16 + fr;
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + row * 128 + (((4 * hf + fg) ^ (row & 7)) << 4));
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][hf], hf ? s[kt][qt] : f32x4{0.f, 0.f, 0.f, 0.f},
+                                                                            0, 0, 0);
                 }
+            if constexpr (MASK) {
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (k0 + kt * 16 + 4 * fg + r >= L) s[kt][qt][r] = -INFINITY;
             }
-            const bool tail = k0 + 64 > L;            // only the last block can hold masked keys
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 float mx = -INFINITY;
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float x = s[kt][qt][r];
-                        if (tail && k0 + kt * 16 + 4 * fg + r >= L) x = -INFINITY;
-                        s[kt][qt][r] = x;
-                        mx = fmaxf(mx, x);
-                    }
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
                 mx = fmaxf(mx, __shfl_xor(mx, 16));
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
                 mx *= c;                                            // running max kept in the exp2 domain
@@ -984,7 +1008,10 @@ __global__ void __launch_bounds__(WPB * 64, QT == 2 ? 4 : 2) attention_flash_ker
                 }
             }
         }
-    }
+    };
+    for (int j = 0; j + 1 < nb; ++j) block(std::false_type{}, j);
+    if ((nb << 6) > L) block(std::true_type{}, nb - 1);
+    else block(std::false_type{}, nb - 1);
 
     if (!wave_active) return;
 #pragma unroll
