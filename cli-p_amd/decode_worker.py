@@ -1,0 +1,90 @@
+"""The Pillow part of the CLIP transform, and a worker PROCESS that runs it (host image pipeline).
+
+`load_uint8` is what `transform(image)` does before its float tail (build-index.py:47-48): open, resize the shorter side
+to n_px (bicubic), centre crop, RGB. It needs numpy and Pillow only, so this file can also run as a plain script
+
+    python decode_worker.py
+
+that serves decode requests over its stdin / stdout (see DecodePool in pipeline.py). Why processes: Pillow releases the
+GIL inside the JPEG decoder, but for small images the Python around it dominates — eight decode THREADS gave 902 images/s
+on 224 x 224 JPEGs where one gave 895; eight worker processes scale with the cores. The script is started by path, never
+imported through the package, so a worker never imports torch or touches the GPU.
+
+Protocol (binary, one request at a time per worker):
+  request : one text line  b"<n_px>\\t<shm name or ->\\t<byte offset>\\t<path utf-8>\\n"
+  response: one status byte b"1" (decoded) or b"0" (failed: not an image, unreadable - reported per file like
+            build-index.py:55-58), followed by 3*n_px*n_px raw bytes ONLY when no shared memory segment was named;
+            otherwise the pixels were written into the segment at the offset.
+"""
+import sys
+
+import numpy as np
+
+
+def load_uint8(path, n_px):
+    """Pillow part of the upstream transform: resize shorter side to n_px (bicubic), centre crop,
+    RGB; returns uint8 [3, n_px, n_px]. Identical pixels to `make_transform` before its float tail."""
+    from PIL import Image
+    img = Image.open(path)
+    w, h = img.size
+    if not (w <= h and w == n_px) and not (h <= w and h == n_px):
+        if w <= h:
+            nw, nh = n_px, int(n_px * h / w)
+        else:
+            nh, nw = n_px, int(n_px * w / h)
+        img = img.resize((nw, nh), Image.BICUBIC)
+        w, h = nw, nh
+    left = int(round((w - n_px) / 2.0))
+    top = int(round((h - n_px) / 2.0))
+    img = img.crop((left, top, left + n_px, top + n_px)).convert("RGB")
+    return np.ascontiguousarray(np.asarray(img, dtype=np.uint8).transpose(2, 0, 1))
+
+
+def serve(fin, fout):
+    """Answer requests until stdin closes."""
+    from multiprocessing import shared_memory
+    segments = {}
+    while True:
+        line = fin.readline()
+        if not line:
+            break
+        try:
+            n_px_s, shm_name, off_s, path = line.rstrip(b"\n").split(b"\t", 3)
+            n_px, off = int(n_px_s), int(off_s)
+            arr = load_uint8(path.decode("utf-8", "surrogateescape"), n_px)
+        except KeyboardInterrupt:
+            break
+        except Exception:
+            fout.write(b"0")
+            fout.flush()
+            continue
+        if shm_name == b"-":
+            fout.write(b"1")
+            fout.write(arr.tobytes())
+        else:
+            name = shm_name.decode()
+            seg = segments.get(name)
+            if seg is None:
+                if len(segments) > 8:                          # the parent rotates a few segments; drop stale handles
+                    for s in segments.values():
+                        s.close()
+                    segments.clear()
+                seg = segments[name] = shared_memory.SharedMemory(name=name)
+                try:                                           # the parent owns the segment: an attaching process must not
+                    from multiprocessing import resource_tracker   # unlink it at exit (Python < 3.13 registers attachments)
+                    resource_tracker.unregister(seg._name, "shared_memory")
+                except Exception:
+                    pass
+            n = arr.size
+            np.frombuffer(seg.buf, dtype=np.uint8, count=n, offset=off)[:] = arr.reshape(-1)
+            fout.write(b"1")
+        fout.flush()
+    for s in segments.values():
+        s.close()
+
+
+if __name__ == "__main__":
+    try:
+        serve(sys.stdin.buffer, sys.stdout.buffer)
+    except (BrokenPipeError, KeyboardInterrupt):
+        pass

@@ -13,23 +13,93 @@ import numpy as np
 import torch
 
 
-def load_uint8(path, n_px):
-    """Pillow part of the upstream transform: resize shorter side to n_px (bicubic), centre crop,
-    RGB; returns uint8 [3, n_px, n_px]. Identical pixels to `make_transform` before its float tail."""
-    from PIL import Image
-    img = Image.open(path)
-    w, h = img.size
-    if not (w <= h and w == n_px) and not (h <= w and h == n_px):
-        if w <= h:
-            nw, nh = n_px, int(n_px * h / w)
-        else:
-            nh, nw = n_px, int(n_px * w / h)
-        img = img.resize((nw, nh), Image.BICUBIC)
-        w, h = nw, nh
-    left = int(round((w - n_px) / 2.0))
-    top = int(round((h - n_px) / 2.0))
-    img = img.crop((left, top, left + n_px, top + n_px)).convert("RGB")
-    return np.ascontiguousarray(np.asarray(img, dtype=np.uint8).transpose(2, 0, 1))
+from .decode_worker import load_uint8  # noqa: E402,F401  (the Pillow part of the transform lives beside its worker script)
+
+
+class DecodePool:
+    """Worker PROCESSES for the Pillow part of the transform (decode_worker.py): decode throughput that scales with
+    the host cores also for small images, where threads are bound by the GIL. The workers are plain `python
+    decode_worker.py` children started HERE - create the pool BEFORE the process initialises the GPU (indexer.main
+    does): a process that has touched the GPU should not spawn programs on this platform. Pixels come back through
+    ONE shared-memory segment per pool (workers write their slots; no pickling, no copies through pipes)."""
+
+    def __init__(self, workers):
+        import os
+        import subprocess
+        import sys
+        self.n = max(1, int(workers))
+        script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "decode_worker.py")
+        self.procs = [subprocess.Popen([sys.executable, script], stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+                      for _ in range(self.n)]
+        self.threads = ThreadPoolExecutor(max_workers=self.n)
+        self.shm = None
+
+    def _segment(self, nbytes):
+        from multiprocessing import shared_memory
+        if self.shm is None or self.shm.size < nbytes:
+            if self.shm is not None:
+                self.shm.close()
+                self.shm.unlink()
+            self.shm = shared_memory.SharedMemory(create=True, size=int(nbytes))
+        return self.shm
+
+    def _run(self, w, jobs, n_px, name):
+        """Worker w decodes its share of the batch: (slot, path) pairs, one request at a time."""
+        p = self.procs[w]
+        ok = []
+        per = 3 * n_px * n_px
+        for slot, path in jobs:
+            p.stdin.write(b"%d\t%s\t%d\t" % (n_px, name, slot * per) + path.encode("utf-8", "surrogateescape") + b"\n")
+            p.stdin.flush()
+            st = p.stdout.read(1)
+            if st == b"":
+                raise RuntimeError("decode worker exited")
+            ok.append((slot, st == b"1"))
+        return ok
+
+    def decode(self, paths, n_px):
+        """-> (uint8 array [n_ok,3,n_px,n_px] (a copy), ok_paths, failed_paths), file order kept."""
+        n = len(paths)
+        per = 3 * n_px * n_px
+        seg = self._segment(max(1, n * per))
+        name = seg.name.encode()
+        futs = [self.threads.submit(self._run, w, [(i, paths[i]) for i in range(w, n, self.n)], n_px, name)
+                for w in range(min(self.n, n))]
+        good = np.zeros(n, dtype=bool)
+        for f in futs:
+            for slot, fine in f.result():
+                good[slot] = fine
+        arr = np.frombuffer(seg.buf, dtype=np.uint8, count=n * per).reshape(n, 3, n_px, n_px)
+        out = arr[good].copy() if not good.all() else arr.copy()
+        ok = [p for p, g_ in zip(paths, good) if g_]
+        bad = [p for p, g_ in zip(paths, good) if not g_]
+        return out, ok, bad
+
+    def close(self):
+        for p in self.procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=5)
+            except Exception:
+                p.kill()
+        self.threads.shutdown(wait=False)
+        if self.shm is not None:
+            try:
+                self.shm.close()
+                self.shm.unlink()
+            except Exception:
+                pass
+            self.shm = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def _load_safe(args):
@@ -42,21 +112,26 @@ def _load_safe(args):
         return None
 
 
-def encode_files(model, paths, batch=256, workers=8):
+def encode_files(model, paths, batch=256, workers=8, pool=None):
     """Generator over batches: yields (ok_paths, features f32 [n,E] numpy normalised, failed_paths).
-    Decode runs on `workers` threads (Pillow releases the GIL while decoding)."""
+    Decode runs in the worker processes of `pool` (a DecodePool) when given, else on `workers` threads (Pillow
+    releases the GIL while decoding, which is enough for large photos and not for small images)."""
     n_px = model.visual.input_resolution
     dev = model.device
     use_gpu = dev.type == "cuda"
     copy_stream = torch.cuda.Stream(device=dev) if use_gpu else None
 
     def stage(chunk):
-        arrs = list(pool.map(_load_safe, [(p, n_px) for p in chunk]))
-        ok = [p for p, a in zip(chunk, arrs) if a is not None]
-        bad = [p for p, a in zip(chunk, arrs) if a is None]
+        if pool is not None:
+            stacked, ok, bad = pool.decode(chunk, n_px)
+        else:
+            arrs = list(tpool.map(_load_safe, [(p, n_px) for p in chunk]))
+            ok = [p for p, a in zip(chunk, arrs) if a is not None]
+            bad = [p for p, a in zip(chunk, arrs) if a is None]
+            stacked = np.stack([a for a in arrs if a is not None]) if ok else None
         if not ok:
             return ok, bad, None, None
-        host = torch.from_numpy(np.stack([a for a in arrs if a is not None]))
+        host = torch.from_numpy(stacked)
         if use_gpu:
             host = host.pin_memory()
             with torch.cuda.stream(copy_stream):
@@ -67,7 +142,7 @@ def encode_files(model, paths, batch=256, workers=8):
         return ok, bad, host, None
 
     chunks = [paths[i:i + batch] for i in range(0, len(paths), batch)]
-    with ThreadPoolExecutor(max_workers=workers) as pool, ThreadPoolExecutor(max_workers=1) as stager:
+    with ThreadPoolExecutor(max_workers=workers) as tpool, ThreadPoolExecutor(max_workers=1) as stager:
         nxt = stager.submit(stage, chunks[0]) if chunks else None
         for ci in range(len(chunks)):
             ok, bad, devt, ev = nxt.result()

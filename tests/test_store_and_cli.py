@@ -88,6 +88,35 @@ def test_pipeline_uint8_equals_transform_pixels(clipmi, tmp_path):
     assert np.array_equal(clipmi.make_transform(224)(Image.open(p)).numpy(), (u8.astype(np.float32) / 255.0 - mean) / std)
 
 
+def test_decode_pool_matches_in_process_decode(clipmi, tmp_path):
+    """Worker processes (pipeline.DecodePool -> decode_worker.py) return the pixels load_uint8 returns, in file order,
+    report a file that does not decode instead of failing (build-index.py:55-58), and feed encode_files."""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    paths = []
+    for i, (h, w, ext) in enumerate([(224, 224, "jpg"), (300, 500, "png"), (640, 480, "jpg"), (224, 224, "png"), (100, 90, "jpg")]):
+        p = str(tmp_path / f"img_{i}.{ext}")
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(p)
+        paths.append(p)
+    bad = str(tmp_path / "broken.jpg")
+    with open(bad, "wb") as f:
+        f.write(b"not an image")
+    mixed = paths[:2] + [bad] + paths[2:] + [str(tmp_path / "missing.jpg")]
+    with clipmi.pipeline.DecodePool(3) as pool:
+        arr, ok, failed = pool.decode(mixed, 224)
+        assert ok == paths and failed == [bad, mixed[-1]]
+        assert arr.shape == (5, 3, 224, 224) and arr.dtype == np.uint8
+        for a, p in zip(arr, paths):
+            assert np.array_equal(a, clipmi.pipeline.load_uint8(p, 224))
+        arr2, ok2, _ = pool.decode(paths[::-1], 224)                       # the segment is reused; order follows the call
+        assert ok2 == paths[::-1] and np.array_equal(arr2[0], arr[4])
+        got = list(clipmi.pipeline.encode_files(_StubModel(), mixed, batch=3, workers=2, pool=pool))
+    ref = list(clipmi.pipeline.encode_files(_StubModel(), mixed, batch=3, workers=2))
+    assert [g[0] for g in got] == [r[0] for r in ref] and [g[2] for g in got] == [r[2] for r in ref]
+    for g, r in zip(got, ref):
+        assert (g[1] is None and r[1] is None) or np.array_equal(g[1], r[1])
+
+
 class _StubModel:
     """encode_image/encode_text that are deterministic functions of the input (CPU, test only)."""
     embed_dim, context_length = 512, 77
@@ -123,7 +152,8 @@ def test_build_index_glue_keys_skip_resume(clipmi, tmp_path, monkeypatch, capsys
     base = str(d) + "/"                                   # trailing slash: key = base + name
     monkeypatch.chdir(tmp_path)
     db = clipmi.store.VectorStore("vectors.lmdb", dim=512, backend="packed")
-    bi.encode_directories([base], _StubModel(), db, batch=2, workers=2)
+    with clipmi.pipeline.DecodePool(2) as pool:           # the CLI's default: decode in worker processes
+        bi.encode_directories([base], _StubModel(), db, batch=2, workers=2, pool=pool)
     out = capsys.readouterr().out
     assert out.startswith(f"CLIPing {base}...") and out.count(".") >= 3 and out.count("#") == 1
     assert db.count() == 3 and db.is_skipped(base + "broken.jpeg") and db.has_vector(base + "a.JPG")
