@@ -31,6 +31,7 @@ class DecodePool:
         script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "decode_worker.py")
         self.procs = [subprocess.Popen([sys.executable, script], stdin=subprocess.PIPE, stdout=subprocess.PIPE)
                       for _ in range(self.n)]
+        self._all_procs = list(self.procs)
         self.threads = ThreadPoolExecutor(max_workers=self.n)
         self.shm = None
 
@@ -43,18 +44,34 @@ class DecodePool:
             self.shm = shared_memory.SharedMemory(create=True, size=int(nbytes))
         return self.shm
 
-    def _run(self, w, jobs, n_px, name):
-        """Worker w decodes its share of the batch: (slot, path) pairs, one request at a time."""
+    def _run(self, w, jobs, n_px, name, seg):
+        """Worker w decodes its share of the batch: (slot, path) pairs, one request at a time. If the worker process dies
+        (a file that crashes the decoder, an OOM kill), that file is reported as failed and the rest of the share - and of
+        every later batch - is decoded in this process: no program is spawned once the GPU may have been initialised."""
         p = self.procs[w]
         ok = []
         per = 3 * n_px * n_px
         for slot, path in jobs:
-            p.stdin.write(b"%d\t%s\t%d\t" % (n_px, name, slot * per) + path.encode("utf-8", "surrogateescape") + b"\n")
-            p.stdin.flush()
-            st = p.stdout.read(1)
-            if st == b"":
-                raise RuntimeError("decode worker exited")
-            ok.append((slot, st == b"1"))
+            if p is not None:
+                try:
+                    p.stdin.write(b"%d\t%s\t%d\t" % (n_px, name, slot * per) + path.encode("utf-8", "surrogateescape") + b"\n")
+                    p.stdin.flush()
+                    st = p.stdout.read(1)
+                except (BrokenPipeError, OSError):
+                    st = b""
+                if st == b"":
+                    self.procs[w] = p = None
+                    ok.append((slot, False))
+                    continue
+                ok.append((slot, st == b"1"))
+            else:
+                try:
+                    np.frombuffer(seg.buf, dtype=np.uint8, count=per, offset=slot * per)[:] = load_uint8(path, n_px).reshape(-1)
+                    ok.append((slot, True))
+                except KeyboardInterrupt:
+                    raise
+                except Exception:
+                    ok.append((slot, False))
         return ok
 
     def decode(self, paths, n_px):
@@ -63,8 +80,9 @@ class DecodePool:
         per = 3 * n_px * n_px
         seg = self._segment(max(1, n * per))
         name = seg.name.encode()
-        futs = [self.threads.submit(self._run, w, [(i, paths[i]) for i in range(w, n, self.n)], n_px, name)
-                for w in range(min(self.n, n))]
+        live = [w for w in range(self.n) if self.procs[w] is not None] or [0]
+        futs = [self.threads.submit(self._run, w, [(i, paths[i]) for i in range(k, n, len(live))], n_px, name, seg)
+                for k, w in enumerate(live) if k < n]
         good = np.zeros(n, dtype=bool)
         for f in futs:
             for slot, fine in f.result():
@@ -76,12 +94,13 @@ class DecodePool:
         return out, ok, bad
 
     def close(self):
-        for p in self.procs:
+        procs = [p for p in getattr(self, "_all_procs", self.procs) if p is not None]
+        for p in procs:
             try:
                 p.stdin.close()
             except Exception:
                 pass
-        for p in self.procs:
+        for p in procs:
             try:
                 p.wait(timeout=5)
             except Exception:

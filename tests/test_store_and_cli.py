@@ -111,6 +111,14 @@ def test_decode_pool_matches_in_process_decode(clipmi, tmp_path):
         arr2, ok2, _ = pool.decode(paths[::-1], 224)                       # the segment is reused; order follows the call
         assert ok2 == paths[::-1] and np.array_equal(arr2[0], arr[4])
         got = list(clipmi.pipeline.encode_files(_StubModel(), mixed, batch=3, workers=2, pool=pool))
+        # a worker that dies (a file that crashes the decoder, an OOM kill) costs at most the file it was on: its share is
+        # decoded in-process from then on, nothing is spawned
+        pool.procs[1].kill()
+        pool.procs[1].wait()
+        arr3, ok3, failed3 = pool.decode(paths, 224)
+        assert pool.procs[1] is None and len(ok3) >= len(paths) - 1 and set(ok3) | set(failed3) == set(paths)
+        arr4, ok4, failed4 = pool.decode(paths, 224)
+        assert ok4 == paths and failed4 == [] and np.array_equal(arr4, arr)
     ref = list(clipmi.pipeline.encode_files(_StubModel(), mixed, batch=3, workers=2))
     assert [g[0] for g in got] == [r[0] for r in ref] and [g[2] for g in got] == [r[2] for r in ref]
     for g, r in zip(got, ref):
