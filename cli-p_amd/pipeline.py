@@ -45,37 +45,44 @@ class DecodePool:
         return self.shm
 
     def _run(self, w, jobs, n_px, name, seg):
-        """Worker w decodes its share of the batch: (slot, path) pairs, one request at a time. If the worker process dies
+        """Worker w decodes its share of the batch: (slot, path) pairs. If the worker process dies
         (a file that crashes the decoder, an OOM kill), that file is reported as failed and the rest of the share - and of
         every later batch - is decoded in this process: no program is spawned once the GPU may have been initialised."""
         p = self.procs[w]
         ok = []
         per = 3 * n_px * n_px
-        for slot, path in jobs:
-            if p is not None:
-                try:
-                    p.stdin.write(b"%d\t%s\t%d\t" % (n_px, name, slot * per) + path.encode("utf-8", "surrogateescape") + b"\n")
-                    p.stdin.flush()
-                    st = p.stdout.read(1)
-                except (BrokenPipeError, OSError):
-                    st = b""
-                if st == b"":
-                    self.procs[w] = p = None
-                    ok.append((slot, False))
-                    continue
-                ok.append((slot, st == b"1"))
-            else:
-                try:
-                    np.frombuffer(seg.buf, dtype=np.uint8, count=per, offset=slot * per)[:] = load_uint8(path, n_px).reshape(-1)
-                    ok.append((slot, True))
-                except KeyboardInterrupt:
-                    raise
-                except Exception:
-                    ok.append((slot, False))
+        done = 0
+        if p is not None:
+            # the whole share in one write, the status bytes in one read: this thread sleeps while the worker decodes
+            # (one request per round trip kept 16 parent threads busy handing the GIL around)
+            req = b"".join(b"%d\t%s\t%d\t" % (n_px, name, slot * per) + path.encode("utf-8", "surrogateescape") + b"\n"
+                           for slot, path in jobs)
+            try:
+                p.stdin.write(req)
+                p.stdin.flush()
+                st = p.stdout.read(len(jobs))
+            except (BrokenPipeError, OSError):
+                st = b""
+            ok = [(jobs[i][0], st[i:i + 1] == b"1") for i in range(len(st))]
+            done = len(st)
+            if done < len(jobs):                   # the worker died on file `done`: that one failed, the rest in-process
+                self.procs[w] = None
+                ok.append((jobs[done][0], False))
+                done += 1
+        for slot, path in jobs[done:]:
+            try:
+                np.frombuffer(seg.buf, dtype=np.uint8, count=per, offset=slot * per)[:] = load_uint8(path, n_px).reshape(-1)
+                ok.append((slot, True))
+            except KeyboardInterrupt:
+                raise
+            except Exception:
+                ok.append((slot, False))
         return ok
 
-    def decode(self, paths, n_px):
-        """-> (uint8 array [n_ok,3,n_px,n_px] (a copy), ok_paths, failed_paths), file order kept."""
+    def decode(self, paths, n_px, copy=True):
+        """-> (uint8 array [n_ok,3,n_px,n_px], ok_paths, failed_paths), file order kept. copy=False returns a VIEW of
+        the pool's shared-memory segment (all slots, plus a boolean mask of the good ones instead of the compacted
+        array): valid until the next decode() - encode_files copies it straight into pinned memory."""
         n = len(paths)
         per = 3 * n_px * n_px
         seg = self._segment(max(1, n * per))
@@ -88,9 +95,11 @@ class DecodePool:
             for slot, fine in f.result():
                 good[slot] = fine
         arr = np.frombuffer(seg.buf, dtype=np.uint8, count=n * per).reshape(n, 3, n_px, n_px)
-        out = arr[good].copy() if not good.all() else arr.copy()
         ok = [p for p, g_ in zip(paths, good) if g_]
         bad = [p for p, g_ in zip(paths, good) if not g_]
+        if not copy:
+            return (arr, good), ok, bad
+        out = arr[good].copy() if not good.all() else arr.copy()
         return out, ok, bad
 
     def close(self):
@@ -140,23 +149,53 @@ def encode_files(model, paths, batch=256, workers=8, pool=None):
     use_gpu = dev.type == "cuda"
     copy_stream = torch.cuda.Stream(device=dev) if use_gpu else None
 
+    # three pinned staging buffers used in turn (GPU): batch i may still be in its H2D copy while batch i+1 is filled;
+    # a buffer is reused only after the copy that read it has finished. Pixels go shared memory -> pinned -> device:
+    # ONE host copy (the first version copied out of the segment, then again into freshly pinned memory: 55 ms per
+    # 435-image batch against 23 ms of decode on 16 workers).
+    ring = []
+
+    def staging(n):
+        slot = ring.pop(0) if len(ring) >= 3 else {"buf": None, "ev": None}
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()
+        if slot["buf"] is None or slot["buf"].shape[0] < n:
+            slot["buf"] = torch.empty((max(n, batch), 3, n_px, n_px), dtype=torch.uint8).pin_memory()
+        ring.append(slot)
+        return slot
+
     def stage(chunk):
         if pool is not None:
-            stacked, ok, bad = pool.decode(chunk, n_px)
+            (view, good), ok, bad = pool.decode(chunk, n_px, copy=False)
+            if not ok:
+                return ok, bad, None, None
+            src = torch.from_numpy(view)
+            if use_gpu:
+                slot = staging(len(ok))
+                host = slot["buf"][:len(ok)]
+                if len(ok) == len(chunk):
+                    host.copy_(src)
+                else:
+                    torch.index_select(src, 0, torch.from_numpy(np.nonzero(good)[0]), out=host)
+            else:
+                host = src[torch.from_numpy(good)].clone() if len(ok) != len(chunk) else src.clone()
         else:
             arrs = list(tpool.map(_load_safe, [(p, n_px) for p in chunk]))
             ok = [p for p, a in zip(chunk, arrs) if a is not None]
             bad = [p for p, a in zip(chunk, arrs) if a is None]
-            stacked = np.stack([a for a in arrs if a is not None]) if ok else None
-        if not ok:
-            return ok, bad, None, None
-        host = torch.from_numpy(stacked)
+            if not ok:
+                return ok, bad, None, None
+            host = torch.from_numpy(np.stack([a for a in arrs if a is not None]))
+            slot = None
+            if use_gpu:
+                host = host.pin_memory()
         if use_gpu:
-            host = host.pin_memory()
             with torch.cuda.stream(copy_stream):
                 devt = host.to(dev, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
+            if slot is not None:
+                slot["ev"] = ev
             return ok, bad, devt, ev
         return ok, bad, host, None
 
