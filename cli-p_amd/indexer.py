@@ -18,7 +18,8 @@ committed in rank order; rank 0 alone assembles the matrix and writes `images.in
 Weights: $CLIPMI_WEIGHTS (a local ViT-B-32.pt / state-dict), or CLIPMI_RANDOM_WEIGHTS=<seed> for a
 synthetic model. Knobs: CLIPMI_BATCH (default 435 = whole rounds of GEMM tiles on 256 CUs),
 CLIPMI_WORKERS (decode workers, default 8), CLIPMI_DECODE (`procs`, the default: worker processes started before
-the GPU is touched — small images decode 4-5x faster than on threads, which the GIL binds; `threads`: the old form).
+the GPU is touched — 16 k images/s end to end from 224 x 224 JPEGs on 16 workers against 4 k on threads, which the GIL
+binds; `threads`: the old form).
 """
 import os
 

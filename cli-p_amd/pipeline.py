@@ -38,11 +38,24 @@ class DecodePool:
     def _segment(self, nbytes):
         from multiprocessing import shared_memory
         if self.shm is None or self.shm.size < nbytes:
-            if self.shm is not None:
-                self.shm.close()
-                self.shm.unlink()
+            self._drop_segment()
             self.shm = shared_memory.SharedMemory(create=True, size=int(nbytes))
         return self.shm
+
+    def _drop_segment(self):
+        """Unlink first (always possible), then unmap (refused while a caller still holds a view: the mapping then goes
+        with the last reference)."""
+        if self.shm is None:
+            return
+        try:
+            self.shm.unlink()
+        except Exception:
+            pass
+        try:
+            self.shm.close()
+        except BufferError:
+            pass
+        self.shm = None
 
     def _run(self, w, jobs, n_px, name, seg):
         """Worker w decodes its share of the batch: (slot, path) pairs. If the worker process dies
@@ -115,13 +128,7 @@ class DecodePool:
             except Exception:
                 p.kill()
         self.threads.shutdown(wait=False)
-        if self.shm is not None:
-            try:
-                self.shm.close()
-                self.shm.unlink()
-            except Exception:
-                pass
-            self.shm = None
+        self._drop_segment()
 
     def __enter__(self):
         return self
@@ -161,6 +168,7 @@ def encode_files(model, paths, batch=256, workers=8, pool=None):
             slot["ev"].synchronize()
         if slot["buf"] is None or slot["buf"].shape[0] < n:
             slot["buf"] = torch.empty((max(n, batch), 3, n_px, n_px), dtype=torch.uint8).pin_memory()
+            slot["np"] = slot["buf"].numpy()              # the same pinned bytes as a numpy array
         ring.append(slot)
         return slot
 
@@ -169,16 +177,18 @@ def encode_files(model, paths, batch=256, workers=8, pool=None):
             (view, good), ok, bad = pool.decode(chunk, n_px, copy=False)
             if not ok:
                 return ok, bad, None, None
-            src = torch.from_numpy(view)
+            # numpy copies on purpose: a 65-MB torch copy_ fans out over every CPU the host shows (256 here) and its
+            # OpenMP team then spins through the container's CPU share - every other batch's decode took 80 ms instead
+            # of 15 (tools/pipe_probe.py: 26.7 k images/s decode only, 5.9 k with a torch copy behind each batch)
             if use_gpu:
                 slot = staging(len(ok))
                 host = slot["buf"][:len(ok)]
                 if len(ok) == len(chunk):
-                    host.copy_(src)
+                    np.copyto(slot["np"][:len(ok)], view)
                 else:
-                    torch.index_select(src, 0, torch.from_numpy(np.nonzero(good)[0]), out=host)
+                    np.compress(good, view, axis=0, out=slot["np"][:len(ok)])
             else:
-                host = src[torch.from_numpy(good)].clone() if len(ok) != len(chunk) else src.clone()
+                host = torch.from_numpy(view[good] if len(ok) != len(chunk) else view.copy())
         else:
             arrs = list(tpool.map(_load_safe, [(p, n_px) for p in chunk]))
             ok = [p for p, a in zip(chunk, arrs) if a is not None]
