@@ -152,6 +152,32 @@ def make_jpegs(n):
     return blobs
 
 
+def files_to_vectors_leg(model, pool):
+    """build-index.py's loop end to end: JPEG FILES -> Pillow decode in worker processes -> pinned
+    H2D -> HIP encode -> normalised f32 vectors on the host, 435 images per batch. Host-bound (the number is the decode
+    rate of the box's CPU share); reported beside the headline, never as it."""
+    import shutil
+    import tempfile
+    n = 10 * 435
+    d = tempfile.mkdtemp(prefix="clipmi_bench_")
+    try:
+        for i, blob in enumerate(make_jpegs(n)):
+            with open(os.path.join(d, f"img_{i:05d}.jpg"), "wb") as f:
+                f.write(blob)
+        paths = sorted(os.path.join(d, f) for f in os.listdir(d))
+        for _ in clipmi.pipeline.encode_files(model, paths[:435], batch=435, pool=pool):
+            pass
+        t0 = time.perf_counter()
+        got = 0
+        for ok, feats, bad in clipmi.pipeline.encode_files(model, paths, batch=435, pool=pool):
+            got += len(ok)
+        dt = time.perf_counter() - t0
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return {"value": got / dt, "unit": "images/s", "images": got, "decode_processes": pool.n, "batch": 435,
+            "data": "synthetic 224x224 JPEG files (quality 95) on local disk", "bound": "host decode"}
+
+
 def cpu_baseline_cfg1(sd):
     """BASELINE.json configs[0] on the host cores, as SURVEY.md §8(d) lays it out: 256 synthetic 224x224 JPEGs
     (rng 0, quality 95) -> decode + transform + fp32 encode at B = 1 per image (reference semantics,
@@ -385,6 +411,10 @@ def main():
     if world != a.gpus:
         print(json.dumps({"error": f"--gpus {a.gpus} but WORLD_SIZE={world}", "n_gpus": a.gpus, "value": None}), flush=True)
         sys.exit(2)
+    # decode workers for the files-to-vectors leg are child programs: start them before this process touches the GPU
+    decode_pool = None
+    if world == 1 and not a.quick and not a.no_cpu_baseline:
+        decode_pool = clipmi.pipeline.DecodePool(clipmi.indexer.default_workers())
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
@@ -529,6 +559,9 @@ def main():
         out["encode_vitl14_336"] = l14
     if shard is not None:
         out["search_shard_12p5m"] = shard
+    if decode_pool is not None:
+        out["files_to_vectors"] = files_to_vectors_leg(clipmi.CLIP(sd, device=dev), decode_pool)
+        decode_pool.close()
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_cfg1(sd)
         out["search"]["cpu_baseline"] = cpu_baseline_search(a.rows, Q, K)
