@@ -108,7 +108,12 @@ def default_workers():
 def main(argv):
     workers = int(os.environ.get("CLIPMI_WORKERS", "0")) or default_workers()
     # decode workers first: they are child programs, and nothing in this process has touched the GPU yet
-    pool = pipeline.DecodePool(workers) if os.environ.get("CLIPMI_DECODE", "procs") == "procs" else None
+    pool = None
+    if os.environ.get("CLIPMI_DECODE", "procs") == "procs":
+        try:
+            pool = pipeline.DecodePool(workers)
+        except OSError as e:                          # no room for child processes: decode on threads, as before
+            print(f"(decode workers unavailable: {e}; decoding on {workers} threads)")
     try:
         ranks = Ranks("cuda").init()
         device = str(ranks.device)
