@@ -21,7 +21,8 @@ class DecodePool:
     the host cores also for small images, where threads are bound by the GIL. The workers are plain `python
     decode_worker.py` children started HERE - create the pool BEFORE the process initialises the GPU (indexer.main
     does): a process that has touched the GPU should not spawn programs on this platform. Pixels come back through
-    ONE shared-memory segment per pool (workers write their slots; no pickling, no copies through pipes)."""
+    shared memory (workers write their slots; no pickling, no copies through pipes): two segments used in turn, so that
+    a batch can be decoded while the previous one is still being copied out."""
 
     def __init__(self, workers):
         import os
@@ -33,29 +34,31 @@ class DecodePool:
                       for _ in range(self.n)]
         self._all_procs = list(self.procs)
         self.threads = ThreadPoolExecutor(max_workers=self.n)
-        self.shm = None
+        self.segs = [None, None]
 
-    def _segment(self, nbytes):
+    def _segment(self, nbytes, which=0):
         from multiprocessing import shared_memory
-        if self.shm is None or self.shm.size < nbytes:
-            self._drop_segment()
-            self.shm = shared_memory.SharedMemory(create=True, size=int(nbytes))
-        return self.shm
+        seg = self.segs[which]
+        if seg is None or seg.size < nbytes:
+            self._drop_segment(which)
+            seg = self.segs[which] = shared_memory.SharedMemory(create=True, size=int(nbytes))
+        return seg
 
-    def _drop_segment(self):
+    def _drop_segment(self, which):
         """Unlink first (always possible), then unmap (refused while a caller still holds a view: the mapping then goes
         with the last reference)."""
-        if self.shm is None:
+        seg = self.segs[which]
+        if seg is None:
             return
         try:
-            self.shm.unlink()
+            seg.unlink()
         except Exception:
             pass
         try:
-            self.shm.close()
+            seg.close()
         except BufferError:
             pass
-        self.shm = None
+        self.segs[which] = None
 
     def _run(self, w, jobs, n_px, name, seg):
         """Worker w decodes its share of the batch: (slot, path) pairs. If the worker process dies
@@ -92,13 +95,14 @@ class DecodePool:
                 ok.append((slot, False))
         return ok
 
-    def decode(self, paths, n_px, copy=True):
+    def decode(self, paths, n_px, copy=True, segment=0):
         """-> (uint8 array [n_ok,3,n_px,n_px], ok_paths, failed_paths), file order kept. copy=False returns a VIEW of
-        the pool's shared-memory segment (all slots, plus a boolean mask of the good ones instead of the compacted
-        array): valid until the next decode() - encode_files copies it straight into pinned memory."""
+        the pool's shared-memory segment `segment` (all slots, plus a boolean mask of the good ones instead of the
+        compacted array): valid until the next decode() into the same segment - encode_files copies it straight into
+        pinned memory. One decode() at a time (the workers take one request stream)."""
         n = len(paths)
         per = 3 * n_px * n_px
-        seg = self._segment(max(1, n * per))
+        seg = self._segment(max(1, n * per), segment)
         name = seg.name.encode()
         live = [w for w in range(self.n) if self.procs[w] is not None] or [0]
         futs = [self.threads.submit(self._run, w, [(i, paths[i]) for i in range(k, n, len(live))], n_px, name, seg)
@@ -128,7 +132,8 @@ class DecodePool:
             except Exception:
                 p.kill()
         self.threads.shutdown(wait=False)
-        self._drop_segment()
+        self._drop_segment(0)
+        self._drop_segment(1)
 
     def __enter__(self):
         return self
@@ -172,52 +177,85 @@ def encode_files(model, paths, batch=256, workers=8, pool=None):
         ring.append(slot)
         return slot
 
-    def stage(chunk):
-        if pool is not None:
-            (view, good), ok, bad = pool.decode(chunk, n_px, copy=False)
-            if not ok:
-                return ok, bad, None, None
-            # numpy copies on purpose: a 65-MB torch copy_ fans out over every CPU the host shows (256 here) and its
-            # OpenMP team then spins through the container's CPU share - every other batch's decode took 80 ms instead
-            # of 15 (tools/pipe_probe.py: 26.7 k images/s decode only, 5.9 k with a torch copy behind each batch)
-            if use_gpu:
-                slot = staging(len(ok))
-                host = slot["buf"][:len(ok)]
-                if len(ok) == len(chunk):
-                    np.copyto(slot["np"][:len(ok)], view)
-                else:
-                    np.compress(good, view, axis=0, out=slot["np"][:len(ok)])
-            else:
-                host = torch.from_numpy(view[good] if len(ok) != len(chunk) else view.copy())
+    def to_device(host, slot):
+        with torch.cuda.stream(copy_stream):
+            devt = host.to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        if slot is not None:
+            slot["ev"] = ev
+        return devt, ev
+
+    def copy_out(decoded, chunk):
+        """shared memory -> pinned staging (GPU) or a private tensor (CPU) -> device. numpy copies on purpose: a 65-MB torch
+        copy_ fans out over every CPU the host shows (256 here) and its OpenMP team then spins through the container's CPU
+        share - every other batch's decode took 80 ms instead of 15 (tools/pipe_probe.py: 26.7 k images/s decode only,
+        5.9 k with a torch copy behind each batch)."""
+        (view, good), ok, bad = decoded
+        if not ok:
+            return ok, bad, None, None
+        if not use_gpu:
+            return ok, bad, torch.from_numpy(view[good] if len(ok) != len(chunk) else view.copy()), None
+        slot = staging(len(ok))
+        if len(ok) == len(chunk):
+            np.copyto(slot["np"][:len(ok)], view)
         else:
-            arrs = list(tpool.map(_load_safe, [(p, n_px) for p in chunk]))
-            ok = [p for p, a in zip(chunk, arrs) if a is not None]
-            bad = [p for p, a in zip(chunk, arrs) if a is None]
-            if not ok:
-                return ok, bad, None, None
-            host = torch.from_numpy(np.stack([a for a in arrs if a is not None]))
-            slot = None
-            if use_gpu:
-                host = host.pin_memory()
-        if use_gpu:
-            with torch.cuda.stream(copy_stream):
-                devt = host.to(dev, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(copy_stream)
-            if slot is not None:
-                slot["ev"] = ev
-            return ok, bad, devt, ev
-        return ok, bad, host, None
+            np.compress(good, view, axis=0, out=slot["np"][:len(ok)])
+        devt, ev = to_device(slot["buf"][:len(ok)], slot)
+        return ok, bad, devt, ev
+
+    def stage(chunk):
+        """The thread form: decode on `workers` threads, stack, pin, copy."""
+        arrs = list(tpool.map(_load_safe, [(p, n_px) for p in chunk]))
+        ok = [p for p, a in zip(chunk, arrs) if a is not None]
+        bad = [p for p, a in zip(chunk, arrs) if a is None]
+        if not ok:
+            return ok, bad, None, None
+        host = torch.from_numpy(np.stack([a for a in arrs if a is not None]))
+        if not use_gpu:
+            return ok, bad, host, None
+        devt, ev = to_device(host.pin_memory(), None)
+        return ok, bad, devt, ev
 
     chunks = [paths[i:i + batch] for i in range(0, len(paths), batch)]
+
+    def consume(item):
+        ok, bad, devt, ev = item
+        feats = None
+        if devt is not None:
+            if ev is not None:
+                torch.cuda.current_stream(dev).wait_event(ev)
+            feats = model.encode_image(devt, normalize=True).cpu().numpy().astype("float32")
+        return ok, feats, bad
+
+    if pool is not None:
+        # three stages, one thread each: decode batch j+1 (worker processes, shared-memory segment (j+1) & 1) | copy batch j
+        # out of its segment and to the device | encode batch j-1 here. A segment is decoded into again only after its
+        # previous batch has been copied out.
+        with ThreadPoolExecutor(max_workers=1) as dec, ThreadPoolExecutor(max_workers=1) as cpy:
+            copies = {}
+
+            def decode_job(j):
+                if j - 2 in copies:
+                    copies[j - 2].result()                 # segment j & 1 is free again
+                return pool.decode(chunks[j], n_px, copy=False, segment=j & 1)
+
+            def submit(j):
+                d = dec.submit(decode_job, j)
+                copies[j] = cpy.submit(lambda d=d, j=j: copy_out(d.result(), chunks[j]))
+
+            for j in range(min(2, len(chunks))):
+                submit(j)
+            for ci in range(len(chunks)):
+                item = copies[ci].result()
+                if ci + 2 < len(chunks):
+                    submit(ci + 2)
+                copies.pop(ci - 2, None)
+                yield consume(item)
+        return
     with ThreadPoolExecutor(max_workers=workers) as tpool, ThreadPoolExecutor(max_workers=1) as stager:
         nxt = stager.submit(stage, chunks[0]) if chunks else None
         for ci in range(len(chunks)):
-            ok, bad, devt, ev = nxt.result()
+            item = nxt.result()
             nxt = stager.submit(stage, chunks[ci + 1]) if ci + 1 < len(chunks) else None
-            feats = None
-            if devt is not None:
-                if ev is not None:
-                    torch.cuda.current_stream(dev).wait_event(ev)
-                feats = model.encode_image(devt, normalize=True).cpu().numpy().astype("float32")
-            yield ok, feats, bad
+            yield consume(item)
