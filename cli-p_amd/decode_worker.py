@@ -21,9 +21,10 @@ import sys
 import numpy as np
 
 
-def load_uint8(path, n_px):
+def load_uint8(path, n_px, out=None):
     """Pillow part of the upstream transform: resize shorter side to n_px (bicubic), centre crop,
-    RGB; returns uint8 [3, n_px, n_px]. Identical pixels to `make_transform` before its float tail."""
+    RGB; returns uint8 [3, n_px, n_px] (written into `out` when given: the worker's slot of the shared segment, one
+    strided copy instead of two). Identical pixels to `make_transform` before its float tail."""
     from PIL import Image
     img = Image.open(path)
     w, h = img.size
@@ -37,7 +38,11 @@ def load_uint8(path, n_px):
     left = int(round((w - n_px) / 2.0))
     top = int(round((h - n_px) / 2.0))
     img = img.crop((left, top, left + n_px, top + n_px)).convert("RGB")
-    return np.ascontiguousarray(np.asarray(img, dtype=np.uint8).transpose(2, 0, 1))
+    chw = np.asarray(img, dtype=np.uint8).transpose(2, 0, 1)
+    if out is None:
+        return np.ascontiguousarray(chw)
+    np.copyto(out, chw)
+    return out
 
 
 def serve(fin, fout):
@@ -51,36 +56,45 @@ def serve(fin, fout):
         try:
             n_px_s, shm_name, off_s, path = line.rstrip(b"\n").split(b"\t", 3)
             n_px, off = int(n_px_s), int(off_s)
-            arr = load_uint8(path.decode("utf-8", "surrogateescape"), n_px)
+            fname = path.decode("utf-8", "surrogateescape")
+            if shm_name == b"-":
+                payload = load_uint8(fname, n_px).tobytes()
+            else:
+                name = shm_name.decode()
+                seg = segments.get(name)
+                if seg is None:
+                    if len(segments) > 8:                      # the parent rotates a few segments; drop stale handles
+                        _close_all(segments)
+                    seg = segments[name] = shared_memory.SharedMemory(name=name)
+                    try:                                       # the parent owns the segment: an attaching process must not
+                        from multiprocessing import resource_tracker   # unlink it at exit (Python < 3.13 registers attachments)
+                        resource_tracker.unregister(seg._name, "shared_memory")
+                    except Exception:
+                        pass
+                slot = np.frombuffer(seg.buf, dtype=np.uint8, count=3 * n_px * n_px, offset=off).reshape(3, n_px, n_px)
+                load_uint8(fname, n_px, out=slot)
+                slot = None                                    # no view may outlive the request (close() refuses then)
+                payload = b""
         except KeyboardInterrupt:
             break
         except Exception:
             fout.write(b"0")
             fout.flush()
             continue
-        if shm_name == b"-":
-            fout.write(b"1")
-            fout.write(arr.tobytes())
-        else:
-            name = shm_name.decode()
-            seg = segments.get(name)
-            if seg is None:
-                if len(segments) > 8:                          # the parent rotates a few segments; drop stale handles
-                    for s in segments.values():
-                        s.close()
-                    segments.clear()
-                seg = segments[name] = shared_memory.SharedMemory(name=name)
-                try:                                           # the parent owns the segment: an attaching process must not
-                    from multiprocessing import resource_tracker   # unlink it at exit (Python < 3.13 registers attachments)
-                    resource_tracker.unregister(seg._name, "shared_memory")
-                except Exception:
-                    pass
-            n = arr.size
-            np.frombuffer(seg.buf, dtype=np.uint8, count=n, offset=off)[:] = arr.reshape(-1)
-            fout.write(b"1")
+        fout.write(b"1")
+        if payload:
+            fout.write(payload)
         fout.flush()
+    _close_all(segments)
+
+
+def _close_all(segments):
     for s in segments.values():
-        s.close()
+        try:
+            s.close()
+        except BufferError:
+            pass
+    segments.clear()
 
 
 if __name__ == "__main__":
