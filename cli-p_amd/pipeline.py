@@ -57,7 +57,7 @@ class DecodePool:
         try:
             seg.close()
         except BufferError:
-            pass
+            seg.close = lambda: None          # a view is still alive: the mapping goes with it; keep __del__ quiet
         self.segs[which] = None
 
     def _run(self, w, jobs, n_px, name, seg):
@@ -238,11 +238,11 @@ def encode_files(model, paths, batch=256, workers=8, pool=None):
             def decode_job(j):
                 if j - 2 in copies:
                     copies[j - 2].result()                 # segment j & 1 is free again
-                return pool.decode(chunks[j], n_px, copy=False, segment=j & 1)
+                return [pool.decode(chunks[j], n_px, copy=False, segment=j & 1)]
 
             def submit(j):
-                d = dec.submit(decode_job, j)
-                copies[j] = cpy.submit(lambda d=d, j=j: copy_out(d.result(), chunks[j]))
+                d = dec.submit(decode_job, j)              # (the result travels in a list the copy stage empties: no
+                copies[j] = cpy.submit(lambda d=d, j=j: copy_out(d.result().pop(), chunks[j]))   # view outlives its copy)
 
             for j in range(min(2, len(chunks))):
                 submit(j)
