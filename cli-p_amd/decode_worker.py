@@ -47,8 +47,9 @@ def load_uint8(path, n_px, out=None):
 
 def serve(fin, fout):
     """Answer requests until stdin closes."""
-    from multiprocessing import shared_memory
-    segments = {}
+    import mmap
+    import os
+    segments = {}                                              # name -> mmap of /dev/shm/<name> (the parent owns it)
     while True:
         line = fin.readline()
         if not line:
@@ -63,15 +64,16 @@ def serve(fin, fout):
                 name = shm_name.decode()
                 seg = segments.get(name)
                 if seg is None:
-                    if len(segments) > 8:                      # the parent rotates a few segments; drop stale handles
+                    if len(segments) > 8:                      # the parent rotates a few segments; drop stale mappings
                         _close_all(segments)
-                    seg = segments[name] = shared_memory.SharedMemory(name=name)
-                    try:                                       # the parent owns the segment: an attaching process must not
-                        from multiprocessing import resource_tracker   # unlink it at exit (Python < 3.13 registers attachments)
-                        resource_tracker.unregister(seg._name, "shared_memory")
-                    except Exception:
-                        pass
-                slot = np.frombuffer(seg.buf, dtype=np.uint8, count=3 * n_px * n_px, offset=off).reshape(3, n_px, n_px)
+                    # plain mmap of the POSIX segment's file: multiprocessing.shared_memory would start a resource-tracker
+                    # process per worker and try to unlink the parent's segment at exit (Python < 3.13)
+                    fd = os.open("/dev/shm/" + name.lstrip("/"), os.O_RDWR)
+                    try:
+                        seg = segments[name] = mmap.mmap(fd, 0)
+                    finally:
+                        os.close(fd)
+                slot = np.frombuffer(seg, dtype=np.uint8, count=3 * n_px * n_px, offset=off).reshape(3, n_px, n_px)
                 load_uint8(fname, n_px, out=slot)
                 slot = None                                    # no view may outlive the request (close() refuses then)
                 payload = b""
