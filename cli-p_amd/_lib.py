@@ -21,7 +21,7 @@ SYMBOLS = [
     "clipmi_quantize_rows_i8", "clipmi_topk_ip_coarse_i8", "clipmi_dbg_topk_coarse_i8_scan_ms",
     "clipmi_dbg_quantize_rows_fp8", "clipmi_dbg_gemm_fp8",
     "clipmi_merge_topk_workspace_bytes", "clipmi_merge_topk", "clipmi_merge_topk_packed",
-    "clipmi_l2_normalize_rows", "clipmi_last_error", "clipmi_abi_version",
+    "clipmi_l2_normalize_rows", "clipmi_resize_crop_rgb8", "clipmi_last_error", "clipmi_abi_version",
     "clipmi_dbg_gemm_bf16", "clipmi_dbg_layernorm", "clipmi_dbg_attention", "clipmi_dbg_topk_scan_ms",
     "clipmi_dbg_encode_image_probe_ms",
     "clipmi_dbg_split_stats", "clipmi_dbg_gemm_ln", "clipmi_dbg_gemm_resid_ln",
@@ -108,6 +108,8 @@ def lib():
     L.clipmi_merge_topk_packed.argtypes = [vp, sz, i32, i32, i32, vp, vp, vp]
     L.clipmi_l2_normalize_rows.restype = i32
     L.clipmi_l2_normalize_rows.argtypes = [vp, i64, i32, vp]
+    L.clipmi_resize_crop_rgb8.restype = i32
+    L.clipmi_resize_crop_rgb8.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp]
     L.clipmi_dbg_gemm_bf16.restype = i32
     L.clipmi_dbg_gemm_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.clipmi_dbg_split_stats.restype = i32

@@ -45,6 +45,67 @@ def load_uint8(path, n_px, out=None):
     return out
 
 
+# ---- the resize on the device: integer coefficient tables of Pillow's bicubic resampling -------------------------------
+RESIZE_PREC = 22          # Pillow: PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic(x):
+    a = -0.5              # Pillow's bicubic_filter
+    x = np.abs(x)
+    return np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1,
+                    np.where(x < 2.0, (((x - 5) * x + 8) * x - 4) * a, 0.0))
+
+
+def coeffs_window(in_size, out_size, o0, n_out):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc (the published algorithm, same float64 operations in the same
+    order) for outputs o0 .. o0 + n_out - 1 of an axis resampled from in_size to out_size.
+    -> (first tap int32 [n_out], tap count int32 [n_out], coefficients int32 [n_out][ksize])"""
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    ss = 1.0 / filterscale
+    center = (np.arange(o0, o0 + n_out, dtype=np.float64) + 0.5) * scale
+    xmin = np.maximum(np.trunc(center - support + 0.5).astype(np.int64), 0)
+    xmax = np.minimum(np.trunc(center + support + 0.5).astype(np.int64), in_size)
+    cnt = xmax - xmin
+    k = np.arange(ksize, dtype=np.float64)[None, :]
+    w = np.where(k < cnt[:, None], _bicubic((k + xmin[:, None] - center[:, None] + 0.5) * ss), 0.0)
+    ww = np.cumsum(w, axis=1)[:, -1]                          # a sequential sum, as the C loop's
+    w = np.where(ww[:, None] != 0.0, w / ww[:, None], w)
+    kk = np.trunc(np.where(w < 0, -0.5 + w * (1 << RESIZE_PREC), 0.5 + w * (1 << RESIZE_PREC))).astype(np.int64)
+    kk = np.where(k < cnt[:, None], kk, 0)
+    return xmin.astype(np.int32), cnt.astype(np.int32), kk.astype(np.int32)
+
+
+def resize_plan(w, h, n_px):
+    """What clipmi_resize_crop_rgb8 needs to turn a w x h RGB image into the transform's n_px x n_px pixels: the sizes
+    torchvision's Resize(n_px) + CenterCrop(n_px) arrive at (as load_uint8), the source rows the crop window needs, and the
+    coefficient blocks ([n_px] first tap | [n_px] count | [n_px][k] coefficients) of the resampled axes."""
+    if (w <= h and w == n_px) or (h <= w and h == n_px):
+        nw, nh = w, h
+    elif w <= h:
+        nw, nh = n_px, int(n_px * h / w)
+    else:
+        nh, nw = n_px, int(n_px * w / h)
+    left = int(round((nw - n_px) / 2.0))
+    top = int(round((nh - n_px) / 2.0))
+    plan = {"nw": nw, "nh": nh, "left": left, "top": top, "need_h": int(nw != w), "need_v": int(nh != h), "hk": 0, "vk": 0,
+            "hcoef": np.zeros(0, np.int32), "vcoef": np.zeros(0, np.int32), "r0": top, "nrows": n_px}
+    if plan["need_v"]:
+        ymin, ycnt, kv = coeffs_window(h, nh, top, n_px)
+        plan["r0"] = int(ymin.min())
+        plan["nrows"] = int((ymin + ycnt).max()) - plan["r0"]
+        plan["vk"] = kv.shape[1]
+        plan["vcoef"] = np.concatenate([ymin, ycnt, kv.reshape(-1)])
+    if plan["need_h"]:
+        xmin, xcnt, kh = coeffs_window(w, nw, left, n_px)
+        plan["hk"] = kh.shape[1]
+        plan["hcoef"] = np.concatenate([xmin, xcnt, kh.reshape(-1)])
+    return plan
+
+
 def serve(fin, fout):
     """Answer requests until stdin closes."""
     import mmap

@@ -195,6 +195,27 @@ int clipmi_merge_topk_packed(const void* gathered_dev, size_t record_bytes, int 
  * norm < 1e-9 are left unchanged, as query-index.py:13-17 does). */
 int clipmi_l2_normalize_rows(float* x_dev, int64_t n, int E, void* stream);
 
+/* ---- a2 on the device: Pillow's bicubic resize (shorter side -> n_px) + centre crop of 8-bit RGB images that were
+ * shipped at full size, bit for bit what `transform(image)` computes before its float tail (build-index.py:48; Pillow's
+ * two-pass 8-bit resampling with 22-bit integer coefficients). The host supplies, per image, a job record and the integer
+ * coefficient blocks of the n_px outputs per axis that survive the crop ([n_px] first tap | [n_px] tap count | [n_px][k]
+ * coefficients, int32): cli-p_amd/decode_worker.py computes them with Pillow's own float64 formula.
+ * raw_dev: the images, HWC bytes at job.src_off; out_dev: uint8 [.][3][n_px][n_px] (block job.out_index);
+ * scratch_dev: the 8-bit intermediate rows, job.tmp_off + nrows*n_px*3 bytes each; max_rows = the largest job.nrows. */
+typedef struct clipmi_resize_job {
+    int64_t src_off;              /* bytes from raw_dev to the image's first pixel (rows of w*3 bytes) */
+    int32_t w, h;                 /* source size */
+    int32_t r0, nrows;            /* source rows [r0, r0 + nrows) the output window needs */
+    int32_t out_index;
+    int32_t need_h, need_v;       /* 0: that axis is not resampled (source size == target size), only cropped */
+    int32_t left, top;            /* window origin on an axis that is not resampled */
+    int32_t hk, vk;               /* taps per output of the horizontal / vertical coefficient block */
+    int64_t hcoef_off, vcoef_off; /* int32 offsets into coef_dev */
+    int64_t tmp_off;              /* bytes into scratch_dev */
+} clipmi_resize_job;
+int clipmi_resize_crop_rgb8(const void* raw_dev, const void* jobs_dev, int njobs, int max_rows, const int32_t* coef_dev,
+                            int n_px, void* out_dev, void* scratch_dev, void* stream);
+
 /* thread-local message of the last failing call on this thread ("" if none) */
 const char* clipmi_last_error(void);
 int clipmi_abi_version(void);

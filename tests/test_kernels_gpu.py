@@ -416,3 +416,30 @@ def test_gemm_resid_ln_producer(clipmi, gpu, M, N, K):
     for algo in (1, 2):
         for got, want, what in zip(res[algo], res[3], ("hi", "lo", "part")):
             assert torch.equal(got, want), f"algo {algo} vs the fused store pass: {what} differs"
+
+
+@pytest.mark.parametrize("n_px", [224, 336])
+def test_resize_crop_on_device_matches_pillow(clipmi, gpu, n_px):
+    """Row a2 on the device (csrc/resize.hip + the coefficient tables of decode_worker.resize_plan): bit for bit the pixels
+    Pillow's bicubic resize + centre crop give (pipeline.load_uint8 is the host form of the same transform), for
+    down- and up-scaling, extreme aspect ratios and sizes that need one pass only."""
+    import os, tempfile
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    sizes = [(224, 224), (336, 336), (225, 224), (224, 300), (336, 500), (100, 90), (30, 500), (500, 30), (1600, 1200),
+             (1200, 1600), (448, 448), (223, 223), (1024, 768), (640, 480), (17, 23)]
+    sizes += [(int(rng.integers(20, 1000)), int(rng.integers(20, 1000))) for _ in range(12)]
+    images = []
+    for k, (w, h) in enumerate(sizes):
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        if k % 3 == 1:                                   # smooth content exercises the rounding of long tap sums
+            a = ((np.linspace(0, 255, w)[None, :, None] + np.linspace(0, 120, h)[:, None, None]) % 256 * np.ones((1, 1, 3))).astype(np.uint8)
+        images.append(a)
+    got = clipmi.resize.resize_crop_device(images, n_px, gpu).cpu().numpy()
+    d = tempfile.mkdtemp()
+    for k, a in enumerate(images):
+        p = os.path.join(d, f"{k}.png")
+        Image.fromarray(a).save(p)
+        want = clipmi.pipeline.load_uint8(p, n_px)
+        assert np.array_equal(got[k], want), f"image {k} {a.shape}: {(got[k].astype(int) - want).__abs__().max()}"
