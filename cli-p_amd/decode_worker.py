@@ -10,11 +10,7 @@ GIL inside the JPEG decoder, but for small images the Python around it dominates
 on 224 x 224 JPEGs where one gave 895; eight worker processes scale with the cores. The script is started by path, never
 imported through the package, so a worker never imports torch or touches the GPU.
 
-Protocol (binary, one request at a time per worker):
-  request : one text line  b"<n_px>\\t<shm name or ->\\t<byte offset>\\t<path utf-8>\\n"
-  response: one status byte b"1" (decoded) or b"0" (failed: not an image, unreadable - reported per file like
-            build-index.py:55-58), followed by 3*n_px*n_px raw bytes ONLY when no shared memory segment was named;
-            otherwise the pixels were written into the segment at the offset.
+Protocol: see serve(). A file that does not decode is answered b"0" and reported per file like build-index.py:55-58.
 """
 import sys
 
@@ -106,47 +102,88 @@ def resize_plan(w, h, n_px):
     return plan
 
 
+PLAN_INTS = 16            # header of a full-size image's region: w h r0 nrows need_h need_v left top hk vk n_hcoef n_vcoef
+
+
+def decode_full(path, n_px, region):
+    """For the resize on the device: decode an RGB image at full size into `region` (a uint8 view of the parent's big
+    segment) as [pixels HWC | pad to 16 | PLAN_INTS int32 | horizontal coefficient block | vertical block] and return
+    (w, h, bytes used); None when the image should take the host path instead (not 8-bit RGB - the transform resamples in
+    the image's own mode and converts afterwards -, nothing to resample, or it does not fit the region)."""
+    from PIL import Image
+    img = Image.open(path)
+    w, h = img.size
+    if img.mode != "RGB" or (w <= h and w == n_px) or (h <= w and h == n_px):
+        return None
+    npix = w * h * 3
+    if npix + 4096 > region.size:
+        return None
+    plan = resize_plan(w, h, n_px)
+    o_hdr = (npix + 15) // 16 * 16
+    total = o_hdr + 4 * (PLAN_INTS + plan["hcoef"].size + plan["vcoef"].size)
+    if total > region.size:
+        return None
+    region[:npix] = np.asarray(img, dtype=np.uint8).reshape(-1)
+    ints = np.frombuffer(region, dtype=np.int32, count=(total - o_hdr) // 4, offset=o_hdr)
+    ints[:PLAN_INTS] = [w, h, plan["r0"], plan["nrows"], plan["need_h"], plan["need_v"], plan["left"], plan["top"],
+                        plan["hk"], plan["vk"], plan["hcoef"].size, plan["vcoef"].size, 0, 0, 0, 0]
+    ints[PLAN_INTS:PLAN_INTS + plan["hcoef"].size] = plan["hcoef"]
+    ints[PLAN_INTS + plan["hcoef"].size:] = plan["vcoef"]
+    return w, h, total
+
+
 def serve(fin, fout):
-    """Answer requests until stdin closes."""
+    """Answer requests until stdin closes. Request line (tab separated):
+         n_px | small segment or - | byte offset of the slot | big segment or - | byte offset of the region | its size | path
+       Reply: b"0" failed | b"1" the transform's n_px x n_px pixels are in the slot (or follow, when no segment was named) |
+              b"2" + <iiq (w, h, bytes)>: the image sits at full size, with its resize plan, in the region (decode_full)."""
     import mmap
     import os
+    import struct
     segments = {}                                              # name -> mmap of /dev/shm/<name> (the parent owns it)
+
+    def mapped(name):
+        seg = segments.get(name)
+        if seg is None:
+            if len(segments) > 8:                              # the parent rotates a few segments; drop stale mappings
+                _close_all(segments)
+            # plain mmap of the POSIX segment's file: multiprocessing.shared_memory would start a resource-tracker
+            # process per worker and try to unlink the parent's segment at exit (Python < 3.13)
+            fd = os.open("/dev/shm/" + name.lstrip("/"), os.O_RDWR)
+            try:
+                seg = segments[name] = mmap.mmap(fd, 0)
+            finally:
+                os.close(fd)
+        return seg
+
     while True:
         line = fin.readline()
         if not line:
             break
         try:
-            n_px_s, shm_name, off_s, path = line.rstrip(b"\n").split(b"\t", 3)
+            n_px_s, shm_name, off_s, big_name, big_off_s, big_cap_s, path = line.rstrip(b"\n").split(b"\t", 6)
             n_px, off = int(n_px_s), int(off_s)
             fname = path.decode("utf-8", "surrogateescape")
-            if shm_name == b"-":
-                payload = load_uint8(fname, n_px).tobytes()
-            else:
-                name = shm_name.decode()
-                seg = segments.get(name)
-                if seg is None:
-                    if len(segments) > 8:                      # the parent rotates a few segments; drop stale mappings
-                        _close_all(segments)
-                    # plain mmap of the POSIX segment's file: multiprocessing.shared_memory would start a resource-tracker
-                    # process per worker and try to unlink the parent's segment at exit (Python < 3.13)
-                    fd = os.open("/dev/shm/" + name.lstrip("/"), os.O_RDWR)
-                    try:
-                        seg = segments[name] = mmap.mmap(fd, 0)
-                    finally:
-                        os.close(fd)
-                slot = np.frombuffer(seg, dtype=np.uint8, count=3 * n_px * n_px, offset=off).reshape(3, n_px, n_px)
-                load_uint8(fname, n_px, out=slot)
-                slot = None                                    # no view may outlive the request (close() refuses then)
-                payload = b""
+            reply = None
+            if big_name != b"-":
+                region = np.frombuffer(mapped(big_name.decode()), dtype=np.uint8, count=int(big_cap_s), offset=int(big_off_s))
+                full = decode_full(fname, n_px, region)
+                region = None
+                if full is not None:
+                    reply = b"2" + struct.pack("<iiq", *full)
+            if reply is None:
+                if shm_name == b"-":
+                    reply = b"1" + load_uint8(fname, n_px).tobytes()
+                else:
+                    slot = np.frombuffer(mapped(shm_name.decode()), dtype=np.uint8, count=3 * n_px * n_px, offset=off)
+                    load_uint8(fname, n_px, out=slot.reshape(3, n_px, n_px))
+                    slot = None                                # no view may outlive the request (close() refuses then)
+                    reply = b"1"
         except KeyboardInterrupt:
             break
         except Exception:
-            fout.write(b"0")
-            fout.flush()
-            continue
-        fout.write(b"1")
-        if payload:
-            fout.write(payload)
+            reply = b"0"
+        fout.write(reply)
         fout.flush()
     _close_all(segments)
 

@@ -34,7 +34,7 @@ class DecodePool:
                       for _ in range(self.n)]
         self._all_procs = list(self.procs)
         self.threads = ThreadPoolExecutor(max_workers=self.n)
-        self.segs = [None, None]
+        self.segs = [None, None, None, None]      # 0, 1: the n_px x n_px slots of two batches in turn; 2, 3: their full-size regions
 
     def _segment(self, nbytes, which=0):
         from multiprocessing import shared_memory
@@ -60,34 +60,44 @@ class DecodePool:
             seg.close = lambda: None          # a view is still alive: the mapping goes with it; keep __del__ quiet
         self.segs[which] = None
 
-    def _run(self, w, jobs, n_px, name, seg):
-        """Worker w decodes its share of the batch: (slot, path) pairs. If the worker process dies
-        (a file that crashes the decoder, an OOM kill), that file is reported as failed and the rest of the share - and of
-        every later batch - is decoded in this process: no program is spawned once the GPU may have been initialised."""
+    def _run(self, w, jobs, n_px, name, seg, big=None):
+        """Worker w decodes its share of the batch: (slot, path) pairs -> (slot, status) with status False (failed), True
+        (the transform's pixels are in the slot) or (w, h, bytes): the image is in its region of the big segment at full
+        size, for the resize on the device. If the worker process dies (a file that crashes the decoder, an OOM kill), that
+        file is reported as failed and the rest of the share - and of every later batch - is decoded in this process: no
+        program is spawned once the GPU may have been initialised."""
+        import struct
         p = self.procs[w]
         ok = []
         per = 3 * n_px * n_px
-        done = 0
+        bname, bcap = (big[0], big[1]) if big else (b"-", 0)
         if p is not None:
-            # the whole share in one write, the status bytes in one read: this thread sleeps while the worker decodes
-            # (one request per round trip kept 16 parent threads busy handing the GIL around)
-            req = b"".join(b"%d\t%s\t%d\t" % (n_px, name, slot * per) + path.encode("utf-8", "surrogateescape") + b"\n"
-                           for slot, path in jobs)
+            # the whole share in one write: this thread sleeps in read() while the worker decodes (one request per round
+            # trip kept 16 parent threads busy handing the GIL around)
+            req = b"".join(b"%d\t%s\t%d\t%s\t%d\t%d\t" % (n_px, name, slot * per, bname, slot * bcap, bcap) +
+                           path.encode("utf-8", "surrogateescape") + b"\n" for slot, path in jobs)
             try:
                 p.stdin.write(req)
                 p.stdin.flush()
-                st = p.stdout.read(len(jobs))
+                for slot, _ in jobs:
+                    st = p.stdout.read(1)
+                    if st == b"2":
+                        rest = p.stdout.read(16)
+                        if len(rest) < 16:
+                            break
+                        ok.append((slot, struct.unpack("<iiq", rest)))
+                    elif st == b"":
+                        break
+                    else:
+                        ok.append((slot, st == b"1"))
             except (BrokenPipeError, OSError):
-                st = b""
-            ok = [(jobs[i][0], st[i:i + 1] == b"1") for i in range(len(st))]
-            done = len(st)
-            if done < len(jobs):                   # the worker died on file `done`: that one failed, the rest in-process
+                pass
+            if len(ok) < len(jobs):                # the worker died on file len(ok): that one failed, the rest in-process
                 self.procs[w] = None
-                ok.append((jobs[done][0], False))
-                done += 1
-        for slot, path in jobs[done:]:
+                ok.append((jobs[len(ok)][0], False))
+        for slot, path in jobs[len(ok):]:
             try:
-                np.frombuffer(seg.buf, dtype=np.uint8, count=per, offset=slot * per)[:] = load_uint8(path, n_px).reshape(-1)
+                load_uint8(path, n_px, out=np.frombuffer(seg.buf, dtype=np.uint8, count=per, offset=slot * per).reshape(3, n_px, n_px))
                 ok.append((slot, True))
             except KeyboardInterrupt:
                 raise
@@ -95,26 +105,39 @@ class DecodePool:
                 ok.append((slot, False))
         return ok
 
-    def decode(self, paths, n_px, copy=True, segment=0):
+    def decode(self, paths, n_px, copy=True, segment=0, full_cap=0):
         """-> (uint8 array [n_ok,3,n_px,n_px], ok_paths, failed_paths), file order kept. copy=False returns a VIEW of
         the pool's shared-memory segment `segment` (all slots, plus a boolean mask of the good ones instead of the
         compacted array): valid until the next decode() into the same segment - encode_files copies it straight into
-        pinned memory. One decode() at a time (the workers take one request stream)."""
+        pinned memory. One decode() at a time (the workers take one request stream).
+        full_cap > 0 (with copy=False): 8-bit RGB images that need resampling and fit full_cap bytes are delivered at FULL
+        size in a second segment, one region of full_cap bytes per slot (tmpfs pages exist only where written), for the
+        resize on the device; the result is then ((slots view, good mask, big view, {slot: (w, h, bytes)}), ok, bad)."""
         n = len(paths)
         per = 3 * n_px * n_px
         seg = self._segment(max(1, n * per), segment)
         name = seg.name.encode()
+        big = bseg = None
+        if full_cap > 0 and not copy:
+            full_cap = (int(full_cap) + 15) // 16 * 16
+            bseg = self._segment(max(1, n * full_cap), 2 + segment)
+            big = (bseg.name.encode(), full_cap)
         live = [w for w in range(self.n) if self.procs[w] is not None] or [0]
-        futs = [self.threads.submit(self._run, w, [(i, paths[i]) for i in range(k, n, len(live))], n_px, name, seg)
+        futs = [self.threads.submit(self._run, w, [(i, paths[i]) for i in range(k, n, len(live))], n_px, name, seg, big)
                 for k, w in enumerate(live) if k < n]
         good = np.zeros(n, dtype=bool)
+        full = {}
         for f in futs:
-            for slot, fine in f.result():
-                good[slot] = fine
+            for slot, st in f.result():
+                good[slot] = bool(st)
+                if isinstance(st, tuple):
+                    full[slot] = st
         arr = np.frombuffer(seg.buf, dtype=np.uint8, count=n * per).reshape(n, 3, n_px, n_px)
         ok = [p for p, g_ in zip(paths, good) if g_]
         bad = [p for p, g_ in zip(paths, good) if not g_]
         if not copy:
+            if big is not None:
+                return (arr, good, np.frombuffer(bseg.buf, dtype=np.uint8, count=n * full_cap), full), ok, bad
             return (arr, good), ok, bad
         out = arr[good].copy() if not good.all() else arr.copy()
         return out, ok, bad
@@ -132,8 +155,8 @@ class DecodePool:
             except Exception:
                 p.kill()
         self.threads.shutdown(wait=False)
-        self._drop_segment(0)
-        self._drop_segment(1)
+        for which in range(4):
+            self._drop_segment(which)
 
     def __enter__(self):
         return self
@@ -152,14 +175,21 @@ def _load_safe(args):
         return None
 
 
-def encode_files(model, paths, batch=256, workers=8, pool=None):
+def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb=None):
     """Generator over batches: yields (ok_paths, features f32 [n,E] numpy normalised, failed_paths).
     Decode runs in the worker processes of `pool` (a DecodePool) when given, else on `workers` threads (Pillow
-    releases the GIL while decoding, which is enough for large photos and not for small images)."""
+    releases the GIL while decoding, which is enough for large photos and not for small images).
+    device_resize_mb (default $CLIPMI_DEVICE_RESIZE_MB, 0 = off; needs `pool` and a GPU): 8-bit RGB images of up to that
+    many MB decoded travel at full size and are resized + cropped by clipmi_resize_crop_rgb8 - the same pixels, with the
+    workers left to decode only (Pillow's bicubic resize is half of a photo-sized file's host time)."""
+    import os
     n_px = model.visual.input_resolution
     dev = model.device
     use_gpu = dev.type == "cuda"
     copy_stream = torch.cuda.Stream(device=dev) if use_gpu else None
+    if device_resize_mb is None:
+        device_resize_mb = float(os.environ.get("CLIPMI_DEVICE_RESIZE_MB", "0"))
+    full_cap = int(device_resize_mb * (1 << 20)) if (use_gpu and pool is not None) else 0
 
     # three pinned staging buffers used in turn (GPU): batch i may still be in its H2D copy while batch i+1 is filled;
     # a buffer is reused only after the copy that read it has finished. Pixels go shared memory -> pinned -> device:
@@ -177,6 +207,66 @@ def encode_files(model, paths, batch=256, workers=8, pool=None):
         ring.append(slot)
         return slot
 
+    big_ring = []
+
+    def big_staging(nbytes):
+        slot = big_ring.pop(0) if len(big_ring) >= 3 else {"buf": None, "ev": None}
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()
+        if slot["buf"] is None or slot["buf"].numel() < nbytes:
+            slot["buf"] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+            slot["np"] = slot["buf"].numpy()
+        big_ring.append(slot)
+        return slot
+
+    def resize_on_device(devt, bigview, full, good):
+        """The full-size images of the batch: pack [pixels | plan | coefficients]... + job records into one pinned buffer,
+        one H2D copy, clipmi_resize_crop_rgb8 into their rows of devt (on the copy stream, behind devt's own copy)."""
+        from . import _lib
+        from .decode_worker import PLAN_INTS
+        from .resize import JOB
+        comp = np.cumsum(good) - 1                           # slot -> row of devt
+        entries = sorted(full.items())
+        cap = bigview.size // len(good)
+        sizes = [(nb + 15) // 16 * 16 for _, (_, _, nb) in entries]
+        o_jobs = sum(sizes)
+        slot = big_staging(o_jobs + len(entries) * JOB.itemsize)
+        hv = slot["np"]
+        jobs = np.zeros(len(entries), dtype=JOB)
+        off, toff, max_rows = 0, 0, 1
+        for t, (s_, (w, h, nb)) in enumerate(entries):
+            src = bigview[s_ * cap:s_ * cap + nb]
+            np.copyto(hv[off:off + nb], src)
+            o_hdr = (w * h * 3 + 15) // 16 * 16
+            hd = np.frombuffer(src, dtype=np.int32, count=PLAN_INTS, offset=o_hdr)
+            j = jobs[t]
+            j["src_off"], j["w"], j["h"], j["r0"], j["nrows"], j["out_index"] = off, w, h, hd[2], hd[3], comp[s_]
+            j["need_h"], j["need_v"], j["left"], j["top"], j["hk"], j["vk"] = hd[4], hd[5], hd[6], hd[7], hd[8], hd[9]
+            j["hcoef_off"] = (off + o_hdr) // 4 + PLAN_INTS
+            j["vcoef_off"] = j["hcoef_off"] + hd[10]
+            j["tmp_off"] = toff
+            toff += int(hd[3]) * n_px * 3
+            max_rows = max(max_rows, int(hd[3]))
+            off += sizes[t]
+        hv[o_jobs:o_jobs + jobs.nbytes] = jobs.view(np.uint8).reshape(-1)
+        L = _lib.lib()
+        with torch.cuda.stream(copy_stream):
+            dbig = slot["buf"][:o_jobs + jobs.nbytes].to(dev, non_blocking=True)
+            scratch = torch.empty(max(toff, 1), dtype=torch.uint8, device=dev)
+            base = dbig.data_ptr()
+            rc = L.clipmi_resize_crop_rgb8(base, base + o_jobs, len(entries), max_rows, base, n_px, devt.data_ptr(),
+                                           scratch.data_ptr(), _lib.stream_ptr(dev))
+            _lib.check(rc, "clipmi_resize_crop_rgb8")
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        slot["ev"] = ev
+        keep.append((dbig, scratch, ev))                      # alive until the kernel has run
+        while len(keep) > 4:
+            keep.pop(0)
+        return ev
+
+    keep = []
+
     def to_device(host, slot):
         with torch.cuda.stream(copy_stream):
             devt = host.to(dev, non_blocking=True)
@@ -191,7 +281,11 @@ def encode_files(model, paths, batch=256, workers=8, pool=None):
         copy_ fans out over every CPU the host shows (256 here) and its OpenMP team then spins through the container's CPU
         share - every other batch's decode took 80 ms instead of 15 (tools/pipe_probe.py: 26.7 k images/s decode only,
         5.9 k with a torch copy behind each batch)."""
-        (view, good), ok, bad = decoded
+        bigview = full = None
+        if len(decoded[0]) == 4:
+            (view, good, bigview, full), ok, bad = decoded
+        else:
+            (view, good), ok, bad = decoded
         if not ok:
             return ok, bad, None, None
         if not use_gpu:
@@ -202,6 +296,8 @@ def encode_files(model, paths, batch=256, workers=8, pool=None):
         else:
             np.compress(good, view, axis=0, out=slot["np"][:len(ok)])
         devt, ev = to_device(slot["buf"][:len(ok)], slot)
+        if full:
+            ev = resize_on_device(devt, bigview, full, good)
         return ok, bad, devt, ev
 
     def stage(chunk):
@@ -238,7 +334,7 @@ def encode_files(model, paths, batch=256, workers=8, pool=None):
             def decode_job(j):
                 if j - 2 in copies:
                     copies[j - 2].result()                 # segment j & 1 is free again
-                return [pool.decode(chunks[j], n_px, copy=False, segment=j & 1)]
+                return [pool.decode(chunks[j], n_px, copy=False, segment=j & 1, full_cap=full_cap)]
 
             def submit(j):
                 d = dec.submit(decode_job, j)              # (the result travels in a list the copy stage empties: no

@@ -174,3 +174,35 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--quick"], capture_output=True,
                        text=True, timeout=120, cwd=ROOT, env=env)
     assert r.returncode != 0 and '"error"' in r.stdout
+
+
+def test_pipeline_resize_on_device_gives_the_same_vectors(clipmi, gpu, tmp_path):
+    """encode_files with the resize on the device (full-size RGB images -> clipmi_resize_crop_rgb8) returns the vectors of
+    the all-host path bit for bit - the device computes the same pixels - for photo-sized, tall, small, already-sized,
+    grey, RGBA and broken files in one batch sequence."""
+    from PIL import Image
+    rng = np.random.default_rng(21)
+    specs = [(1024, 768, "RGB", "jpg"), (600, 900, "RGB", "jpg"), (224, 224, "RGB", "jpg"), (224, 400, "RGB", "png"),
+             (90, 70, "RGB", "png"), (640, 480, "L", "png"), (500, 300, "RGBA", "png"), (1600, 1200, "RGB", "jpg"),
+             (333, 777, "RGB", "jpg"), (3000, 2000, "RGB", "jpg")]
+    paths = []
+    for i, (w, h, mode, ext) in enumerate(specs):
+        ch = {"RGB": 3, "L": 1, "RGBA": 4}[mode]
+        a = rng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+        p = str(tmp_path / f"f{i:02d}.{ext}")
+        Image.fromarray(a[:, :, 0] if ch == 1 else a, mode).save(p)
+        paths.append(p)
+    bad = str(tmp_path / "f99.jpg")
+    with open(bad, "wb") as f:
+        f.write(b"broken")
+    files = paths[:4] + [bad] + paths[4:]
+    model = clipmi.CLIP(clipmi.weights.random_state_dict("ViT-B/32", seed=0), device=gpu)
+    with clipmi.pipeline.DecodePool(3) as pool:
+        host = list(clipmi.pipeline.encode_files(model, files, batch=4, pool=pool, device_resize_mb=0))
+        devr = list(clipmi.pipeline.encode_files(model, files, batch=4, pool=pool, device_resize_mb=8))   # 3000x2000 stays on the host
+        (_, _, _, full), _, _ = pool.decode(files[:4], 224, copy=False, full_cap=8 << 20)
+        assert sorted(full) == [0, 1, 3] or sorted(full) == [0, 1]      # photo-sized RGB files travel at full size
+    assert [h[0] for h in host] == [d[0] for d in devr] and [h[2] for h in host] == [d[2] for d in devr]
+    assert sum(len(h[0]) for h in host) == len(paths) and host[1][2] == [bad]
+    for h, d in zip(host, devr):
+        assert np.array_equal(h[1], d[1])
