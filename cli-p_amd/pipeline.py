@@ -44,12 +44,43 @@ class DecodePool:
             seg = self.segs[which] = shared_memory.SharedMemory(create=True, size=int(nbytes))
         return seg
 
+    def pin_segment(self, which):
+        """Page-lock segment `which` for the GPU (hipHostRegister through torch's runtime handle) so that it can be copied
+        to the device where it lies - no packing copy in this process. True when it is (already) locked."""
+        seg = self.segs[which]
+        if seg is None:
+            return False
+        reg = self.__dict__.setdefault("_pinned", {})
+        if reg.get(which) == seg.name:
+            return True
+        try:
+            import ctypes
+            addr = ctypes.addressof(ctypes.c_char.from_buffer(seg.buf))
+            rc = torch.cuda.cudart().cudaHostRegister(addr, seg.size, 0)
+            ok = int(rc) == 0
+        except Exception:
+            ok = False
+        if ok:
+            reg[which] = seg.name
+            self.__dict__.setdefault("_pinned_addr", {})[which] = addr
+        return ok
+
+    def _unpin_segment(self, which):
+        reg = self.__dict__.get("_pinned", {})
+        if which in reg:
+            try:
+                torch.cuda.cudart().cudaHostUnregister(self._pinned_addr[which])
+            except Exception:
+                pass
+            reg.pop(which, None)
+
     def _drop_segment(self, which):
         """Unlink first (always possible), then unmap (refused while a caller still holds a view: the mapping then goes
         with the last reference)."""
         seg = self.segs[which]
         if seg is None:
             return
+        self._unpin_segment(which)
         try:
             seg.unlink()
         except Exception:
@@ -228,6 +259,36 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
         comp = np.cumsum(good) - 1                           # slot -> row of devt
         entries = sorted(full.items())
         cap = bigview.size // len(good)
+        if pool.pin_segment(2 + seg_index[0]):
+            # the segment is page-locked: copy it to the device where it lies (one H2D of the used range, no packing copy
+            # on the host: packing 1 GB per batch of photo-sized images with one thread was slower than Pillow's resize)
+            L = _lib.lib()
+            jobs = np.zeros(len(entries), dtype=JOB)
+            toff, max_rows = 0, 1
+            for t, (s_, (w, h, nb)) in enumerate(entries):
+                base_ = s_ * cap
+                o_hdr = (w * h * 3 + 15) // 16 * 16
+                hd = np.frombuffer(bigview, dtype=np.int32, count=PLAN_INTS, offset=base_ + o_hdr)
+                j = jobs[t]
+                j["src_off"], j["w"], j["h"], j["r0"], j["nrows"], j["out_index"] = base_, w, h, hd[2], hd[3], comp[s_]
+                j["need_h"], j["need_v"], j["left"], j["top"], j["hk"], j["vk"] = hd[4], hd[5], hd[6], hd[7], hd[8], hd[9]
+                j["hcoef_off"] = (base_ + o_hdr) // 4 + PLAN_INTS
+                j["vcoef_off"] = j["hcoef_off"] + hd[10]
+                j["tmp_off"] = toff
+                toff += int(hd[3]) * n_px * 3
+                max_rows = max(max_rows, int(hd[3]))
+            used = (entries[-1][0] + 1) * cap
+            with torch.cuda.stream(copy_stream):
+                dbig = torch.from_numpy(bigview[:used]).to(dev, non_blocking=True)
+                djobs = torch.from_numpy(jobs.view(np.uint8).reshape(-1).copy()).to(dev)
+                scratch = torch.empty(max(toff, 1), dtype=torch.uint8, device=dev)
+                rc = L.clipmi_resize_crop_rgb8(dbig.data_ptr(), djobs.data_ptr(), len(entries), max_rows, dbig.data_ptr(), n_px,
+                                               devt.data_ptr(), scratch.data_ptr(), _lib.stream_ptr(dev))
+                _lib.check(rc, "clipmi_resize_crop_rgb8")
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            ev.synchronize()                                  # the segment is decoded into again two batches later
+            return ev
         sizes = [(nb + 15) // 16 * 16 for _, (_, _, nb) in entries]
         o_jobs = sum(sizes)
         slot = big_staging(o_jobs + len(entries) * JOB.itemsize)
@@ -275,6 +336,8 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
         if slot is not None:
             slot["ev"] = ev
         return devt, ev
+
+    seg_index = [0]
 
     def copy_out(decoded, chunk):
         """shared memory -> pinned staging (GPU) or a private tensor (CPU) -> device. numpy copies on purpose: a 65-MB torch
@@ -338,7 +401,7 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
 
             def submit(j):
                 d = dec.submit(decode_job, j)              # (the result travels in a list the copy stage empties: no
-                copies[j] = cpy.submit(lambda d=d, j=j: copy_out(d.result().pop(), chunks[j]))   # view outlives its copy)
+                copies[j] = cpy.submit(lambda d=d, j=j: (seg_index.__setitem__(0, j & 1), copy_out(d.result().pop(), chunks[j]))[1])   # view outlives its copy)
 
             for j in range(min(2, len(chunks))):
                 submit(j)

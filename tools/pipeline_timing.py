@@ -22,7 +22,7 @@ else:                                       # smooth gradients + texture: JPEGs 
         a[::3, ::5] = rng.integers(0, 256, 3)
         Image.fromarray(a).save(os.path.join(d, f"img_{i:05d}.jpg"), quality=90)
 model = clipmi.CLIP(clipmi.weights.random_state_dict("ViT-B/32", seed=0), device=dev)
-paths = sorted(os.path.join(d, f) for f in os.listdir(d))
+paths = sorted(os.path.join(d, f) for f in os.listdir(d)) * int(os.environ.get("PIPE_REPEAT", "1"))   # files decoded again
 for _ in clipmi.pipeline.encode_files(model, paths[:512], batch=256, workers=workers, pool=pool): pass
 t0 = time.perf_counter(); got = 0
 for ok, feats, bad in clipmi.pipeline.encode_files(model, paths, batch=435, workers=workers, pool=pool):
