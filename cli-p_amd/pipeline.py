@@ -220,7 +220,7 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
     copy_stream = torch.cuda.Stream(device=dev) if use_gpu else None
     if device_resize_mb is None:
         device_resize_mb = float(os.environ.get("CLIPMI_DEVICE_RESIZE_MB", "0"))
-    full_cap = int(device_resize_mb * (1 << 20)) if (use_gpu and pool is not None) else 0
+    full_cap = [int(device_resize_mb * (1 << 20)) if (use_gpu and pool is not None) else 0]     # [0]: mutable (may be switched off)
 
     # three pinned staging buffers used in turn (GPU): batch i may still be in its H2D copy while batch i+1 is filled;
     # a buffer is reused only after the copy that read it has finished. Pixels go shared memory -> pinned -> device:
@@ -289,6 +289,9 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
                 ev.record(copy_stream)
             ev.synchronize()                                  # the segment is decoded into again two batches later
             return ev
+        # the segment could not be page-locked (locked-memory limit?): this batch is packed into pinned memory by hand -
+        # slower than Pillow's own resize - and the following ones go back to the host path
+        full_cap[0] = 0
         sizes = [(nb + 15) // 16 * 16 for _, (_, _, nb) in entries]
         o_jobs = sum(sizes)
         slot = big_staging(o_jobs + len(entries) * JOB.itemsize)
@@ -397,7 +400,7 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
             def decode_job(j):
                 if j - 2 in copies:
                     copies[j - 2].result()                 # segment j & 1 is free again
-                return [pool.decode(chunks[j], n_px, copy=False, segment=j & 1, full_cap=full_cap)]
+                return [pool.decode(chunks[j], n_px, copy=False, segment=j & 1, full_cap=full_cap[0])]
 
             def submit(j):
                 d = dec.submit(decode_job, j)              # (the result travels in a list the copy stage empties: no
