@@ -44,6 +44,17 @@ class DecodePool:
             seg = self.segs[which] = shared_memory.SharedMemory(create=True, size=int(nbytes))
         return seg
 
+    @staticmethod
+    def shm_room():
+        """Bytes free for shared-memory segments (/dev/shm is a tmpfs whose pages exist only once written: a segment larger
+        than what is free is created without complaint and kills the writer later; containers default to 64 MB)."""
+        import os
+        try:
+            st = os.statvfs("/dev/shm")
+            return st.f_bavail * st.f_frsize
+        except OSError:
+            return 0
+
     def pin_segment(self, which):
         """Page-lock segment `which` for the GPU (hipHostRegister through torch's runtime handle) so that it can be copied
         to the device where it lies - no packing copy in this process. True when it is (already) locked."""
@@ -220,7 +231,13 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
     copy_stream = torch.cuda.Stream(device=dev) if use_gpu else None
     if device_resize_mb is None:
         device_resize_mb = float(os.environ.get("CLIPMI_DEVICE_RESIZE_MB", "0"))
+    if pool is not None and pool.shm_room() < 2 * batch * 3 * n_px * n_px + (64 << 20):
+        print(f"(shared memory too small for decode workers' batches: {pool.shm_room() >> 20} MB free in /dev/shm; "
+              f"decoding on {workers} threads)")
+        pool = None
     full_cap = [int(device_resize_mb * (1 << 20)) if (use_gpu and pool is not None) else 0]     # [0]: mutable (may be switched off)
+    if full_cap[0] and pool.shm_room() < 2 * batch * (3 * n_px * n_px + full_cap[0]) + (256 << 20):
+        full_cap[0] = 0
 
     # three pinned staging buffers used in turn (GPU): batch i may still be in its H2D copy while batch i+1 is filled;
     # a buffer is reused only after the copy that read it has finished. Pixels go shared memory -> pinned -> device:
