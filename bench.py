@@ -158,13 +158,13 @@ def files_to_vectors_leg(model, pool):
     rate of the box's CPU share); reported beside the headline, never as it."""
     import shutil
     import tempfile
-    n = 10 * 435
+    n = 5 * 435
     d = tempfile.mkdtemp(prefix="clipmi_bench_")
     try:
         for i, blob in enumerate(make_jpegs(n)):
             with open(os.path.join(d, f"img_{i:05d}.jpg"), "wb") as f:
                 f.write(blob)
-        paths = sorted(os.path.join(d, f) for f in os.listdir(d))
+        paths = sorted(os.path.join(d, f) for f in os.listdir(d)) * 4      # 20 batches: every file is decoded four times
         for _ in clipmi.pipeline.encode_files(model, paths[:435], batch=435, pool=pool):
             pass
         t0 = time.perf_counter()
@@ -175,7 +175,7 @@ def files_to_vectors_leg(model, pool):
     finally:
         shutil.rmtree(d, ignore_errors=True)
     return {"value": got / dt, "unit": "images/s", "images": got, "decode_processes": pool.n, "batch": 435,
-            "data": "synthetic 224x224 JPEG files (quality 95) on local disk", "bound": "host decode"}
+            "data": "synthetic 224x224 JPEG files (quality 95) on local disk, 2175 files x 4", "bound": "host decode"}
 
 
 def cpu_baseline_cfg1(sd):
