@@ -176,7 +176,7 @@ class IndexFlatIP:
         elif coarse:
             dbh, rmax = self.matrix_bf16()
             coarse = rmax > 0.0 and np.isfinite(rmax)
-        if coarse and Q >= 2 * self.PASS_Q and self.batches_in_flight > 1 and not self._in_pipeline:
+        if coarse and Q > self.PASS_Q and self.batches_in_flight > 1 and not self._in_pipeline:
             return self._search_pipelined(q, K, out)
         need = (L.clipmi_topk_ip_coarse_workspace_bytes if coarse else L.clipmi_topk_ip_workspace_bytes)(N, self.d, Q, K)
         if need == 0:
@@ -215,7 +215,7 @@ class IndexFlatIP:
     _in_pipeline = False
 
     def _search_pipelined(self, q, K, out):
-        """A search of >= 128 queries on the coarse path: its 64-query passes alternate between the caller's stream and an
+        """A search of more than 64 queries on the coarse path: its 64-query passes alternate between the caller's stream and an
         internal HIP stream (each with its own workspace), so one pass's latency-bound side kernels run beside the other's
         HBM-bound scan -
         what bench.py measures as "two batches in flight" (0.97-1.03 vs 1.09-1.10 ms per pass at 10 M rows). Same calls,
