@@ -395,7 +395,7 @@ def test_two_search_batches_in_flight_on_two_streams(clipmi, gpu, topk_oracle):
 
 @pytest.mark.parametrize("kind", ["int8", "bf16"])
 def test_large_query_batch_is_pipelined_and_exact(clipmi, gpu, topk_oracle, kind):
-    """A search of >= 128 queries runs its 64-query passes alternately on the caller's stream and an internal one
+    """A search of more than 64 queries runs its 64-query passes alternately on the caller's stream and an internal one
     (index.py _search_pipelined): the oracle's bits, the same bits as the one-stream form, and usable back to back."""
     rng = np.random.default_rng(4242)
     N, Q, K = 90_000, 200, 51
