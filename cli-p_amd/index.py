@@ -159,7 +159,7 @@ class IndexFlatIP:
         return self.coarse in ("bf16", "int8") and self.d == 512 and self.ntotal >= 65536
 
     # -- query side ---------------------------------------------------------------------------
-    def search_device(self, q, K, out=None):
+    def search_device(self, q, K, out=None, _one_pass=False):
         """q: f32 [Q,d] device tensor -> (scores f32 [Q,K], ids i64 [Q,K]) device tensors. Async.
         `out` = (scores, ids) views to write into (the packed all-gather record of ShardedFlatIP)."""
         L = _lib.lib()
@@ -176,7 +176,7 @@ class IndexFlatIP:
         elif coarse:
             dbh, rmax = self.matrix_bf16()
             coarse = rmax > 0.0 and np.isfinite(rmax)
-        if coarse and Q > self.PASS_Q and self.batches_in_flight > 1 and not self._in_pipeline:
+        if coarse and Q > self.PASS_Q and self.batches_in_flight > 1 and not _one_pass:
             return self._search_pipelined(q, K, out)
         need = (L.clipmi_topk_ip_coarse_workspace_bytes if coarse else L.clipmi_topk_ip_workspace_bytes)(N, self.d, Q, K)
         if need == 0:
@@ -212,7 +212,6 @@ class IndexFlatIP:
 
     PASS_Q = 64                   # queries of one coarse pass (csrc/topk.hip COARSE_Q)
     batches_in_flight = 2         # 64-query passes of ONE large search kept in flight on internal streams (1 = off)
-    _in_pipeline = False
 
     def _search_pipelined(self, q, K, out):
         """A search of more than 64 queries on the coarse path: its 64-query passes alternate between the caller's stream and an
@@ -237,14 +236,10 @@ class IndexFlatIP:
         lanes = [cur] + side
         for s_ in side:
             s_.wait_stream(cur)                       # q, the outputs and the index copies are ready
-        self._in_pipeline = True
-        try:
-            for gi, lo in enumerate(range(0, Q, self.PASS_Q)):
-                hi = min(Q, lo + self.PASS_Q)
-                with torch.cuda.stream(lanes[gi % len(lanes)]):
-                    self.search_device(q[lo:hi], K, out=(out_s[lo:hi], out_i[lo:hi]))
-        finally:
-            self._in_pipeline = False
+        for gi, lo in enumerate(range(0, Q, self.PASS_Q)):
+            hi = min(Q, lo + self.PASS_Q)
+            with torch.cuda.stream(lanes[gi % len(lanes)]):
+                self.search_device(q[lo:hi], K, out=(out_s[lo:hi], out_i[lo:hi]), _one_pass=True)
         for s_ in side:
             cur.wait_stream(s_)
         return out_s, out_i
