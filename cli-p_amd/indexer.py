@@ -18,7 +18,7 @@ committed in rank order; rank 0 alone assembles the matrix and writes `images.in
 Weights: $CLIPMI_WEIGHTS (a local ViT-B-32.pt / state-dict), or CLIPMI_RANDOM_WEIGHTS=<seed> for a
 synthetic model. Knobs: CLIPMI_BATCH (default 435 = whole rounds of GEMM tiles on 256 CUs),
 CLIPMI_WORKERS (decode workers per rank, default min(16, CPUs / ranks on the node)), CLIPMI_DECODE (`procs`, the default: worker processes started before
-the GPU is touched — 17 k images/s end to end from 224 x 224 JPEGs on 16 workers against 4 k on threads, which the GIL
+the GPU is touched — 23 k images/s end to end from 224 x 224 JPEGs on 16 workers against 4 k on threads, which the GIL
 binds; `threads`: the old form).
 """
 import os
@@ -96,7 +96,7 @@ def finalise(db, device, out="images.index"):
 
 def default_workers():
     """Decode workers per rank when CLIPMI_WORKERS is not set: the CPUs this process may run on, shared between the
-    ranks of the node, at most 16 (16 workers: 17 k images/s from 224 x 224 JPEGs, 8: 13 k)."""
+    ranks of the node, at most 16 (16 workers: 23 k images/s from 224 x 224 JPEGs, 8: 14 k)."""
     try:
         cpus = len(os.sched_getaffinity(0))
     except AttributeError:

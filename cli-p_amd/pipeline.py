@@ -358,6 +358,7 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
         return devt, ev
 
     seg_index = [0]
+    pin_small = os.environ.get("CLIPMI_PIN_SHM", "1") != "0"
 
     def copy_out(decoded, chunk):
         """shared memory -> pinned staging (GPU) or a private tensor (CPU) -> device. numpy copies on purpose: a 65-MB torch
@@ -373,12 +374,18 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
             return ok, bad, None, None
         if not use_gpu:
             return ok, bad, torch.from_numpy(view[good] if len(ok) != len(chunk) else view.copy()), None
-        slot = staging(len(ok))
-        if len(ok) == len(chunk):
-            np.copyto(slot["np"][:len(ok)], view)
+        if len(ok) == len(chunk) and pin_small and pool.pin_segment(seg_index[0]):
+            # the segment itself is page-locked (hipHostRegister): copy it to the device where it lies, and let this
+            # thread wait for the copy (1-2 ms) - the segment is decoded into again two batches later
+            devt, ev = to_device(torch.from_numpy(view), None)
+            ev.synchronize()
         else:
-            np.compress(good, view, axis=0, out=slot["np"][:len(ok)])
-        devt, ev = to_device(slot["buf"][:len(ok)], slot)
+            slot = staging(len(ok))
+            if len(ok) == len(chunk):
+                np.copyto(slot["np"][:len(ok)], view)
+            else:
+                np.compress(good, view, axis=0, out=slot["np"][:len(ok)])
+            devt, ev = to_device(slot["buf"][:len(ok)], slot)
         if full:
             ev = resize_on_device(devt, bigview, full, good)
         return ok, bad, devt, ev
