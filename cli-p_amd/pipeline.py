@@ -397,10 +397,12 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
         bad = [p for p, a in zip(chunk, arrs) if a is None]
         if not ok:
             return ok, bad, None, None
-        host = torch.from_numpy(np.stack([a for a in arrs if a is not None]))
+        good_arrs = [a for a in arrs if a is not None]
         if not use_gpu:
-            return ok, bad, host, None
-        devt, ev = to_device(host.pin_memory(), None)
+            return ok, bad, torch.from_numpy(np.stack(good_arrs)), None
+        slot = staging(len(ok))                            # numpy writes straight into pinned memory (no torch copy: see copy_out)
+        np.stack(good_arrs, out=slot["np"][:len(ok)])
+        devt, ev = to_device(slot["buf"][:len(ok)], slot)
         return ok, bad, devt, ev
 
     chunks = [paths[i:i + batch] for i in range(0, len(paths), batch)]
