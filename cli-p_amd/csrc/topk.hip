@@ -15,6 +15,7 @@
 //     a beats b  <=>  a.score > b.score || (a.score == b.score && a.id < b.id); NaN never selected.
 #include "common.hpp"
 #include <float.h>
+#include <stdlib.h>
 #include <type_traits>
 #include <hip/hip_ext.h>
 
@@ -382,7 +383,8 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
                                                                  int K, long long id_base, float* out_s,
                                                                  long long* out_i, float* thr_out,
                                                                  const unsigned* run_if, unsigned* m_out = nullptr,
-                                                                 int keep = 0, int stage_cap = -1, float* qmeta = nullptr) {
+                                                                 int keep = 0, int stage_cap = -1, float* qmeta = nullptr,
+                                                                 int qs = 64) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (run_if && *run_if == 0) return;
     unsigned long long* red = reinterpret_cast<unsigned long long*>(smem);   // [16] min, [16] max
@@ -508,7 +510,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
             }
             if (thr_out && rank == K - 1) thr_out[q] = __uint_as_float(me.x);
             // coarse search: the next segment's scan threshold, (tau - margin) / t_q (coarse_prep_kernel's qmeta)
-            if (qmeta && rank == K - 1) qmeta[128 + q] = (__uint_as_float(me.x) - qmeta[192 + q]) * qmeta[q];
+            if (qmeta && rank == K - 1) qmeta[2 * qs + q] = (__uint_as_float(me.x) - qmeta[3 * qs + q]) * qmeta[q];
         }
         if (out_s)
             for (int e = need + tid; e < K; e += SEL_THREADS) {
@@ -516,7 +518,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
                 out_i[(size_t)q * K + e] = -1;
             }
         if (thr_out && need < K && tid == 0) thr_out[q] = -INFINITY;
-        if (qmeta && need < K && tid == 0) qmeta[128 + q] = -INFINITY;
+        if (qmeta && need < K && tid == 0) qmeta[2 * qs + q] = -INFINITY;
     };
     if (staged) passes([&](long long e) -> uint2 { return lent[e]; });
     else passes([&](long long e) -> uint2 { return src[e]; });
@@ -659,19 +661,20 @@ __global__ void __launch_bounds__(256) quantize_rows_i8_kernel(const float* __re
     if (lane == 0) meta[r] = make_float2(s, sqrtf(ee) * 1.001f);
 }
 
-// Per-query constants of a coarse search, once per group of <= 64 queries (one wave per query), qmeta [4][64]:
-//   [0]   1 / t_q (int8; t_q = max|y| / 127)            or 1 (bf16)
-//   [64]  1.001 ||y|| / t_q (int8)                       or 0
-//   [128] the value the scan compares against, (tau - margin) * [0] - written by select_topk_kernel each time a new exact
-//         K-th best tau is known (-inf until then)
-//   [192] margin: 1.001 (R_max + A_max) ||f_q|| + 1e-4 R_max ||y|| (int8, f_q = y - t_q p_q) or 1.001 * 0.0041 R_max ||q||
+// Per-query constants of a coarse search, once per group of <= qs queries (one wave per query), qmeta [4][qs]
+// (qs = 64 for the 64-query passes, the padded query count of a wide pass):
+//   [0]    1 / t_q (int8; t_q = max|y| / 127)            or 1 (bf16)
+//   [qs]   1.001 ||y|| / t_q (int8)                       or 0
+//   [2 qs] the value the scan compares against, (tau - margin) * [0] - written by select_topk_kernel each time a new exact
+//          K-th best tau is known (-inf until then)
+//   [3 qs] margin: 1.001 (R_max + A_max) ||f_q|| + 1e-4 R_max ||y|| (int8, f_q = y - t_q p_q) or 1.001 * 0.0041 R_max ||q||
 //         (bf16); +inf when it is not a number (the threshold then stays -inf: everything survives, the result stays exact)
 // and the query image the scan kernels copy into LDS (entry [(qg*KS + s)*64 + lane] = 16 bytes of query 16 qg + (lane & 15):
 // bf16 k = 32 s + 8 g .. + 7, or int8 k = 64 s + 16 g .. + 15, g = lane >> 4; zero for queries >= QA). Block 0 also clears
 // the call's control words (candidate counters, overflow flag): no memset node.
 template <bool I8>
 __global__ void __launch_bounds__(256) coarse_prep_kernel(const float* __restrict__ q, int E, float rmax, float amax, int QA,
-                                                          float* qmeta, uint4* qimage, unsigned* ctl, int nctl) {
+                                                          float* qmeta, uint4* qimage, unsigned* ctl, int nctl, int qs) {
     constexpr int KS = 512 / (I8 ? 64 : 32);
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -705,9 +708,9 @@ __global__ void __launch_bounds__(256) coarse_prep_kernel(const float* __restric
         float margin = I8 ? 1.001f * (rmax + amax) * F + 1e-4f * rmax * Y : 0.0041f * rmax * Y * 1.001f;
         if (!(margin == margin) || !(Y == Y)) margin = INFINITY;
         qmeta[qi] = inv;
-        qmeta[64 + qi] = I8 ? 1.001f * Y * inv : 0.f;
-        qmeta[128 + qi] = -INFINITY;
-        qmeta[192 + qi] = margin;
+        qmeta[qs + qi] = I8 ? 1.001f * Y * inv : 0.f;
+        qmeta[2 * qs + qi] = -INFINITY;
+        qmeta[3 * qs + qi] = margin;
     }
     if (lane < KS * 4) {
         const int s_ = lane >> 2, g_ = lane & 3;
@@ -755,6 +758,7 @@ struct CoarseArgs {
 // overrun by construction (and the append is bound-checked all the same: a miss arms the exact fallback). 6 KiB per
 // wave keeps a 64-query int8 scan workgroup at 56 KiB of LDS, so the small kernels of ANOTHER batch in flight (exact
 // re-scoring 72 KiB, selects, the sample scan 64 KiB) fit on the same CU instead of waiting for the scan to drain.
+constexpr int COARSE_QS = 64;           // qmeta stride of the 64-query passes
 constexpr int COARSE_FLUSH = 512;       // flush when more than this many are pending
 constexpr int COARSE_LIST = COARSE_FLUSH + 256;
 constexpr size_t COARSE_WAVE_BYTES = (size_t)COARSE_LIST * 8 + 16;
@@ -817,8 +821,8 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
         active[qg] = qg * 16 + col < a.QA;
-        tau[qg] = active[qg] ? a.qmeta[128 + qg * 16 + col] : INFINITY;
-        yt[qg] = (I8 && active[qg]) ? a.qmeta[64 + qg * 16 + col] : 0.f;
+        tau[qg] = active[qg] ? a.qmeta[2 * COARSE_QS + qg * 16 + col] : INFINITY;
+        yt[qg] = (I8 && active[qg]) ? a.qmeta[COARSE_QS + qg * 16 + col] : 0.f;
     }
 
     // steps are counted from row 0 of the copy (row0 % 32 == 0), so row = 32 step + ... is the global row id
@@ -1041,6 +1045,257 @@ __global__ void __launch_bounds__(256) rescore_pairs_kernel(const float* __restr
             wave_lds_sync();
         }
         if (my < M) lst[my].x = __float_as_uint(acc == acc ? acc : -INFINITY);      // NaN never ranks
+    }
+}
+
+// =================================================================================================
+// Wide coarse pass (int8 copy only): ONE stream of the copy for up to WIDE_MAX_Q = 1024 queries of one search call
+// (reference: query-index.py:111 is one index.search call; SURVEY.md §8d "DB streamed once per batch").
+//
+// The 64-query pass above is HBM-bound with the matrix cores 17 % busy; a search of Q >> 64 queries as Q / 64 such
+// passes streams the copy Q / 64 times. Here the queries are cut into tiles of <= 256 (a 128-KiB int8 image in LDS)
+// and every workgroup keeps ONE tile resident for the whole launch. Workgroups with the same `row lane` and different
+// tiles walk the same rows of the copy in the same order; they sit on one XCD (blockIdx % 8 labels the XCD's share of
+// the grid - speed only), so the copy crosses HBM about once per launch and the other tiles' reads are L2 / Infinity
+// Cache hits. Per 32-row step a wave holds the rows' fragments in registers (16 KiB) and walks the tile's 64-query sets:
+// per set and k-step 4 query fragments from LDS feed 8 MFMAs (both 16-row tiles: half an LDS read per MFMA, so the LDS
+// pipe is at 50 % when the matrix pipe is full); the fragments' registers are refilled with the next step's rows during
+// the LAST set. Two waves per SIMD (512 threads): one wave's compare epilogue and its wait for the next rows run under
+// the other's MFMAs. The pass is matrix-bound: 2 N Q 512 int8 operations per launch.
+// Survivors go to the same per-query lists as the 64-query pass's (entries appended by ballot prefix, no LDS atomics).
+// =================================================================================================
+constexpr int WIDE_MAX_Q = 1024;                 // queries of one wide launch (4 tiles of 256)
+constexpr int WIDE_TILE_SETS = 4;                // 64-query sets per tile: 4 x 32 KiB of image
+constexpr int WIDE_FLUSH = 128;                  // pending pairs per wave that trigger a flush
+constexpr int WIDE_LIST = WIDE_FLUSH + 256;      // a (row tile, query group) block appends <= 256 behind a pending flush
+constexpr size_t WIDE_WAVE_BYTES = (size_t)WIDE_LIST * 8;
+constexpr long long WIDE_CAP = 1ll << 15;        // candidate slots per query of a wide pass (overflow arms the exact fallback)
+
+struct WideArgs {
+    const signed char* dbc;      // int8 [nrows][512]
+    const float2* rmeta;         // per row (scale, error norm), padded to 32 rows
+    const float* qmeta;          // [4][qs]
+    const uint4* qimage;         // all queries' image, 64-query sets of 32 KiB
+    long long row0, nrows;       // rows [row0, row0 + nrows), row0 % 32 == 0
+    int Q, qs;
+    int nqt, spt;                // query tiles, 64-query sets per tile (<= WIDE_TILE_SETS)
+    uint2* cand;                 // [Q][cap]
+    unsigned* gcnt;              // [qs]
+    long long cap;
+    unsigned* overflow;
+};
+
+__device__ __noinline__ void wide_flush(const uint2* list, int n, int qbase, unsigned* gcnt, uint2* cand, long long cap,
+                                        unsigned* overflow) {
+    const int lane = threadIdx.x & 63;
+    wave_lds_sync();
+    for (int e = lane; e < n; e += 64) {
+        const uint2 c = list[e];
+        const unsigned q = (unsigned)qbase + c.x;
+        const unsigned pos = atomicAdd(&gcnt[q], 1u);
+        if ((long long)pos < cap) cand[(size_t)q * cap + pos] = make_uint2(0u, c.y);
+        else *overflow = 1u;
+    }
+    wave_lds_sync();
+}
+
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) scan_coarse_wide_kernel(WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = 8, ROWB = 512, QGS = 4;                // k-steps per row tile, bytes per row, query groups per set
+    constexpr int SET_ENTRIES = QGS * KS * 64;                // 16-byte entries of one set's image (32 KiB)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, g = lane >> 4;
+
+    // workgroup -> (query tile, row lane): blocks b, b + 8, ... share an XCD (observed dispatch; speed only)
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, jb = gridDim.x >> 3;
+    const int rlx = jb / a.nqt;                               // row lanes per XCD label
+    if (j >= rlx * a.nqt) return;
+    const int qt = j % a.nqt, rl = (j / a.nqt) * 8 + x, nrl = rlx * 8;
+    const int set0 = qt * a.spt;
+    int nsets = ((a.Q + 63) >> 6) - set0;
+    nsets = nsets > a.spt ? a.spt : nsets;
+    if (nsets < 1) return;
+    const int qbase = set0 * 64;
+
+    uint4* qimg = reinterpret_cast<uint4*>(smem);
+    {
+        const uint4* src = a.qimage + (size_t)set0 * SET_ENTRIES;
+        const int n = nsets * SET_ENTRIES;                    // multiple of 2048
+        for (int base = tid; base < n; base += 8 * WAVES * 64) {
+            uint4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = base + i * WAVES * 64 < n ? src[base + i * WAVES * 64] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (base + i * WAVES * 64 < n) qimg[base + i * WAVES * 64] = v[i];
+        }
+    }
+    float* ltau = reinterpret_cast<float*>(smem + (size_t)a.spt * SET_ENTRIES * 16);       // [256] scaled thresholds
+    float* lyt = ltau + 64 * WIDE_TILE_SETS;                                               // [256] 1.001 ||y|| / t_q
+    for (int i = tid; i < 64 * WIDE_TILE_SETS; i += WAVES * 64) {
+        const bool act = i < nsets * 64 && qbase + i < a.Q;
+        ltau[i] = act ? a.qmeta[2 * a.qs + qbase + i] : INFINITY;
+        lyt[i] = act ? a.qmeta[a.qs + qbase + i] : 0.f;
+    }
+    uint2* list = reinterpret_cast<uint2*>(reinterpret_cast<char*>(lyt + 64 * WIDE_TILE_SETS) + (size_t)wave * WIDE_WAVE_BYTES);
+    __syncthreads();
+
+    const long long step0 = a.row0 >> 5;
+    const long long nsteps = step0 + ((a.nrows + 31) >> 5);
+    const long long tw = (long long)nrl * WAVES;
+    const long long last_row = a.row0 + a.nrows - 1;
+    int npend = 0;                                            // wave-uniform: pairs pending in `list`
+
+    long long step = step0 + (long long)rl * WAVES + wave;
+    if (step < nsteps) {
+        uint4 T[2 * KS];
+        auto frag_ptr = [&](long long st, int rt) {
+            long long r = st * 32 + rt * 16 + col;
+            r = r > last_row ? last_row : r;
+            return reinterpret_cast<const char*>(a.dbc) + r * ROWB + 16 * g;
+        };
+        uint4 M[4];
+        auto load_meta = [&](long long st, uint4* m) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const uint4* mp = reinterpret_cast<const uint4*>(a.rmeta + st * 32 + rt * 16 + 4 * g);
+                m[2 * rt] = mp[0];
+                m[2 * rt + 1] = mp[1];
+            }
+        };
+        {
+            const char* p0 = frag_ptr(step, 0);
+            const char* p1 = frag_ptr(step, 1);
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {
+                T[s_] = *reinterpret_cast<const uint4*>(p0 + 64 * s_);
+                T[KS + s_] = *reinterpret_cast<const uint4*>(p1 + 64 * s_);
+            }
+            load_meta(step, M);
+        }
+        while (true) {
+            const long long nxt = step + tw;
+            const bool has_next = nxt < nsteps;
+            const char* pn0 = frag_ptr(has_next ? nxt : step, 0);
+            const char* pn1 = frag_ptr(has_next ? nxt : step, 1);
+            uint4 MN[4];
+            load_meta(has_next ? nxt : step, MN);
+            const float sr[2][4] = {{__uint_as_float(M[0].x), __uint_as_float(M[0].z), __uint_as_float(M[1].x), __uint_as_float(M[1].z)},
+                                    {__uint_as_float(M[2].x), __uint_as_float(M[2].z), __uint_as_float(M[3].x), __uint_as_float(M[3].z)}};
+            const float ar[2][4] = {{__uint_as_float(M[0].y), __uint_as_float(M[0].w), __uint_as_float(M[1].y), __uint_as_float(M[1].w)},
+                                    {__uint_as_float(M[2].y), __uint_as_float(M[2].w), __uint_as_float(M[3].y), __uint_as_float(M[3].w)}};
+
+            // one 64-query set against the step's 32 rows; REFILL: the fragments' registers take the next step's rows
+            auto run_set = [&](int set, auto refill) {
+                constexpr bool REFILL = decltype(refill)::value;
+                const uint4* img = qimg + (size_t)set * SET_ENTRIES;
+                i32x4 acc[2][QGS];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int qg = 0; qg < QGS; ++qg) acc[rt][qg] = i32x4{0, 0, 0, 0};
+                uint4 B[2][QGS];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int qg = 0; qg < QGS; ++qg) B[0][qg] = img[(qg * KS + 0) * 64 + lane];
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    if (s_ + 1 < KS) {
+#pragma unroll
+                        for (int qg = 0; qg < QGS; ++qg) B[(s_ + 1) & 1][qg] = img[(qg * KS + s_ + 1) * 64 + lane];
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                        for (int qg = 0; qg < QGS; ++qg)
+                            acc[rt][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, T[rt * KS + s_]),
+                                                                                __builtin_bit_cast(i32x4, B[s_ & 1][qg]),
+                                                                                acc[rt][qg], 0, 0, 0);
+                    if (REFILL) {
+                        T[s_] = *reinterpret_cast<const uint4*>(pn0 + 64 * s_);
+                        T[KS + s_] = *reinterpret_cast<const uint4*>(pn1 + 64 * s_);
+                    }
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, QGS, 0);                   // k-step 0's query fragments
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    if (s_ + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, QGS, 0);   // DS reads: next k-step's fragments
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * QGS, 0);                // this k-step's MFMAs
+                    if (REFILL) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);          // VMEM reads: the refills
+                }
+                __builtin_amdgcn_sched_barrier(0);
+
+                // compare: D * s_r + a_r * 1.001 ||y|| / t_q  >=  (tau - margin) / t_q
+                float tau[QGS], yt[QGS];
+#pragma unroll
+                for (int qg = 0; qg < QGS; ++qg) {
+                    tau[qg] = ltau[set * 64 + qg * 16 + col];
+                    yt[qg] = lyt[set * 64 + qg * 16 + col];
+                }
+                bool pass[2][QGS][4];
+                bool any = false;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int qg = 0; qg < QGS; ++qg)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float val = fmaf((float)acc[rt][qg][r], sr[rt][r], ar[rt][r] * yt[qg]);
+                            pass[rt][qg][r] = (val >= tau[qg]) && (step * 32 + rt * 16 + 4 * g + r <= last_row);
+                            any |= pass[rt][qg][r];
+                        }
+                if (__ballot(any)) {
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                        for (int qg = 0; qg < QGS; ++qg) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const unsigned long long m = __ballot(pass[rt][qg][r]);
+                                if (m) {
+                                    const int pos = npend + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                    if (pass[rt][qg][r])
+                                        list[pos] = make_uint2((unsigned)(set * 64 + qg * 16 + col),
+                                                               (unsigned)(step * 32 + rt * 16 + 4 * g + r));
+                                    npend += __builtin_popcountll(m);
+                                }
+                            }
+                            if (npend > WIDE_FLUSH) {
+                                wide_flush(list, npend, qbase, a.gcnt, a.cand, a.cap, a.overflow);
+                                npend = 0;
+                            }
+                        }
+                }
+            };
+            for (int set = 0; set + 1 < nsets; ++set) run_set(set, std::false_type{});
+            run_set(nsets - 1, std::true_type{});
+
+            if (!has_next) break;
+            step = nxt;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) M[i] = MN[i];
+        }
+    }
+    // final publication, aggregated per block (one returning global atomic per (block, query))
+    __syncthreads();
+    constexpr int QMAXC = 64 * WIDE_TILE_SETS;
+    unsigned* hist = reinterpret_cast<unsigned*>(smem);              // the image is dead now
+    unsigned* gbase = hist + QMAXC;
+    unsigned* hoff = hist + 2 * QMAXC;
+    for (int i = tid; i < QMAXC; i += WAVES * 64) { hist[i] = 0; hoff[i] = 0; }
+    __syncthreads();
+    for (int e = lane; e < npend; e += 64) atomicAdd(&hist[list[e].x], 1u);
+    __syncthreads();
+    for (int i = tid; i < QMAXC; i += WAVES * 64) gbase[i] = hist[i] ? atomicAdd(&a.gcnt[qbase + i], hist[i]) : 0u;
+    __syncthreads();
+    for (int e = lane; e < npend; e += 64) {
+        const uint2 c = list[e];
+        const unsigned pos = gbase[c.x] + atomicAdd(&hoff[c.x], 1u);
+        if ((long long)pos < a.cap) a.cand[(size_t)(qbase + c.x) * a.cap + pos] = make_uint2(0u, c.y);
+        else *a.overflow = 1u;
     }
 }
 
@@ -1308,10 +1563,10 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             const int nq = (qa + 15) / 16 * 16;
             if (i8)
                 hipLaunchKernelGGL(coarse_prep_kernel<true>, dim3(nq / 4), dim3(256), 0, st, qg, E, rmax, amax, qa, w.qmeta, w.qimage,
-                                   w.gcnt_e, COARSE_CTL);
+                                   w.gcnt_e, COARSE_CTL, COARSE_QS);
             else
                 hipLaunchKernelGGL(coarse_prep_kernel<false>, dim3(nq / 4), dim3(256), 0, st, qg, E, rmax, amax, qa, w.qmeta, w.qimage,
-                                   w.gcnt_e, COARSE_CTL);
+                                   w.gcnt_e, COARSE_CTL, COARSE_QS);
             CLIPMI_CHECK_LAUNCH("coarse_prep_kernel");
         }
         ScanArgs a;
@@ -1420,6 +1675,172 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
     }
     return 0;
 }
+
+// ---- wide pass: host side -----------------------------------------------------------------------------------------
+struct WideWs {
+    uint2* cand_e; uint2* cand_c; unsigned* gcnt_e; unsigned* gcnt_c; unsigned* flag; float* thr0; unsigned* last_m;
+    float* qmeta; uint4* qimage;
+};
+
+inline int wide_qs(int Q) { return (Q + 63) / 64 * 64; }
+
+size_t carve_wide(const Plan& p, int Qc, void* base, size_t cap, WideWs* w) {
+    const size_t qs = (size_t)wide_qs(Qc);
+    Arena ar(base ? base : reinterpret_cast<void*>(256), cap);
+    WideWs x;
+    x.cand_e = ar.take<uint2>(qs * p.cap);            // the exact fallback's lists
+    x.cand_c = ar.take<uint2>(qs * WIDE_CAP);
+    x.gcnt_e = ar.take<unsigned>(2 * qs + 4);         // one control block, cleared by coarse_prep_kernel
+    x.gcnt_c = x.gcnt_e + qs;
+    x.flag = x.gcnt_e + 2 * qs;
+    x.thr0 = ar.take<float>(qs);
+    x.last_m = ar.take<unsigned>(qs);
+    x.qmeta = ar.take<float>(4 * qs);
+    x.qimage = ar.take<uint4>(qs / 64 * 2048);        // 32 KiB per 64-query set
+    if (w) *w = x;
+    return ar.off + 256;
+}
+
+bool wide_disabled() {          // CLIPMI_WIDE=0: searches of more than 64 queries as 64-query passes (A/B aid)
+    static const bool off = [] { const char* e = getenv("CLIPMI_WIDE"); return e && atoi(e) == 0; }();
+    return off;
+}
+
+int wide_waves() {
+    static const int w = [] {
+        const char* e = getenv("CLIPMI_WIDE_WAVES");
+        return e && atoi(e) == 4 ? 4 : 8;
+    }();
+    return w;
+}
+
+template <int WAVES>
+int launch_wide_t(const WideArgs& a, hipStream_t st, hipEvent_t* ev) {
+    const size_t lds = (size_t)a.spt * 32768 + 2048 + WAVES * WIDE_WAVE_BYTES;
+    if (lds > (size_t)LDS_LIMIT) return set_err(CLIPMI_EUNSUPPORTED, "scan_coarse_wide: %zu B of LDS", lds);
+    if (int rc = opt_in_lds((const void*)scan_coarse_wide_kernel<WAVES>, lds)) return rc;
+    if (ev) (void)hipEventRecord(ev[0], st);
+    hipLaunchKernelGGL((scan_coarse_wide_kernel<WAVES>), dim3(NUM_CU), dim3(WAVES * 64), lds, st, a);
+    if (ev) (void)hipEventRecord(ev[1], st);
+    CLIPMI_CHECK_LAUNCH("scan_coarse_wide_kernel");
+    return 0;
+}
+
+// segment boundaries of a wide search: rows [0, b[0]), [b[0], b[1]), ... [b[n-2], N); b[n-1] = N. After every segment the
+// exact K-th best of all rows seen so far filters the next one, so the boundaries grow geometrically: with ratio r the
+// number of exactly re-scored rows per query is about (segments) x (r - 1) x K x e^{0.36 z} - 4 segments of ratio ~5 from
+// 64 k rows give ~3.3 k at 10 M rows where the 64-query pass's three (ratio ~10 from N K / 2048) give ~5 k; a wide pass
+// re-scores for up to 1024 queries at once (2 KB of f32 row per pair), so its re-scoring bytes rival the scan's.
+constexpr int WIDE_MAX_SEGS = 8;
+int wide_segments(long long N, int K, long long S1, long long* b) {
+    static const long long first = [] { const char* e = getenv("CLIPMI_WIDE_SEG0"); return e ? atoll(e) : 0ll; }();
+    static const int ratio = [] { const char* e = getenv("CLIPMI_WIDE_SEG_RATIO"); return e && atoi(e) >= 2 ? atoi(e) : 5; }();
+    long long s = first > 0 ? first : 65536;
+    if (s < S1) s = S1;
+    s = (s + 31) & ~31ll;
+    int n = 0;
+    while (n < WIDE_MAX_SEGS - 1 && s * 2 <= N && s + 65536 <= N) {
+        b[n++] = s;
+        s = (s * ratio) & ~31ll;
+    }
+    b[n++] = N;
+    (void)K;
+    return n;
+}
+
+// int8 coarse-then-exact search of 64 < Q queries: chunks of <= WIDE_MAX_Q queries, each ONE pass of the copy in segments
+int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta, float amax, int64_t N, int E, float rmax,
+                   const float* q_dev, int Q, int K, int64_t id_base, float* out_score_dev, int64_t* out_id_dev, void* ws_dev,
+                   size_t ws_bytes, void* stream, hipEvent_t* scan_ev, int max_ev, int* n_ev) {
+    if (!db_dev || !db8_dev || !q_dev || !out_score_dev || !out_id_dev || !ws_dev || !rmeta)
+        return set_err(CLIPMI_EINVAL, "topk_ip_coarse_i8: NULL pointer");
+    if (!(amax >= 0.f)) return set_err(CLIPMI_EINVAL, "topk_ip_coarse_i8: amax=%g", amax);
+    if (E != 512 || N < SAMPLE_MIN_N) return set_err(CLIPMI_EUNSUPPORTED, "topk_ip_coarse: needs E = 512 and N >= %d", SAMPLE_MIN_N);
+    if (!(rmax > 0.f) || N >= (1ll << 32) - 1) return set_err(CLIPMI_EINVAL, "topk_ip_coarse: rmax=%g N=%lld", rmax, (long long)N);
+    Plan p;
+    if (!coarse_plan(N, E, Q, K, p)) return set_err(CLIPMI_EINVAL, "topk_ip_coarse: unsupported Q=%d K=%d", Q, K);
+    const int qc_max = Q < WIDE_MAX_Q ? Q : WIDE_MAX_Q;
+    if (ws_bytes < carve_wide(p, qc_max, nullptr, ~(size_t)0, nullptr))
+        return set_err(CLIPMI_EWORKSPACE, "topk_ip_coarse_i8: workspace %zu too small", ws_bytes);
+    WideWs w;
+    carve_wide(p, qc_max, ws_dev, ws_bytes, &w);
+    const int qs = wide_qs(qc_max);
+    hipStream_t st = as_stream(stream);
+    if (int rc = opt_in_lds((const void*)select_topk_kernel, p.lds_sel)) return rc;
+    if (int rc = opt_in_lds((const void*)rescore_pairs_kernel<512>, 512 * 4 + 4 * 64 * 68 * 4)) return rc;
+    const size_t lds1 = (size_t)(512 / 16) * 1024;
+    if (int rc = opt_in_lds((const void*)sample_scores_kernel<512>, lds1)) return rc;
+    int ev_used = 0;
+
+    for (int q0 = 0; q0 < Q; q0 += WIDE_MAX_Q) {
+        const int qc = (Q - q0) < WIDE_MAX_Q ? (Q - q0) : WIDE_MAX_Q;
+        const float* qg = q_dev + (size_t)q0 * E;
+        const int nsets = (qc + 63) / 64;
+        hipLaunchKernelGGL(coarse_prep_kernel<true>, dim3(nsets * 16), dim3(256), 0, st, qg, E, rmax, amax, qc, w.qmeta, w.qimage,
+                           w.gcnt_e, 2 * qs + 4, qs);
+        CLIPMI_CHECK_LAUNCH("coarse_prep_kernel(wide)");
+        long long S1 = p.stage < 4096 ? 4096 : (p.stage / 16) * 16;
+        if (S1 > 12288) S1 = 12288;
+        {
+            long long gs = ((S1 + 15) / 16 + 3) / 4;
+            if (gs > NUM_CU) gs = NUM_CU;
+            hipLaunchKernelGGL(sample_scores_kernel<512>, dim3((unsigned)gs, (unsigned)((qc + 15) / 16)), dim3(256), lds1, st,
+                               static_cast<const float*>(db_dev), S1, qg, qc, w.cand_c, (long long)WIDE_CAP, w.gcnt_c);
+            CLIPMI_CHECK_LAUNCH("sample_scores_kernel(wide)");
+            hipLaunchKernelGGL(select_topk_kernel, dim3(qc), dim3(SEL_THREADS), p.lds_sel, st, w.cand_c, w.gcnt_c, WIDE_CAP, K,
+                               (long long)0, (float*)nullptr, (long long*)nullptr, w.thr0, (const unsigned*)nullptr,
+                               (unsigned*)nullptr, 0, p.stage, w.qmeta, qs);
+            CLIPMI_CHECK_LAUNCH("select_topk_kernel(wide sample)");
+        }
+        WideArgs c;
+        c.dbc = static_cast<const signed char*>(db8_dev); c.rmeta = rmeta; c.qmeta = w.qmeta; c.qimage = w.qimage;
+        c.Q = qc; c.qs = qs;
+        c.nqt = (nsets + WIDE_TILE_SETS - 1) / WIDE_TILE_SETS;
+        c.spt = (nsets + c.nqt - 1) / c.nqt;
+        c.cand = w.cand_c; c.gcnt = w.gcnt_c; c.cap = WIDE_CAP; c.overflow = w.flag;
+        long long bnd[WIDE_MAX_SEGS];
+        const int nseg = wide_segments(N, K, S1, bnd);
+        float* os_final = out_score_dev + (size_t)q0 * K;
+        long long* oi_final = (long long*)out_id_dev + (size_t)q0 * K;
+        const int scap = p.stage < 4096 ? p.stage : 4096;
+        long long r0 = 0;
+        for (int sgi = 0; sgi < nseg; ++sgi) {
+            const bool last = sgi + 1 == nseg;
+            c.row0 = r0;
+            c.nrows = bnd[sgi] - r0;
+            hipEvent_t* ev = (scan_ev && ev_used + 2 <= max_ev) ? scan_ev + ev_used : nullptr;
+            if (int rc = wide_waves() == 4 ? launch_wide_t<4>(c, st, ev) : launch_wide_t<8>(c, st, ev)) return rc;
+            if (ev) ev_used += 2;
+            hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(12, qc), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
+                               static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, WIDE_CAP);
+            CLIPMI_CHECK_LAUNCH("rescore_pairs_kernel(wide)");
+            // keep: bit 0 = the K best stay at the head of the list for the next segment; bit 1 = add to the survivor count
+            const int keep = (last ? 0 : 1) | (sgi > 0 ? 2 : 0);
+            hipLaunchKernelGGL(select_topk_kernel, dim3(qc), dim3(SEL_THREADS), SEL_FIXED + (size_t)K * 8 + (size_t)scap * 8, st,
+                               w.cand_c, w.gcnt_c, WIDE_CAP, K, last ? (long long)id_base : 0ll, last ? os_final : (float*)nullptr,
+                               last ? oi_final : (long long*)nullptr, last ? (float*)nullptr : w.thr0, (const unsigned*)nullptr,
+                               w.last_m, keep, scap, last ? (float*)nullptr : w.qmeta, qs);
+            CLIPMI_CHECK_LAUNCH("select_topk_kernel(wide)");
+            r0 = bnd[sgi];
+        }
+        // fallback: exact scan + select, exiting at once unless a list overflowed
+        {
+            ScanArgs a;
+            a.db = static_cast<const float*>(db_dev);
+            a.K = K; a.C = p.C; a.wave_bytes = p.wave_bytes;
+            a.cand = w.cand_e; a.gcnt = w.gcnt_e; a.cap = p.cap;
+            const int ny = (qc + p.QA - 1) / p.QA;
+            a.q = qg; a.QA = qc < p.QA ? qc : p.QA; a.q_total = qc; a.nrows = N; a.thr_in = w.thr0; a.run_if = w.flag;
+            if (int rc2 = launch_scan<false>(E, p.QG, a, p.grid, p.waves, p.lds_scan, st, nullptr, ny)) return rc2;
+            hipLaunchKernelGGL(select_topk_kernel, dim3(qc), dim3(SEL_THREADS), p.lds_sel, st, w.cand_e, w.gcnt_e, p.cap, K,
+                               (long long)id_base, os_final, oi_final, (float*)nullptr, (const unsigned*)w.flag,
+                               (unsigned*)nullptr, 0, p.stage, (float*)nullptr, qs);
+            CLIPMI_CHECK_LAUNCH("select_topk_kernel(wide fallback)");
+        }
+    }
+    if (n_ev) *n_ev = ev_used;
+    return 0;
+}
 }  // namespace
 }  // namespace clipmi
 
@@ -1429,7 +1850,12 @@ extern "C" size_t clipmi_topk_ip_coarse_workspace_bytes(int64_t N, int E, int Q,
         set_err(CLIPMI_EUNSUPPORTED, "topk_ip_coarse: needs E = 512, N >= %d and a supported K", SAMPLE_MIN_N);
         return 0;
     }
-    return carve_coarse(p, nullptr, ~(size_t)0, nullptr);
+    size_t need = carve_coarse(p, nullptr, ~(size_t)0, nullptr);
+    if (Q > COARSE_Q) {                       // the int8 path takes a search of more than 64 queries as wide passes
+        const size_t wide = carve_wide(p, Q < WIDE_MAX_Q ? Q : WIDE_MAX_Q, nullptr, ~(size_t)0, nullptr);
+        need = wide > need ? wide : need;
+    }
+    return need;
 }
 
 extern "C" int clipmi_topk_ip_coarse(const void* db_dev, const void* db_bf16_dev, int64_t N, int E, float rmax,
@@ -1451,6 +1877,9 @@ extern "C" int clipmi_quantize_rows_i8(const float* db_dev, int64_t N, int E, vo
 extern "C" int clipmi_topk_ip_coarse_i8(const void* db_dev, const void* db_i8_dev, const float* meta_dev, float amax, int64_t N,
                                         int E, float rmax, const float* q_dev, int Q, int K, int64_t id_base,
                                         float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes, void* stream) {
+    if (Q > COARSE_Q && !wide_disabled())
+        return topk_wide_impl(db_dev, db_i8_dev, reinterpret_cast<const float2*>(meta_dev), amax, N, E, rmax, q_dev, Q, K, id_base,
+                              out_score_dev, out_id_dev, ws_dev, ws_bytes, stream, nullptr, 0, nullptr);
     return topk_ip_coarse_impl(db_dev, db_i8_dev, true, reinterpret_cast<const float2*>(meta_dev), amax, N, E, rmax, q_dev, Q,
                                K, id_base, out_score_dev, out_id_dev, ws_dev, ws_bytes, stream, nullptr);
 }

@@ -176,7 +176,9 @@ class IndexFlatIP:
         elif coarse:
             dbh, rmax = self.matrix_bf16()
             coarse = rmax > 0.0 and np.isfinite(rmax)
-        if coarse and Q > self.PASS_Q and self.batches_in_flight > 1 and not _one_pass:
+        # more than 64 queries: the int8 path takes the whole search as wide passes inside the library (one stream of the
+        # copy per <= 1024 queries, csrc/topk.hip "Wide coarse pass"); the bf16 path pipelines its 64-query passes here
+        if coarse and self.coarse != "int8" and Q > self.PASS_Q and self.batches_in_flight > 1 and not _one_pass:
             return self._search_pipelined(q, K, out)
         need = (L.clipmi_topk_ip_coarse_workspace_bytes if coarse else L.clipmi_topk_ip_workspace_bytes)(N, self.d, Q, K)
         if need == 0:
