@@ -103,7 +103,11 @@ def bracket(dist, world):
     torch.cuda.synchronize()
 
 
-def timed(fn, steps, warmup, dist, world):
+def timed(fn, steps, warmup, dist, world, spread=None):
+    """The contract's bracket (barrier + synchronize on both sides of EXACTLY `steps` steps, max over ranks). `spread`:
+    a dict that receives per-step min / median / max of a SECOND, per-step-synchronised run of the same steps (host
+    clock around fn + synchronize): where a single step stalls (first touch of a fresh allocation, a clock ramp) it shows
+    up here instead of hiding inside the mean. The second run is not part of the reported time."""
     for _ in range(warmup):
         fn()
     bracket(dist, world)
@@ -116,6 +120,15 @@ def timed(fn, steps, warmup, dist, world):
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if spread is not None:
+        per = []
+        for _ in range(min(steps, 20)):
+            t1 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            per.append((time.perf_counter() - t1) * 1e3)
+        per.sort()
+        spread.update({"per_step_synchronised_ms": {"min": per[0], "median": per[len(per) // 2], "max": per[-1], "n": len(per)}})
     return dt
 
 
@@ -344,7 +357,8 @@ def search_leg(L, a, dev, dist, world, rank, rows_total, n_local, seed, steps, w
 
     def search_step():
         res[0] = searcher.search_device(q, K)
-    dt_one = timed(search_step, steps, warmup, dist, world)
+    sp_one, sp_two = {}, {}
+    dt_one = timed(search_step, steps, warmup, dist, world, sp_one)
     assert (res[0][1][:, 0] >= 0).all()
     ref_i = res[0][1].clone()
     # the same K steps with TWO batches in flight on two HIP streams (every call owns its stream's workspace and
@@ -358,19 +372,21 @@ def search_leg(L, a, dev, dist, world, rank, rows_total, n_local, seed, steps, w
         with torch.cuda.stream(streams[turn[0] % nfl]):
             res[0] = searcher.search_device(q, K)
         turn[0] += 1
-    dt_two = timed(search_step2, steps, nfl * ((warmup + nfl - 1) // nfl), dist, world)
+    dt_two = timed(search_step2, steps, nfl * ((warmup + nfl - 1) // nfl), dist, world, sp_two)
     torch.cuda.synchronize()
     assert torch.equal(res[0][1], ref_i)
-    dt_s = min(dt_one, dt_two)
+    # headline of the leg = the two-in-flight form (what a throughput caller runs); the one-in-flight number and both
+    # per-step spreads are beside it, nothing is min()'d away
+    dt_s = dt_two
     Qp = min(Q, 64 if coarse else 32)            # queries of ONE pass
     scan_ms, surv, scan_bytes, scan_name, traffic_key = scan_probe(L, idx, q, Qp, K, dev, kind)
     scan_gbs = scan_bytes / (scan_ms * 1e-3) / 1e9
     passes = (Q + Qp - 1) // Qp
     traffic, tsrc = pmc_traffic(traffic_key)
     out = {"value": Q * steps / dt_s, "unit": "queries/s", "ms_per_step": dt_s / steps * 1e3, "steps": steps,
-           "batches_in_flight": nfl if dt_two < dt_one else 1,
-           "one_batch_in_flight": {"value": Q * steps / dt_one, "ms_per_step": dt_one / steps * 1e3},
-           "two_batches_in_flight": {"value": Q * steps / dt_two, "ms_per_step": dt_two / steps * 1e3},
+           "batches_in_flight": nfl,
+           "one_batch_in_flight": dict({"value": Q * steps / dt_one, "ms_per_step": dt_one / steps * 1e3}, **sp_one),
+           "two_batches_in_flight": dict({"value": Q * steps / dt_two, "ms_per_step": dt_two / steps * 1e3}, **sp_two),
            "dtype": ("int8 coarse scan (i32 MFMA) + f32 exact re-scoring" if kind == "int8" else
                      "bf16 coarse scan + f32 exact re-scoring" if kind == "bf16" else "f32"),
            "path": ("coarse-then-exact (clipmi_topk_ip_coarse_i8)" if kind == "int8" else
@@ -381,9 +397,12 @@ def search_leg(L, a, dev, dist, world, rank, rows_total, n_local, seed, steps, w
                         "kernel_ms": scan_ms, "algorithmic_bytes_per_launch": scan_bytes,
                         "coarse_survivors_per_query": surv,
                         "whole_call_gbs_per_gpu": scan_bytes * passes * steps / dt_s / 1e9,
-                        "whole_call_frac": scan_bytes * passes * steps / dt_s / 1e9 / PEAK_HBM_GBS}}
-    # ONE search call of 1024 queries: the product's own pipelining of 64-query passes (IndexFlatIP._search_pipelined) -
-    # what a caller with many queries gets without managing streams. Reported beside the 64-query number, never as it.
+                        "whole_call_frac": scan_bytes * passes * steps / dt_s / 1e9 / PEAK_HBM_GBS,
+                        "whole_call_frac_one_in_flight": scan_bytes * passes * steps / dt_one / 1e9 / PEAK_HBM_GBS}}
+    # ONE search call of 1024 queries (query-index.py:111 is one index.search call whatever Q): the int8 path takes it as ONE
+    # wide pass of the copy (csrc/topk.hip scan_coarse_wide_kernel: query tiles resident in LDS, integer MFMA). Two rooflines:
+    # SURVEY.md 8(d)'s bytes (the copy streamed once per call) against HBM, and 2 N Q E int8 operations against the dense
+    # int8 MFMA peak (2 x the bf16 figure: MI355X_MICROARCH.md "Matrix cores"). Reported beside the 64-query number.
     if coarse and large_q > 0:
         gq.manual_seed(3)
         qL = torch.randn((large_q, 512), generator=gq, device=dev)
@@ -391,10 +410,22 @@ def search_leg(L, a, dev, dist, world, rank, rows_total, n_local, seed, steps, w
 
         def big_step():
             res[0] = searcher.search_device(qL, K)
-        dt_big = timed(big_step, 3, 1, dist, world)
-        out["one_call_many_queries"] = {"queries": large_q, "value": large_q * 3 / dt_big, "unit": "queries/s",
-                                        "ms_per_call": dt_big / 3 * 1e3,
-                                        "passes_in_flight": getattr(idx, "batches_in_flight", 1)}
+        sp_big = {}
+        dt_big = timed(big_step, 5, 2, dist, world, sp_big)
+        ms_call = dt_big / 5 * 1e3
+        copy_bytes = n_local * (512 + 8) if kind == "int8" else n_local * 1024
+        ops = 2.0 * n_local * large_q * 512
+        out["one_call_many_queries"] = dict({
+            "queries": large_q, "value": large_q * 5 / dt_big, "unit": "queries/s", "ms_per_call": ms_call, "steps": 5,
+            "path": "wide pass (clipmi_topk_ip_coarse_i8, Q > 64)" if kind == "int8" else "64-query passes on two streams",
+            "roofline_hbm": {"bound": "hbm", "algorithmic_bytes_per_call": copy_bytes,
+                             "achieved": copy_bytes / (ms_call * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": copy_bytes / (ms_call * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            "roofline_mfma_int8": {"bound": "mfma", "ops_per_call": ops, "achieved": ops / (ms_call * 1e-3) / 1e12,
+                                   "peak": 2 * PEAK_BF16_TFLOPS, "unit": "TOP/s",
+                                   "frac": ops / (ms_call * 1e-3) / 1e12 / (2 * PEAK_BF16_TFLOPS),
+                                   "note": "whole call (sample, scans, exact re-scoring, selects) over the scan's operations"}},
+            **sp_big)
     del searcher, idx, db
     torch.cuda.empty_cache()
     return out
@@ -436,7 +467,8 @@ def main():
 
     def enc_step():
         enc_out[0] = model.encode_image(images, normalize=True)
-    dt_enc = timed(enc_step, a.steps, a.warmup, dist, world)
+    sp_enc = {}
+    dt_enc = timed(enc_step, a.steps, a.warmup, dist, world, sp_enc)
     img_per_s = world * B * a.steps / dt_enc
     assert torch.isfinite(enc_out[0]).all()
 
@@ -460,11 +492,12 @@ def main():
         def enc8_step():
             enc_out[0] = model8.encode_image(images, normalize=True)
         steps8 = max(3, a.steps // 2)
-        dt8 = timed(enc8_step, steps8, 2, dist, world)
+        sp8 = {}
+        dt8 = timed(enc8_step, steps8, 2, dist, world, sp8)
         cos = torch.nn.functional.cosine_similarity(enc_out[0].double(), ref16.double(), dim=-1)
         fp8_info = {"metric": "images/sec ViT-B/32 encode, FP8 (e4m3) linear layers", "value": world * B * steps8 / dt8,
                     "unit": "images/s", "ms_per_step": dt8 / steps8 * 1e3, "steps": steps8, "dtype": "fp8 e4m3 x e4m3 -> f32",
-                    "min_cosine_to_bf16_path": float(cos.min()),
+                    "min_cosine_to_bf16_path": float(cos.min()), **sp8,
                     "note": "BASELINE.json configs[4] parity case; not the headline (configs[1] is bf16)"}
         del model8
 
@@ -474,11 +507,20 @@ def main():
     need = L.clipmi_encode_image_workspace_bytes(model.vision, B)
     ews = torch.empty(need, dtype=torch.uint8, device=dev)
     eout = torch.empty((B, 512), dtype=torch.float32, device=dev)
-    kms, nl = C.c_float(0), C.c_int(0)
-    clipmi._lib.check(L.clipmi_dbg_encode_image_probe_ms(model.vision, model._vblob.data_ptr(), images.data_ptr(),
-                                                         clipmi._lib.U8, B, eout.data_ptr(), ews.data_ptr(), ews.numel(),
-                                                         clipmi._lib.stream_ptr(dev), 1, 3, C.byref(kms), C.byref(nl)),
-                      "encode_image_probe")
+    ms3, nl, kkind, kepi = (C.c_float * 3)(), C.c_int(0), C.c_int(-1), C.c_int(-1)
+    clipmi._lib.check(L.clipmi_dbg_encode_image_probe3_ms(model.vision, model._vblob.data_ptr(), images.data_ptr(),
+                                                          clipmi._lib.U8, B, eout.data_ptr(), ews.data_ptr(), ews.numel(),
+                                                          clipmi._lib.stream_ptr(dev), 1, 3, ms3, C.byref(nl), C.byref(kkind),
+                                                          C.byref(kepi)), "encode_image_probe3")
+    # The kernel's in-situ duration: completion of the GEMM directly in front -> completion of this one (ms3[2]) where that
+    # applies (LN-folded tower: out_proj -> c_fc back to back): the kernel + one kernel boundary, the estimator that agrees
+    # with rocprofv3's dispatch duration (profiles/). The launch's own begin -> end events (ms3[0]) read ~14 % long in a
+    # back-to-back stream - the begin stamp is taken when the packet is processed, before the previous kernel has drained;
+    # both are in the line, `frac` uses the former.
+    kms_events = ms3[0]
+    kms = C.c_float(ms3[2] if ms3[2] > 0 else ms3[1] if ms3[1] > 0 else ms3[0])
+    kernel_symbol = (["gemm_bf16_nt_kernel<%d>", "gemm256_bf16_nt_kernel<%d>", "gemm256p_bf16_nt_kernel<%d, false>"][kkind.value]
+                     % kepi.value) if 0 <= kkind.value <= 2 else "?"
     gemm_ms = kms.value
     gemm_tflops = 2.0 * M * N * Kd / (gemm_ms * 1e-3) / 1e12
     del ews, eout, model, images
@@ -499,12 +541,13 @@ def main():
         def l14_step():
             lo_[0] = ml.encode_image(imgs_l, normalize=True)
         steps_l = max(3, a.steps // 4)
-        dt_l = timed(l14_step, steps_l, 1, dist, world)
+        sp_l = {}
+        dt_l = timed(l14_step, steps_l, 1, dist, world, sp_l)
         assert torch.isfinite(lo_[0]).all()
         tf_l = FLOP_PER_IMAGE_L14_336 * Bl * steps_l / dt_l / 1e12
         l14 = {"metric": "images/sec ViT-L/14@336px encode (BASELINE.json configs[3])", "value": world * Bl * steps_l / dt_l,
                "unit": "images/s", "ms_per_step": dt_l / steps_l * 1e3, "steps": steps_l, "images_per_gpu_per_step": Bl,
-               "dtype": "bf16", "flop_per_image": FLOP_PER_IMAGE_L14_336,
+               "dtype": "bf16", "flop_per_image": FLOP_PER_IMAGE_L14_336, **sp_l,
                "roofline": {"bound": "mfma", "kernel": "whole step (24 layers; GEMMs gemm256p/gemm256, flash attention)",
                             "achieved": tf_l, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tf_l / PEAK_BF16_TFLOPS,
                             "traffic": None}}
@@ -519,7 +562,7 @@ def main():
     # configs[4] search half: 12.5 M rows on every rank (weak): at N = 8 a 100 M x 512 DB
     shard = None
     if a.shard_rows > 0:
-        shard = search_leg(L, a, dev, dist, world, rank, a.shard_rows * world, a.shard_rows, 5000, max(5, a.steps // 2), 2)
+        shard = search_leg(L, a, dev, dist, world, rank, a.shard_rows * world, a.shard_rows, 5000, max(5, a.steps // 2), a.warmup)
         shard["metric"] = (f"queries/sec top-{a.k} over {a.shard_rows * world}x512 flat IP, {a.shard_rows} rows per GPU "
                            f"(BASELINE.json configs[4] search half)")
         shard["scaling"] = "weak"
@@ -535,18 +578,19 @@ def main():
     out = {
         "metric": "images/sec ViT-B/32 encode", "value": img_per_s, "unit": "images/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_enc / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic", **sp_enc,
         "config": {"workload": f"BASELINE.json configs[1]: ViT-B/32 bf16 encode of synthetic 224x224 uint8 images "
                                f"(random-init weights, L=50, 12 layers), {B} images per GPU per step, fused normalise, "
                                f"inputs resident in HBM; then exact-result flat-IP top-{K} (k={a.k}+1, "
                                f"query-index.py:111) over {a.rows} x 512 f32 split over {world} GPU(s), Q={Q} per batch",
                    "images_per_gpu_per_step": B, "index_rows_total": a.rows, "queries_per_batch": Q, "K": K},
-        "roofline": {"bound": "mfma", "kernel": ("gemm256p_bf16_nt_kernel<1,false>" if (N // 256) * ((M + 255) // 256) > 256
-                                                 else "gemm256_bf16_nt_kernel<1>") +
-                                                f" (MLP c_fc + bias + QuickGELU, M={M} N={N} K={Kd})",
+        "roofline": {"bound": "mfma", "kernel": kernel_symbol + f" (MLP c_fc + bias + QuickGELU, M={M} N={N} K={Kd})",
                      "achieved": gemm_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": gemm_tflops / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
                      "kernel_ms": gemm_ms, "launches_timed": nl.value,
+                     "kernel_ms_estimators": {"completion_to_completion": ms3[2], "event_in_front_to_end": ms3[1],
+                                              "launch_begin_to_end_events": kms_events,
+                                              "used": "completion_to_completion" if ms3[2] > 0 else "event_in_front_to_end"},
                      "whole_step_tflops_per_gpu": FLOP_PER_IMAGE * B * a.steps / dt_enc / 1e12,
                      "whole_step_frac": FLOP_PER_IMAGE * B * a.steps / dt_enc / 1e12 / PEAK_BF16_TFLOPS},
         "search": search,

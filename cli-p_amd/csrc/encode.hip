@@ -248,32 +248,71 @@ extern "C" int clipmi_encode_text(const clipmi_tower* t, const void* blob_dev, c
     return run_head(t, blob_dev, w, Q, w.rowidx, 1, out_dev, normalize, st);
 }
 
-// Measurement hook (bench.py roofline): clipmi_encode_image `reps` times with HIP events around
-// every launch of the GEMM with epilogue `probe_epi` (1 = MLP c_fc + QuickGELU) on `stream`;
-// synchronises; *kernel_ms = average duration of those launches, *launches = how many were timed.
-extern "C" int clipmi_dbg_encode_image_probe_ms(const clipmi_tower* t, const void* blob_dev, const void* pixels_dev,
-                                                int pix_dtype, int B, float* out_dev, void* ws_dev, size_t ws_bytes,
-                                                void* stream, int probe_epi, int reps, float* kernel_ms, int* launches) {
-    if (!kernel_ms || reps < 1) return set_err(CLIPMI_EINVAL, "dbg_encode_image_probe_ms: bad arguments");
+// Measurement hook (bench.py roofline): clipmi_encode_image `reps` times per estimator with HIP events around the launches
+// of the GEMM whose epilogue is `probe_epi` (1 = MLP c_fc + QuickGELU) on `stream`; synchronises. Three estimators of that
+// kernel's in-situ duration, each from its own `reps` forward passes (ms[0..2], averages over the timed launches):
+//   ms[0] begin -> end events of hipExtLaunchKernel. The begin event is stamped when the dispatch packet is PROCESSED, which in
+//         a back-to-back stream is before the previous kernel has drained: it reads long (14 % for the 200-us c_fc launch).
+//   ms[1] a plain event record in front of the launch (completes with everything before it) -> the launch's end event:
+//         kernel + the boundary to the previous kernel + the event packet.
+//   ms[2] end event of the previous GEMM launch -> end event of this one, used where that previous launch is the kernel
+//         directly in front in the stream (LN-folded tower: out_proj -> c_fc): completion to completion = the kernel + ONE
+//         kernel boundary (~1.5 us), the closest to the profiler's dispatch duration; 0 when not applicable.
+// kernel_kind / epi_ran: which kernel and epilogue the timed launches really were (0 gemm_bf16_nt_kernel, 1 gemm256_..., 2
+// gemm256p_...; the EPI_* number).
+static int encode_probe(const clipmi_tower* t, const void* blob_dev, const void* pixels_dev, int pix_dtype, int B, float* out_dev,
+                        void* ws_dev, size_t ws_bytes, void* stream, int probe_epi, int reps, int nmodes, float* ms, int* launches,
+                        int* kernel_kind, int* epi_ran) {
+    if (!ms || reps < 1) return set_err(CLIPMI_EINVAL, "dbg_encode_image_probe_ms: bad arguments");
     GemmProbe p;             // lives on this call's stack: the library keeps no mutable state (clipmi.h)
     for (int i = 0; i < 2 * GemmProbe::MAX; ++i)
         if (hipEventCreate(&p.ev[i]) != hipSuccess) return set_err(CLIPMI_EHIP, "hipEventCreate");
-    double total = 0.0;
-    int count = 0, rc = 0;
-    for (int r = 0; r < reps && rc == 0; ++r) {
-        p.epi = probe_epi; p.n = 0;
-        rc = encode_image_impl(t, blob_dev, pixels_dev, pix_dtype, B, out_dev, 1, ws_dev, ws_bytes, stream, &p);
-        if (rc) break;
-        if (hipStreamSynchronize(as_stream(stream)) != hipSuccess) { rc = set_err(CLIPMI_EHIP, "hipStreamSynchronize"); break; }
-        for (int i = 0; i < p.n; ++i) {
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]);
-            total += ms;
-            ++count;
+    for (int i = 0; i < GemmProbe::MAX; ++i)
+        if (hipEventCreate(&p.pre[i]) != hipSuccess) return set_err(CLIPMI_EHIP, "hipEventCreate");
+    int rc = 0;
+    for (int mode = 0; mode < nmodes && rc == 0; ++mode) {
+        double total = 0.0;
+        int count = 0;
+        for (int r = 0; r < reps && rc == 0; ++r) {
+            p.epi = probe_epi; p.n = 0; p.mode = mode;
+            rc = encode_image_impl(t, blob_dev, pixels_dev, pix_dtype, B, out_dev, 1, ws_dev, ws_bytes, stream, &p);
+            if (rc) break;
+            if (hipStreamSynchronize(as_stream(stream)) != hipSuccess) { rc = set_err(CLIPMI_EHIP, "hipStreamSynchronize"); break; }
+            for (int i = 0; i < p.n; ++i) {
+                if (GemmProbe::base_of(p.epi_of[i]) != probe_epi) continue;
+                float v = 0.f;
+                if (mode == 0) (void)hipEventElapsedTime(&v, p.ev[2 * i], p.ev[2 * i + 1]);
+                else if (mode == 1) (void)hipEventElapsedTime(&v, p.pre[i], p.ev[2 * i + 1]);
+                else {
+                    // the launch in front must be the residual producer of the same block (no kernel between them)
+                    if (i == 0 || p.epi_of[i - 1] != EPI_BIAS_RESID_LN_F32 || p.kernel_of[i - 1] != 2) continue;
+                    (void)hipEventElapsedTime(&v, p.ev[2 * (i - 1) + 1], p.ev[2 * i + 1]);
+                }
+                total += v;
+                ++count;
+                if (kernel_kind) *kernel_kind = p.kernel_of[i];
+                if (epi_ran) *epi_ran = p.epi_of[i];
+            }
         }
+        if (rc == 0 && count == 0 && mode == 0) rc = set_err(CLIPMI_EINVAL, "dbg_encode_image_probe_ms: no launch matched epi %d", probe_epi);
+        if (rc == 0) { ms[mode] = count ? (float)(total / count) : 0.f; if (launches && mode == 0) *launches = count; }
     }
     for (int i = 0; i < 2 * GemmProbe::MAX; ++i) (void)hipEventDestroy(p.ev[i]);
-    if (rc == 0 && count == 0) rc = set_err(CLIPMI_EINVAL, "dbg_encode_image_probe_ms: no launch matched epi %d", probe_epi);
-    if (rc == 0) { *kernel_ms = (float)(total / count); if (launches) *launches = count; }
+    for (int i = 0; i < GemmProbe::MAX; ++i) (void)hipEventDestroy(p.pre[i]);
     return rc;
+}
+
+extern "C" int clipmi_dbg_encode_image_probe_ms(const clipmi_tower* t, const void* blob_dev, const void* pixels_dev,
+                                                int pix_dtype, int B, float* out_dev, void* ws_dev, size_t ws_bytes,
+                                                void* stream, int probe_epi, int reps, float* kernel_ms, int* launches) {
+    return encode_probe(t, blob_dev, pixels_dev, pix_dtype, B, out_dev, ws_dev, ws_bytes, stream, probe_epi, reps, 1, kernel_ms,
+                        launches, nullptr, nullptr);
+}
+
+extern "C" int clipmi_dbg_encode_image_probe3_ms(const clipmi_tower* t, const void* blob_dev, const void* pixels_dev,
+                                                 int pix_dtype, int B, float* out_dev, void* ws_dev, size_t ws_bytes,
+                                                 void* stream, int probe_epi, int reps, float* ms3, int* launches,
+                                                 int* kernel_kind, int* epi_ran) {
+    return encode_probe(t, blob_dev, pixels_dev, pix_dtype, B, out_dev, ws_dev, ws_bytes, stream, probe_epi, reps, 3, ms3,
+                        launches, kernel_kind, epi_ran);
 }

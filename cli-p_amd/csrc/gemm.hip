@@ -22,9 +22,9 @@ static int launch_epi(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
     if (probe && probe->wants(EPI)) {
         GemmProbe& p = *probe;
         // measurement probe: the events take the dispatch's own begin/end timestamps
-        hipExtLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(grid), dim3(256), GEMM_LDS_BYTES, st, p.ev[2 * p.n],
-                              p.ev[2 * p.n + 1], 0, g);
-        ++p.n;
+        const int i = p.begin(EPI, 0, st);
+        hipExtLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(grid), dim3(256), GEMM_LDS_BYTES, st, p.ev[2 * i],
+                              p.ev[2 * i + 1], 0, g);
     } else {
         hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(grid), dim3(256), GEMM_LDS_BYTES, st, g);
     }
@@ -43,9 +43,9 @@ static int launch_epi256(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
     }
     if (probe && probe->wants(EPI)) {
         GemmProbe& p = *probe;
-        hipExtLaunchKernelGGL(gemm256_bf16_nt_kernel<EPI>, dim3(grid), dim3(512), G256_LDS, st, p.ev[2 * p.n],
-                              p.ev[2 * p.n + 1], 0, g);
-        ++p.n;
+        const int i = p.begin(EPI, 1, st);
+        hipExtLaunchKernelGGL(gemm256_bf16_nt_kernel<EPI>, dim3(grid), dim3(512), G256_LDS, st, p.ev[2 * i],
+                              p.ev[2 * i + 1], 0, g);
     } else {
         hipLaunchKernelGGL(gemm256_bf16_nt_kernel<EPI>, dim3(grid), dim3(512), G256_LDS, st, g);
     }
@@ -83,9 +83,9 @@ static int launch_epi256p(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
     }
     if (probe && probe->wants(EPI)) {
         GemmProbe& p = *probe;
-        hipExtLaunchKernelGGL((gemm256p_bf16_nt_kernel<EPI, FP8>), dim3(grid), dim3(512), lds, st, p.ev[2 * p.n],
-                              p.ev[2 * p.n + 1], 0, g);
-        ++p.n;
+        const int i = p.begin(EPI, 2, st);
+        hipExtLaunchKernelGGL((gemm256p_bf16_nt_kernel<EPI, FP8>), dim3(grid), dim3(512), lds, st, p.ev[2 * i],
+                              p.ev[2 * i + 1], 0, g);
     } else {
         hipLaunchKernelGGL((gemm256p_bf16_nt_kernel<EPI, FP8>), dim3(grid), dim3(512), lds, st, g);
     }
@@ -140,9 +140,10 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmP
         GemmArgs t = g;
         t.out = g.tmp_f32;
         GemmProbe* pr = (probe && probe->wants(EPI_BIAS_RESID_LN_F32)) ? probe : nullptr;
+        const int saved_epi = pr ? pr->epi : -1;
         if (pr) pr->epi = EPI_F32;                       // the probe brackets the GEMM launch itself
         const int rc = use256 ? launch_epi256<EPI_F32>(t, st, pr) : launch_gemm(t, EPI_F32, st, pr);
-        if (pr) pr->epi = EPI_BIAS_RESID_F32;
+        if (pr) pr->epi = saved_epi;
         if (rc) return rc;
         return launch_split_stats(g.tmp_f32, true, g.xhi, g.xlo, g.ln_part, g.M, g.N, st);
     }

@@ -344,11 +344,25 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
 struct GemmProbe {
     static constexpr int MAX = 64;
     int epi = -1, n = 0;
+    // mode 0: events from hipExtLaunchKernel (the dispatch's own begin / end) around the launches whose epilogue matches
+    //         `epi`; mode 1: the same plus a plain event record in front (`pre`: completion of everything before);
+    //         mode 2: begin / end events around EVERY GEMM launch (for completion-to-completion differences)
+    int mode = 0;
     hipEvent_t ev[2 * MAX];
-    bool wants(int e) const {
-        const int base = e == EPI_LN_BIAS_BF16 ? EPI_BIAS_BF16 : e == EPI_LN_BIAS_QGELU_BF16 ? EPI_BIAS_QGELU_BF16 :
-                         e == EPI_BIAS_RESID_LN_F32 ? EPI_BIAS_RESID_F32 : e;
-        return base == epi && n < MAX;
+    hipEvent_t pre[MAX];
+    int epi_of[MAX];          // the epilogue that really ran (EPI_LN_* when the tower folds its LayerNorms)
+    int kernel_of[MAX];       // 0 gemm_bf16_nt_kernel (128^2), 1 gemm256_bf16_nt_kernel, 2 gemm256p_bf16_nt_kernel
+    static int base_of(int e) {
+        return e == EPI_LN_BIAS_BF16 ? EPI_BIAS_BF16 : e == EPI_LN_BIAS_QGELU_BF16 ? EPI_BIAS_QGELU_BF16 :
+               e == EPI_BIAS_RESID_LN_F32 ? EPI_BIAS_RESID_F32 : e;
+    }
+    bool wants(int e) const { return n < MAX && (mode == 2 || base_of(e) == epi); }
+    // called by the launchers right before a probed launch; returns the slot
+    int begin(int e, int kernel, hipStream_t st) {
+        epi_of[n] = e;
+        kernel_of[n] = kernel;
+        if (mode == 1) (void)hipEventRecord(pre[n], st);
+        return n++;
     }
 };
 

@@ -612,7 +612,7 @@ __device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
 }
 
 // ---- int8 coarse copy (clipmi_quantize_rows_i8 / clipmi_topk_ip_coarse_i8) -------------------------------
-// Row r: s_r = max|x_rk| / 127, q_rk = rint(x_rk / s_r) in [-127, 127], a_r = 1.001 * ||x_r - s_r q_r||_2.
+// Row r: s_r = (max |x| over r's 32-row block) / 127, q_rk = rint(x_rk / s_r) in [-127, 127], a_r = 1.001 * ||x_r - s_r q_r||_2.
 // Query: t_q, p_qk the same way, f_q = y - t_q p_q. The int8 MFMA gives the EXACT integer D = q_r . p_q
 // (|D| <= 512 * 127^2 < 2^24), and
 //      x.y = s_r t_q D + e_r.y + (s_r q_r).f_q      =>      |x.y - s_r t_q D| <= a_r ||y|| + (R_max + A_max) ||f_q||
@@ -626,39 +626,65 @@ __device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
 //  with 128 MFMAs per 32-row step the one wave per SIMD is MFMA/VALU-bound in the early segments: scans +75 us. Rejected.)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// Layout of the copy (round 3): 32-row blocks, each [E / 32 k-steps][64 lanes][16 bytes] = the A operand of
+// v_mfma_i32_32x32x32_i8 as it lies in registers - lane l of k-step s holds bytes 32 s + 16 (l >> 5) .. + 15 of row
+// (l & 31) of the block - so a wave reads one k-step of a block as ONE contiguous KiB. The 32 rows of a block share
+// their scale (s = the block's max |x| / 127): a wave's compare then has one scale per step and becomes an integer
+// test (scan_coarse_wide_kernel). meta[r] = (s_block, a_r); bmeta[block] = (s_block, max a_r of the block), stored
+// behind the row meta. Rows past N in the last block are zero.
 __global__ void __launch_bounds__(256) quantize_rows_i8_kernel(const float* __restrict__ db, long long N, int E,
-                                                               signed char* __restrict__ out, float2* __restrict__ meta) {
-    const int lane = threadIdx.x & 63;
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= N) return;
-    const float* x = db + (size_t)r * E;
+                                                               signed char* __restrict__ out, float2* __restrict__ meta,
+                                                               float2* __restrict__ bmeta) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long blk = blockIdx.x, r0 = blk * 32;
     float mx = 0.f;
-    for (int k = lane * 4; k < E; k += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(x + k);
-        mx = fmaxf(fmaxf(mx, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+    for (int i = 0; i < 8; ++i) {
+        const long long r = r0 + wave * 8 + i;
+        if (r < N)
+            for (int k = lane * 4; k < E; k += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(db + (size_t)r * E + k);
+                mx = fmaxf(fmaxf(mx, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+            }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const float s = mx > 0.f ? mx / 127.0f : 1.0f;
     const float inv = 1.0f / s;
-    float ee = 0.f;
-    for (int k = lane * 4; k < E; k += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(x + k);
-        float qv[4] = {rintf(v.x * inv), rintf(v.y * inv), rintf(v.z * inv), rintf(v.w * inv)};
-        const float xv[4] = {v.x, v.y, v.z, v.w};
-        unsigned pk = 0;
+    signed char* oblk = out + (size_t)blk * 32 * E;
+    float amax_w = 0.f;
+    for (int i = 0; i < 8; ++i) {
+        const int rloc = wave * 8 + i;
+        const long long r = r0 + rloc;
+        float ee = 0.f;
+        for (int k = lane * 4; k < E; k += 256) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < N) v = *reinterpret_cast<const float4*>(db + (size_t)r * E + k);
+            float qv[4] = {rintf(v.x * inv), rintf(v.y * inv), rintf(v.z * inv), rintf(v.w * inv)};
+            const float xv[4] = {v.x, v.y, v.z, v.w};
+            unsigned pk = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            qv[j] = fminf(fmaxf(qv[j], -127.f), 127.f);
-            const float e = xv[j] - s * qv[j];
-            ee = fmaf(e, e, ee);
-            pk |= ((unsigned)(int)qv[j] & 0xffu) << (8 * j);
+            for (int j = 0; j < 4; ++j) {
+                qv[j] = fminf(fmaxf(qv[j], -127.f), 127.f);
+                const float e = xv[j] - s * qv[j];
+                ee = fmaf(e, e, ee);
+                pk |= ((unsigned)(int)qv[j] & 0xffu) << (8 * j);
+            }
+            const int ks = k >> 5, h = (k >> 4) & 1, b = k & 15;
+            *reinterpret_cast<unsigned*>(oblk + (size_t)ks * 1024 + (h * 32 + rloc) * 16 + b) = pk;
         }
-        *reinterpret_cast<unsigned*>(out + (size_t)r * E + k) = pk;
-    }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) ee += __shfl_xor(ee, o);
-    if (lane == 0) meta[r] = make_float2(s, sqrtf(ee) * 1.001f);
+        for (int o = 32; o >= 1; o >>= 1) ee += __shfl_xor(ee, o);
+        const float a_r = r < N ? sqrtf(ee) * 1.001f : 0.f;
+        if (lane == 0) meta[r] = make_float2(s, a_r);
+        amax_w = fmaxf(amax_w, a_r);
+    }
+    if (lane == 0) red[4 + wave] = amax_w;
+    __syncthreads();
+    if (tid == 0) bmeta[blk] = make_float2(s, fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
 }
 
 // Per-query constants of a coarse search, once per group of <= qs queries (one wave per query), qmeta [4][qs]
@@ -674,15 +700,20 @@ __global__ void __launch_bounds__(256) quantize_rows_i8_kernel(const float* __re
 // the call's control words (candidate counters, overflow flag): no memset node.
 template <bool I8>
 __global__ void __launch_bounds__(256) coarse_prep_kernel(const float* __restrict__ q, int E, float rmax, float amax, int QA,
-                                                          float* qmeta, uint4* qimage, unsigned* ctl, int nctl, int qs) {
+                                                          float* qmeta, uint4* qimage, unsigned* ctl, int nctl, int qs,
+                                                          int wide = 0) {
     constexpr int KS = 512 / (I8 ? 64 : 32);
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < nctl; i += 256) ctl[i] = 0u;
     const int qg = qi >> 4, col = qi & 15;
-    if (qi >= QA) {                                            // padding query of a used 16-query group: zero image
-        if (lane < KS * 4) qimage[(qg * KS + (lane >> 2)) * 64 + (lane & 3) * 16 + col] = make_uint4(0u, 0u, 0u, 0u);
+    // wide pass (int8): the B operand of v_mfma_i32_32x32x32_i8 - 32-query groups, 16 k-steps of 32 bytes, entry
+    // [(G*16 + s)*64 + h*32 + n] = bytes 32 s + 16 h .. + 15 of query 32 G + n
+    const int widx = ((qi >> 5) * 16 + (lane >> 1)) * 64 + (lane & 1) * 32 + (qi & 31);
+    if (qi >= QA) {                                            // padding query of a used query group: zero image
+        if (wide) { if (lane < 32) qimage[widx] = make_uint4(0u, 0u, 0u, 0u); }
+        else if (lane < KS * 4) qimage[(qg * KS + (lane >> 2)) * 64 + (lane & 3) * 16 + col] = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
     const float* y = q + (size_t)qi * E;
@@ -711,6 +742,24 @@ __global__ void __launch_bounds__(256) coarse_prep_kernel(const float* __restric
         qmeta[qs + qi] = I8 ? 1.001f * Y * inv : 0.f;
         qmeta[2 * qs + qi] = -INFINITY;
         qmeta[3 * qs + qi] = margin;
+    }
+    if (I8 && wide) {
+        if (lane < 32) {
+            const float* p = y + 32 * (lane >> 1) + 16 * (lane & 1);
+            unsigned w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned pk = 0;
+#pragma unroll
+                for (int b_ = 0; b_ < 4; ++b_) {
+                    const float pq = fminf(fmaxf(rintf(p[4 * j + b_] * inv), -127.f), 127.f);
+                    pk |= ((unsigned)(int)pq & 0xffu) << (8 * b_);
+                }
+                w[j] = pk;
+            }
+            qimage[widx] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        return;
     }
     if (lane < KS * 4) {
         const int s_ = lane >> 2, g_ = lane & 3;
@@ -835,7 +884,13 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
     long long step = step0 + wg;
     if (step < nsteps) {
         uint4 T[SLOTS];
+        // bf16 copy: row-major, 64 bytes per row and k-step; int8 copy: 32-row blocks of [16 k-steps of 32 B][64 lanes][16 B]
+        // (quantize_rows_i8_kernel), padded to whole blocks: this lane's 16 bytes of MFMA k-step s are bytes 64 s + 16 g
+        // of row 16 rt + col = 32-byte k-step 2 s + (g >> 1), half g & 1
+        constexpr int KSTRIDE = I8 ? 2048 : 64;
         auto frag_ptr = [&](long long st, int rt) {
+            if (I8)
+                return static_cast<const char*>(a.dbc) + st * (32 * ROWB) + (g >> 1) * 1024 + ((g & 1) * 32 + rt * 16 + col) * 16;
             long long r = st * 32 + rt * 16 + col;
             r = r > last_row ? last_row : r;
             return static_cast<const char*>(a.dbc) + r * ROWB + 16 * g;
@@ -857,8 +912,8 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
             const char* p1 = frag_ptr(step, 1);
 #pragma unroll
             for (int s_ = 0; s_ < KS; ++s_) {
-                T[s_] = *reinterpret_cast<const uint4*>(p0 + 64 * s_);
-                T[KS + s_] = *reinterpret_cast<const uint4*>(p1 + 64 * s_);
+                T[s_] = *reinterpret_cast<const uint4*>(p0 + KSTRIDE * s_);
+                T[KS + s_] = *reinterpret_cast<const uint4*>(p1 + KSTRIDE * s_);
             }
             load_meta(step, M);
         }
@@ -905,7 +960,7 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
                         acc[rt][qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, T[slot]),
                                                                               __builtin_bit_cast(bf16x8, b[qg]), acc[rt][qg], 0, 0, 0);
                 }
-                T[slot] = *reinterpret_cast<const uint4*>(pn[rt] + 64 * (slot % KS));
+                T[slot] = *reinterpret_cast<const uint4*>(pn[rt] + KSTRIDE * (slot % KS));
             }
             constexpr int NBQ = QG;
             __builtin_amdgcn_sched_group_barrier(0x100, NBQ, 0);               // slot 0's fragments
@@ -1064,6 +1119,9 @@ __global__ void __launch_bounds__(256) rescore_pairs_kernel(const float* __restr
 // the other's MFMAs. The pass is matrix-bound: 2 N Q 512 int8 operations per launch.
 // Survivors go to the same per-query lists as the 64-query pass's (entries appended by ballot prefix, no LDS atomics).
 // =================================================================================================
+// meta of the int8 copy: row entries for N rounded up to 32 rows (+32), then one (scale, largest error norm) pair per block (+1)
+inline size_t i8_row_meta_entries(int64_t N) { return (size_t)((N + 31) / 32 * 32 + 32); }
+
 constexpr int WIDE_MAX_Q = 1024;                 // queries of one wide launch (4 tiles of 256)
 constexpr int WIDE_TILE_SETS = 4;                // 64-query sets per tile: 4 x 32 KiB of image
 constexpr int WIDE_FLUSH = 128;                  // pending pairs per wave that trigger a flush
@@ -1072,10 +1130,11 @@ constexpr size_t WIDE_WAVE_BYTES = (size_t)WIDE_LIST * 8;
 constexpr long long WIDE_CAP = 1ll << 15;        // candidate slots per query of a wide pass (overflow arms the exact fallback)
 
 struct WideArgs {
-    const signed char* dbc;      // int8 [nrows][512]
-    const float2* rmeta;         // per row (scale, error norm), padded to 32 rows
+    const signed char* dbc;      // int8 copy, 32-row blocks of [16][64][16 B] (quantize_rows_i8_kernel)
+    const float2* rmeta;         // per row (block scale, error norm), padded to 32 rows
+    const float2* bmeta;         // per 32-row block (scale, largest error norm)
     const float* qmeta;          // [4][qs]
-    const uint4* qimage;         // all queries' image, 64-query sets of 32 KiB
+    const uint4* qimage;         // all queries' image, 64-query sets of 32 KiB (coarse_prep_kernel, wide form)
     long long row0, nrows;       // rows [row0, row0 + nrows), row0 % 32 == 0
     int Q, qs;
     int nqt, spt;                // query tiles, 64-query sets per tile (<= WIDE_TILE_SETS)
@@ -1083,7 +1142,10 @@ struct WideArgs {
     unsigned* gcnt;              // [qs]
     long long cap;
     unsigned* overflow;
+    int map_mode, pf_mode;       // development knobs (CLIPMI_WIDE_MAP / CLIPMI_WIDE_PF)
 };
+
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __noinline__ void wide_flush(const uint2* list, int n, int qbase, unsigned* gcnt, uint2* cand, long long cap,
                                         unsigned* overflow) {
@@ -1099,20 +1161,21 @@ __device__ __noinline__ void wide_flush(const uint2* list, int n, int qbase, uns
     wave_lds_sync();
 }
 
-template <int WAVES>
+template <int WAVES, int ABL = 0>      // ABL: development ablations (1 no compare, 2 few LDS reads, 3 no row loads)
 __global__ void __launch_bounds__(WAVES * 64) scan_coarse_wide_kernel(WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KS = 8, ROWB = 512, QGS = 4;                // k-steps per row tile, bytes per row, query groups per set
-    constexpr int SET_ENTRIES = QGS * KS * 64;                // 16-byte entries of one set's image (32 KiB)
+    constexpr int KS = 16;                                    // k-steps of 32 bytes
+    constexpr int SET_ENTRIES = 2 * KS * 64;                  // 16-byte entries of one 64-query set's image (32 KiB)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = lane & 15, g = lane >> 4;
+    const int n = lane & 31, h = lane >> 5;                   // accumulator column (query of a 32-group), row half
 
     // workgroup -> (query tile, row lane): blocks b, b + 8, ... share an XCD (observed dispatch; speed only)
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3, jb = gridDim.x >> 3;
     const int rlx = jb / a.nqt;                               // row lanes per XCD label
     if (j >= rlx * a.nqt) return;
-    const int qt = j % a.nqt, rl = (j / a.nqt) * 8 + x, nrl = rlx * 8;
+    const int qt = j % a.nqt, nrl = rlx * 8;
+    const int rl = a.map_mode == 1 ? x * rlx + (j / a.nqt) : (j / a.nqt) * 8 + x;
     const int set0 = qt * a.spt;
     int nsets = ((a.Q + 63) >> 6) - set0;
     nsets = nsets > a.spt ? a.spt : nsets;
@@ -1122,14 +1185,14 @@ __global__ void __launch_bounds__(WAVES * 64) scan_coarse_wide_kernel(WideArgs a
     uint4* qimg = reinterpret_cast<uint4*>(smem);
     {
         const uint4* src = a.qimage + (size_t)set0 * SET_ENTRIES;
-        const int n = nsets * SET_ENTRIES;                    // multiple of 2048
-        for (int base = tid; base < n; base += 8 * WAVES * 64) {
+        const int ne = nsets * SET_ENTRIES;                   // multiple of 2048
+        for (int base = tid; base < ne; base += 8 * WAVES * 64) {
             uint4 v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = base + i * WAVES * 64 < n ? src[base + i * WAVES * 64] : make_uint4(0u, 0u, 0u, 0u);
+            for (int i = 0; i < 8; ++i) v[i] = base + i * WAVES * 64 < ne ? src[base + i * WAVES * 64] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (base + i * WAVES * 64 < n) qimg[base + i * WAVES * 64] = v[i];
+                if (base + i * WAVES * 64 < ne) qimg[base + i * WAVES * 64] = v[i];
         }
     }
     float* ltau = reinterpret_cast<float*>(smem + (size_t)a.spt * SET_ENTRIES * 16);       // [256] scaled thresholds
@@ -1142,142 +1205,142 @@ __global__ void __launch_bounds__(WAVES * 64) scan_coarse_wide_kernel(WideArgs a
     uint2* list = reinterpret_cast<uint2*>(reinterpret_cast<char*>(lyt + 64 * WIDE_TILE_SETS) + (size_t)wave * WIDE_WAVE_BYTES);
     __syncthreads();
 
-    const long long step0 = a.row0 >> 5;
-    const long long nsteps = step0 + ((a.nrows + 31) >> 5);
-    const long long tw = (long long)nrl * WAVES;
-    const long long last_row = a.row0 + a.nrows - 1;
+    // block indices fit 32 bits (N < 2^32 rows) and are wave-uniform: kept in scalar registers, so the block meta is a
+    // scalar load (a vector load here put a vmcnt(0) at the head of the group loop - behind the 16 KB prefetch) and the row
+    // loads are scalar base + one lane offset
+    const int blk0 = (int)(a.row0 >> 5);
+    const int nblk = blk0 + (int)((a.nrows + 31) >> 5);
+    const int tw = nrl * WAVES;
+    const unsigned last_row32 = (unsigned)(a.row0 + a.nrows - 1);
     int npend = 0;                                            // wave-uniform: pairs pending in `list`
 
-    long long step = step0 + (long long)rl * WAVES + wave;
-    if (step < nsteps) {
-        uint4 T[2 * KS];
-        auto frag_ptr = [&](long long st, int rt) {
-            long long r = st * 32 + rt * 16 + col;
-            r = r > last_row ? last_row : r;
-            return reinterpret_cast<const char*>(a.dbc) + r * ROWB + 16 * g;
+    int blk = __builtin_amdgcn_readfirstlane(blk0 + rl * WAVES + wave);
+    if (blk < nblk) {
+        uint4 Ta[KS], Tb[KS];                                 // this block's rows / the next block's (in flight for a whole step)
+        // rows are loaded as buffer loads: scalar resource (rebased per block, so 32-bit offsets suffice for any copy size),
+        // ONE lane-offset register, scalar k-step offsets - 64-bit per-lane addresses cost 26 registers here
+        const unsigned lane16 = (unsigned)lane * 16u;
+        auto load_block = [&](int b_, uint4 (&dst)[KS]) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<signed char*>(a.dbc) + (size_t)b_ * (32 * 512), 0, 32 * 512, 0x00020000);
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_)
+                dst[s_] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, s_ * 1024, 0));
         };
-        uint4 M[4];
-        auto load_meta = [&](long long st, uint4* m) {
+        load_block(blk, Ta);
+        // the block's (scale, largest error norm): fetched with the rows, one block ahead (a load at the head of a block
+        // would be waited for behind that block's own 16 KB prefetch: vmcnt counts in order)
+        float2 bm = a.bmeta[blk], bmn = bm;
+        // One 32-row block against the tile's 32-query groups. The next block's 16 KB are requested during group `pf_g`
+        // and land under the remaining MFMAs: group 0 in the tile-0 workgroup of a row lane, halfway through the step in
+        // the other tiles' workgroups of the same row lane (same rows, same order, same XCD; a measured wash - 41 % of the
+        // L2 requests hit either way - kept because it spreads the four workgroups' HBM bursts).
+        // The compare of group G - 1 is issued between the MFMAs of group G (two accumulators): alone it left the matrix
+        // pipe idle for the accumulator drain, a dependent VALU chain and a branch per group (19 % of the launch, by ablation).
+        // Returns false after the wave's last block.
+        const int ng = 2 * nsets;
+        const int pf_g = (qt == 0 || a.pf_mode == 1) ? 0 : a.pf_mode == 2 ? ng - 2 : a.pf_mode == 3 ? qt * ng / a.nqt : ng / 2;
+        constexpr int BR = 4;                                  // ring of query fragments: LDS reads run BR MFMAs ahead
+        auto run_block = [&](uint4 (&T)[KS], uint4 (&TN)[KS]) -> bool {
+            const int nxt = __builtin_amdgcn_readfirstlane(blk + tw);
+            const bool has_next = nxt < nblk;
+            const float inv_s = 1.0f / bm.x;
+            uint4 B[BR];                                       // ring of query fragments, continuous over the groups
+            {
+                const uint4* img0 = qimg + lane;
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const uint4* mp = reinterpret_cast<const uint4*>(a.rmeta + st * 32 + rt * 16 + 4 * g);
-                m[2 * rt] = mp[0];
-                m[2 * rt + 1] = mp[1];
+                for (int p_ = 0; p_ < BR; ++p_) B[p_] = img0[p_ * 64];
             }
-        };
-        {
-            const char* p0 = frag_ptr(step, 0);
-            const char* p1 = frag_ptr(step, 1);
+            // The exact test of a (row, query) pair is  D s + a_r Y_q >= T_q  (T_q = (tau - margin) / t_q, Y_q = 1.001 ||y|| / t_q;
+            // s the block's scale). Integer pre-test, one per lane (= query): no row of the block can pass unless
+            // D >= (T_q - amax_block Y_q) / s, rounded down with slack for the f32 roundings on both sides (|D| < 2^23 is exact
+            // in f32; each side rounds a few times at ~1e-7 relative) - so the lane's largest D decides, and the per-row test
+            // runs only where it can succeed. +inf thresholds (padding queries) saturate to "never", -inf (no threshold yet)
+            // and NaN to "always".
+            auto pretest = [&](const i32x16& acc, float tq, float yq) -> bool {
+                float xq = fmaf(-bm.y, yq, tq) * inv_s;
+                xq = xq - 2.0f - fabsf(xq) * 2e-6f;
+                xq = fminf(fmaxf(xq, -1.0e9f), 1.0e9f);                   // fmaxf(NaN, c) = c: NaN -> always
+                const int dmin = (int)floorf(xq);
+                auto max3 = [](int a_, int b_, int c_) { const int m_ = a_ > b_ ? a_ : b_; return m_ > c_ ? m_ : c_; };
+                const int m0 = max3(acc[0], acc[1], acc[2]), m1 = max3(acc[3], acc[4], acc[5]), m2 = max3(acc[6], acc[7], acc[8]);
+                const int m3 = max3(acc[9], acc[10], acc[11]), m4 = max3(acc[12], acc[13], acc[14]);
+                const int ma = max3(m0, m1, m2), mb = max3(m3, m4, acc[15]);              // three levels, not a chain of eight
+                return (ma > mb ? ma : mb) >= dmin;
+            };
+            // per-row test with the block's largest error norm in place of the row's own (a few per cent looser, a superset
+            // all the same): no per-row meta loads here - they would queue behind the next block's 16 KB
+            auto append = [&](const i32x16& acc, int G, float tq, float yq) {
+                const unsigned rbase = (unsigned)blk * 32u + 4u * (unsigned)h;      // rows fit 32 bits (N < 2^32 - 1)
+                const float ay = bm.y * yq;
 #pragma unroll
-            for (int s_ = 0; s_ < KS; ++s_) {
-                T[s_] = *reinterpret_cast<const uint4*>(p0 + 64 * s_);
-                T[KS + s_] = *reinterpret_cast<const uint4*>(p1 + 64 * s_);
-            }
-            load_meta(step, M);
-        }
-        while (true) {
-            const long long nxt = step + tw;
-            const bool has_next = nxt < nsteps;
-            const char* pn0 = frag_ptr(has_next ? nxt : step, 0);
-            const char* pn1 = frag_ptr(has_next ? nxt : step, 1);
-            uint4 MN[4];
-            load_meta(has_next ? nxt : step, MN);
-            const float sr[2][4] = {{__uint_as_float(M[0].x), __uint_as_float(M[0].z), __uint_as_float(M[1].x), __uint_as_float(M[1].z)},
-                                    {__uint_as_float(M[2].x), __uint_as_float(M[2].z), __uint_as_float(M[3].x), __uint_as_float(M[3].z)}};
-            const float ar[2][4] = {{__uint_as_float(M[0].y), __uint_as_float(M[0].w), __uint_as_float(M[1].y), __uint_as_float(M[1].w)},
-                                    {__uint_as_float(M[2].y), __uint_as_float(M[2].w), __uint_as_float(M[3].y), __uint_as_float(M[3].w)}};
-
-            // one 64-query set against the step's 32 rows; REFILL: the fragments' registers take the next step's rows
-            auto run_set = [&](int set, auto refill) {
-                constexpr bool REFILL = decltype(refill)::value;
-                const uint4* img = qimg + (size_t)set * SET_ENTRIES;
-                i32x4 acc[2][QGS];
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int qg = 0; qg < QGS; ++qg) acc[rt][qg] = i32x4{0, 0, 0, 0};
-                uint4 B[2][QGS];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int qg = 0; qg < QGS; ++qg) B[0][qg] = img[(qg * KS + 0) * 64 + lane];
-#pragma unroll
-                for (int s_ = 0; s_ < KS; ++s_) {
-                    if (s_ + 1 < KS) {
-#pragma unroll
-                        for (int qg = 0; qg < QGS; ++qg) B[(s_ + 1) & 1][qg] = img[(qg * KS + s_ + 1) * 64 + lane];
+                for (int i = 0; i < 16; ++i) {
+                    const unsigned row = rbase + (unsigned)((i & 3) + 8 * (i >> 2));
+                    const float val = fmaf((float)acc[i], bm.x, ay);
+                    const bool pass = (val >= tq) && (row <= last_row32);
+                    const unsigned long long m = __ballot(pass);
+                    if (m) {
+                        const int pos = npend + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        if (pass) list[pos] = make_uint2((unsigned)(G * 32 + n), row);
+                        npend += __builtin_popcountll(m);
                     }
-#pragma unroll
-                    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                        for (int qg = 0; qg < QGS; ++qg)
-                            acc[rt][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, T[rt * KS + s_]),
-                                                                                __builtin_bit_cast(i32x4, B[s_ & 1][qg]),
-                                                                                acc[rt][qg], 0, 0, 0);
-                    if (REFILL) {
-                        T[s_] = *reinterpret_cast<const uint4*>(pn0 + 64 * s_);
-                        T[KS + s_] = *reinterpret_cast<const uint4*>(pn1 + 64 * s_);
+                    if ((i & 3) == 3 && npend > WIDE_FLUSH) {              // <= 256 appends between two tests
+                        wide_flush(list, npend, qbase, a.gcnt, a.cand, a.cap, a.overflow);
+                        npend = 0;
                     }
-                }
-                __builtin_amdgcn_sched_group_barrier(0x100, QGS, 0);                   // k-step 0's query fragments
-#pragma unroll
-                for (int s_ = 0; s_ < KS; ++s_) {
-                    if (s_ + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, QGS, 0);   // DS reads: next k-step's fragments
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * QGS, 0);                // this k-step's MFMAs
-                    if (REFILL) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);          // VMEM reads: the refills
-                }
-                __builtin_amdgcn_sched_barrier(0);
-
-                // compare: D * s_r + a_r * 1.001 ||y|| / t_q  >=  (tau - margin) / t_q
-                float tau[QGS], yt[QGS];
-#pragma unroll
-                for (int qg = 0; qg < QGS; ++qg) {
-                    tau[qg] = ltau[set * 64 + qg * 16 + col];
-                    yt[qg] = lyt[set * 64 + qg * 16 + col];
-                }
-                bool pass[2][QGS][4];
-                bool any = false;
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int qg = 0; qg < QGS; ++qg)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float val = fmaf((float)acc[rt][qg][r], sr[rt][r], ar[rt][r] * yt[qg]);
-                            pass[rt][qg][r] = (val >= tau[qg]) && (step * 32 + rt * 16 + 4 * g + r <= last_row);
-                            any |= pass[rt][qg][r];
-                        }
-                if (__ballot(any)) {
-#pragma unroll
-                    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                        for (int qg = 0; qg < QGS; ++qg) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const unsigned long long m = __ballot(pass[rt][qg][r]);
-                                if (m) {
-                                    const int pos = npend + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                                    if (pass[rt][qg][r])
-                                        list[pos] = make_uint2((unsigned)(set * 64 + qg * 16 + col),
-                                                               (unsigned)(step * 32 + rt * 16 + 4 * g + r));
-                                    npend += __builtin_popcountll(m);
-                                }
-                            }
-                            if (npend > WIDE_FLUSH) {
-                                wide_flush(list, npend, qbase, a.gcnt, a.cand, a.cap, a.overflow);
-                                npend = 0;
-                            }
-                        }
                 }
             };
-            for (int set = 0; set + 1 < nsets; ++set) run_set(set, std::false_type{});
-            run_set(nsets - 1, std::true_type{});
-
-            if (!has_next) break;
-            step = nxt;
+            // group G's 16 MFMAs into `acc`; group G - 1's pre-test (accumulator `accp`) between them
+            auto run_group = [&](int G, i32x16& acc, const i32x16& accp, float& tq, float& yq, float tqp, float yqp) {
+                if (G == pf_g) {
+                    if (ABL == 3) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) M[i] = MN[i];
-        }
+                        for (int s_ = 0; s_ < KS; ++s_) TN[s_] = T[s_];
+                    } else {
+                        load_block(has_next ? nxt : blk, TN);
+                    }
+                    bmn = a.bmeta[has_next ? nxt : blk];
+                }
+                const uint4* img = qimg + (size_t)G * (KS * 64) + lane;
+                const uint4* imgn = qimg + (size_t)(G + 1 < ng ? G + 1 : G) * (KS * 64) + lane;   // the next group's head
+                tq = ltau[G * 32 + n];                                     // read ahead of the fragments: no wait of their own
+                yq = lyt[G * 32 + n];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, T[s_]),
+                                                                __builtin_bit_cast(i32x4, B[s_ % BR]), acc, 0, 0, 0);
+                    if (ABL != 2) B[s_ % BR] = s_ + BR < KS ? img[(s_ + BR) * 64] : imgn[(s_ + BR - KS) * 64];
+                }
+                bool hitp = false;
+                if (ABL != 1) hitp = pretest(accp, tqp, yqp);
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // MFMA of k-step s
+                    if (ABL != 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // DS read: the fragment BR k-steps on
+                    if (ABL != 1) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);        // VALU: two of the pre-test's ~30
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ABL == 1) asm volatile("" :: "v"(accp), "v"(tqp), "v"(yqp));
+                if (G > 0 && __ballot(hitp)) append(accp, G - 1, tqp, yqp);
+            };
+            i32x16 accA, accB;
+            float tqA = 0.f, yqA = 0.f, tqB = INFINITY, yqB = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accB[i] = 0;
+            for (int G = 0; G < ng; G += 2) {
+                run_group(G, accA, accB, tqA, yqA, tqB, yqB);
+                run_group(G + 1, accB, accA, tqB, yqB, tqA, yqA);
+            }
+            if (ABL != 1 && __ballot(pretest(accB, tqB, yqB))) append(accB, ng - 1, tqB, yqB);
+            blk = nxt;
+            bm = bmn;
+            return has_next;
+        };
+        while (run_block(Ta, Tb) && run_block(Tb, Ta)) {}
     }
     // final publication, aggregated per block (one returning global atomic per (block, query))
     __syncthreads();
@@ -1714,13 +1777,13 @@ int wide_waves() {
     return w;
 }
 
-template <int WAVES>
+template <int WAVES, int ABL = 0>
 int launch_wide_t(const WideArgs& a, hipStream_t st, hipEvent_t* ev) {
     const size_t lds = (size_t)a.spt * 32768 + 2048 + WAVES * WIDE_WAVE_BYTES;
     if (lds > (size_t)LDS_LIMIT) return set_err(CLIPMI_EUNSUPPORTED, "scan_coarse_wide: %zu B of LDS", lds);
-    if (int rc = opt_in_lds((const void*)scan_coarse_wide_kernel<WAVES>, lds)) return rc;
+    if (int rc = opt_in_lds((const void*)scan_coarse_wide_kernel<WAVES, ABL>, lds)) return rc;
     if (ev) (void)hipEventRecord(ev[0], st);
-    hipLaunchKernelGGL((scan_coarse_wide_kernel<WAVES>), dim3(NUM_CU), dim3(WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((scan_coarse_wide_kernel<WAVES, ABL>), dim3(NUM_CU), dim3(WAVES * 64), lds, st, a);
     if (ev) (void)hipEventRecord(ev[1], st);
     CLIPMI_CHECK_LAUNCH("scan_coarse_wide_kernel");
     return 0;
@@ -1728,13 +1791,14 @@ int launch_wide_t(const WideArgs& a, hipStream_t st, hipEvent_t* ev) {
 
 // segment boundaries of a wide search: rows [0, b[0]), [b[0], b[1]), ... [b[n-2], N); b[n-1] = N. After every segment the
 // exact K-th best of all rows seen so far filters the next one, so the boundaries grow geometrically: with ratio r the
-// number of exactly re-scored rows per query is about (segments) x (r - 1) x K x e^{0.36 z} - 4 segments of ratio ~5 from
-// 64 k rows give ~3.3 k at 10 M rows where the 64-query pass's three (ratio ~10 from N K / 2048) give ~5 k; a wide pass
-// re-scores for up to 1024 queries at once (2 KB of f32 row per pair), so its re-scoring bytes rival the scan's.
+// number of exactly re-scored rows per query is about (segments) x (r - 1) x K x e^{0.36 z} - 5 segments of ratio 4 from
+// 64 k rows give ~3 k at 10 M rows where the 64-query pass's three (ratio ~10 from N K / 2048) give ~5 k; a wide pass
+// re-scores for up to 1024 queries at once (2 KB of f32 row per pair), so its re-scoring bytes rival the scan's
+// (measured at 10 M rows, Q = 1024, same box: ratio 4 158 k q/s, 5 150 k, 6 152 k, 8 149 k, 3 146 k).
 constexpr int WIDE_MAX_SEGS = 8;
 int wide_segments(long long N, int K, long long S1, long long* b) {
     static const long long first = [] { const char* e = getenv("CLIPMI_WIDE_SEG0"); return e ? atoll(e) : 0ll; }();
-    static const int ratio = [] { const char* e = getenv("CLIPMI_WIDE_SEG_RATIO"); return e && atoi(e) >= 2 ? atoi(e) : 5; }();
+    static const int ratio = [] { const char* e = getenv("CLIPMI_WIDE_SEG_RATIO"); return e && atoi(e) >= 2 ? atoi(e) : 4; }();
     long long s = first > 0 ? first : 65536;
     if (s < S1) s = S1;
     s = (s + 31) & ~31ll;
@@ -1777,7 +1841,7 @@ int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta,
         const float* qg = q_dev + (size_t)q0 * E;
         const int nsets = (qc + 63) / 64;
         hipLaunchKernelGGL(coarse_prep_kernel<true>, dim3(nsets * 16), dim3(256), 0, st, qg, E, rmax, amax, qc, w.qmeta, w.qimage,
-                           w.gcnt_e, 2 * qs + 4, qs);
+                           w.gcnt_e, 2 * qs + 4, qs, 1);
         CLIPMI_CHECK_LAUNCH("coarse_prep_kernel(wide)");
         long long S1 = p.stage < 4096 ? 4096 : (p.stage / 16) * 16;
         if (S1 > 12288) S1 = 12288;
@@ -1794,10 +1858,12 @@ int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta,
         }
         WideArgs c;
         c.dbc = static_cast<const signed char*>(db8_dev); c.rmeta = rmeta; c.qmeta = w.qmeta; c.qimage = w.qimage;
+        c.bmeta = rmeta + i8_row_meta_entries(N);
         c.Q = qc; c.qs = qs;
         c.nqt = (nsets + WIDE_TILE_SETS - 1) / WIDE_TILE_SETS;
         c.spt = (nsets + c.nqt - 1) / c.nqt;
         c.cand = w.cand_c; c.gcnt = w.gcnt_c; c.cap = WIDE_CAP; c.overflow = w.flag;
+        { const char* e = getenv("CLIPMI_WIDE_MAP"); c.map_mode = e ? atoi(e) : 0; e = getenv("CLIPMI_WIDE_PF"); c.pf_mode = e ? atoi(e) : 0; }
         long long bnd[WIDE_MAX_SEGS];
         const int nseg = wide_segments(N, K, S1, bnd);
         float* os_final = out_score_dev + (size_t)q0 * K;
@@ -1809,7 +1875,10 @@ int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta,
             c.row0 = r0;
             c.nrows = bnd[sgi] - r0;
             hipEvent_t* ev = (scan_ev && ev_used + 2 <= max_ev) ? scan_ev + ev_used : nullptr;
-            if (int rc = wide_waves() == 4 ? launch_wide_t<4>(c, st, ev) : launch_wide_t<8>(c, st, ev)) return rc;
+            static const int abl = [] { const char* e = getenv("CLIPMI_WIDE_ABL"); return e ? atoi(e) : 0; }();
+            if (int rc = abl == 1 ? launch_wide_t<8, 1>(c, st, ev) : abl == 2 ? launch_wide_t<8, 2>(c, st, ev)
+                       : abl == 3 ? launch_wide_t<8, 3>(c, st, ev)
+                       : wide_waves() == 4 ? launch_wide_t<4>(c, st, ev) : launch_wide_t<8>(c, st, ev)) return rc;
             if (ev) ev_used += 2;
             hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(12, qc), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
                                static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, WIDE_CAP);
@@ -1865,11 +1934,20 @@ extern "C" int clipmi_topk_ip_coarse(const void* db_dev, const void* db_bf16_dev
                                out_id_dev, ws_dev, ws_bytes, stream, nullptr);
 }
 
+extern "C" size_t clipmi_i8_copy_bytes(int64_t N, int E) {
+    return N < 0 || E < 32 ? 0 : (size_t)((N + 31) / 32 * 32) * (size_t)E;
+}
+
+extern "C" size_t clipmi_i8_meta_bytes(int64_t N) {
+    return N < 0 ? 0 : (i8_row_meta_entries(N) + (size_t)((N + 31) / 32 + 1)) * sizeof(float2);
+}
+
 extern "C" int clipmi_quantize_rows_i8(const float* db_dev, int64_t N, int E, void* out_i8_dev, float* meta_dev, void* stream) {
-    if (!db_dev || !out_i8_dev || !meta_dev || N < 1 || E < 4 || E % 4 != 0)
-        return set_err(CLIPMI_EINVAL, "quantize_rows_i8: bad arguments (N=%lld E=%d)", (long long)N, E);
-    hipLaunchKernelGGL(quantize_rows_i8_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, as_stream(stream), db_dev,
-                       (long long)N, E, static_cast<signed char*>(out_i8_dev), reinterpret_cast<float2*>(meta_dev));
+    if (!db_dev || !out_i8_dev || !meta_dev || N < 1 || E < 32 || E % 32 != 0)
+        return set_err(CLIPMI_EINVAL, "quantize_rows_i8: bad arguments (N=%lld E=%d; E must be a multiple of 32)", (long long)N, E);
+    float2* meta = reinterpret_cast<float2*>(meta_dev);
+    hipLaunchKernelGGL(quantize_rows_i8_kernel, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, as_stream(stream), db_dev,
+                       (long long)N, E, static_cast<signed char*>(out_i8_dev), meta, meta + i8_row_meta_entries(N));
     CLIPMI_CHECK_LAUNCH("quantize_rows_i8_kernel");
     return 0;
 }

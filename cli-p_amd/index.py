@@ -140,17 +140,18 @@ class IndexFlatIP:
         return self._rmax
 
     def matrix_i8(self):
-        """(int8 copy [N][d], per-row (scale, error norm) f32 [N32][2] padded to a multiple of 32 rows, largest
+        """(int8 copy in 32-row blocks of [d / 32][64][16 B] - include/clipmi.h clipmi_quantize_rows_i8 -, f32 meta:
+        (block scale, error norm) per row padded to 32 rows (+32) then (scale, largest error norm) per block, largest
         error norm, largest row norm) for the int8 coarse path; built once by clipmi_quantize_rows_i8."""
         if self._db8 is None:
             L = _lib.lib()
             db = self.matrix()
             N = db.shape[0]
-            q8 = torch.empty((N, self.d), dtype=torch.int8, device=db.device)
-            meta = torch.zeros(((N + 31) // 32 * 32 + 32, 2), dtype=torch.float32, device=db.device)
+            q8 = torch.empty(L.clipmi_i8_copy_bytes(N, self.d), dtype=torch.int8, device=db.device)
+            meta = torch.zeros(L.clipmi_i8_meta_bytes(N) // 4, dtype=torch.float32, device=db.device)
             _lib.check(L.clipmi_quantize_rows_i8(db.data_ptr(), N, self.d, q8.data_ptr(), meta.data_ptr(),
                                                  _lib.stream_ptr(self.device)), "clipmi_quantize_rows_i8")
-            amax = float(meta[:N, 1].max()) * (1.0 + 1e-6)
+            amax = float(meta[1:2 * N:2].max()) * (1.0 + 1e-6)
             self._db8 = (q8, meta, amax)
         return self._db8 + (self._row_norm_max(),)
 

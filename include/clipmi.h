@@ -163,12 +163,20 @@ int clipmi_topk_ip_coarse(const void* db_dev, const void* db_bf16_dev, int64_t N
                           void* ws_dev, size_t ws_bytes, void* stream);
 
 /* ---- a12, int8 coarse copy: the same contract with a quarter of the f32 bytes per pass.
- * clipmi_quantize_rows_i8 builds the copy: row r -> scale s_r = max|x_rk| / 127, q_rk = rint(x_rk / s_r) (int8
- * [N][E]) and meta[r] = (s_r, a_r) with a_r >= ||x_r - s_r q_r||_2; `meta_dev` must have room for N rounded up to
- * a multiple of 32 rows (+32), 2 floats each, zero-filled past N. clipmi_topk_ip_coarse_i8 scans it with
- * v_mfma_i32_16x16x64_i8 (exact integer dot products) and keeps every row whose exact score could reach the
- * running K-th best, by |x.y - s_r t_q D| <= a_r ||y|| + (rmax + amax) ||y - t_q p_q||; survivors are re-scored in
- * exact f32 as above. `amax` >= every a_r, `rmax` >= every row norm. Workspace: clipmi_topk_ip_coarse_workspace_bytes. */
+ * clipmi_quantize_rows_i8 builds the copy (E a multiple of 32). Rows are taken in blocks of 32 that share one scale
+ * s = (largest |x| of the block) / 127; q_rk = rint(x_rk / s). `out_i8_dev` (clipmi_i8_copy_bytes) holds the blocks as
+ * [E / 32][64][16 bytes] - entry (k-step s, lane l) = bytes 32 s + 16 (l >> 5) .. + 15 of row (l & 31) of the block, the
+ * register image of v_mfma_i32_32x32x32_i8's row operand, so a scanning wave reads whole contiguous KiB; rows past N in
+ * the last block are zero. `meta_dev` (clipmi_i8_meta_bytes) receives meta[r] = (s, a_r) with a_r >= ||x_r - s q_r||_2
+ * for N rounded up to 32 rows (+32), followed by one (s, largest a_r) pair per block.
+ * clipmi_topk_ip_coarse_i8 scans the copy with integer MFMA (exact integer dot products) and keeps every row whose exact
+ * score could reach the running K-th best, by |x.y - s t_q D| <= a_r ||y|| + (rmax + amax) ||y - t_q p_q||; survivors are
+ * re-scored in exact f32 as above. `amax` >= every a_r, `rmax` >= every row norm. Up to 64 queries are one pass of the
+ * copy (v_mfma_i32_16x16x64_i8, HBM-bound); MORE than 64 queries (query-index.py:111 is one call whatever Q) are taken
+ * in chunks of <= 1024 as ONE pass each (v_mfma_i32_32x32x32_i8, query tiles of 256 resident in LDS, matrix-bound).
+ * Workspace: clipmi_topk_ip_coarse_workspace_bytes. */
+size_t clipmi_i8_copy_bytes(int64_t N, int E);
+size_t clipmi_i8_meta_bytes(int64_t N);
 int clipmi_quantize_rows_i8(const float* db_dev, int64_t N, int E, void* out_i8_dev, float* meta_dev, void* stream);
 int clipmi_topk_ip_coarse_i8(const void* db_dev, const void* db_i8_dev, const float* meta_dev, float amax,
                              int64_t N, int E, float rmax, const float* q_dev, int Q, int K, int64_t id_base,
@@ -278,6 +286,15 @@ int clipmi_dbg_gemm_resid_ln(const void* a_dev, const void* w_dev, const float* 
 int clipmi_dbg_encode_image_probe_ms(const clipmi_tower* t, const void* blob_dev, const void* pixels_dev,
                                      int pix_dtype, int B, float* out_dev, void* ws_dev, size_t ws_bytes,
                                      void* stream, int probe_epi, int reps, float* kernel_ms, int* launches);
+
+/* The same with three estimators of the kernel's in-situ duration, ms3[0..2] (csrc/encode.hip encode_probe): begin -> end
+ * events of the launch itself (reads long in a back-to-back stream), plain event in front -> end event, and end event of the
+ * GEMM directly in front -> end event of this one (completion to completion; 0 when not applicable). *kernel_kind: 0 / 1 / 2 =
+ * gemm_bf16_nt_kernel / gemm256_bf16_nt_kernel / gemm256p_bf16_nt_kernel; *epi_ran: its EPI template argument. */
+int clipmi_dbg_encode_image_probe3_ms(const clipmi_tower* t, const void* blob_dev, const void* pixels_dev,
+                                      int pix_dtype, int B, float* out_dev, void* ws_dev, size_t ws_bytes,
+                                      void* stream, int probe_epi, int reps, float* ms3, int* launches,
+                                      int* kernel_kind, int* epi_ran);
 
 #ifdef __cplusplus
 }

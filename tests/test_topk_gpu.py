@@ -421,26 +421,116 @@ def test_large_query_batch_is_pipelined_and_exact(clipmi, gpu, topk_oracle, kind
     _assert_exact(Dn, In, D, I, "search()")
 
 
+@pytest.mark.parametrize("N,Q,K", [(70001, 65, 51), (100000, 256, 51), (131072, 300, 11), (90000, 640, 21), (200003, 1024, 51),
+                                   (66000, 1100, 51)])
+def test_wide_int8_pass_is_bit_exact(clipmi, gpu, topk_oracle, N, Q, K):
+    """More than 64 queries in ONE call (query-index.py:111 is one index.search whatever Q): the int8 path takes them as
+    wide passes (csrc/topk.hip scan_coarse_wide_kernel: 1, 2, 3 or 4 query tiles, partial sets, a second chunk past 1024).
+    Bit-exact against the oracle on 96 of the queries (every tile / set position) and, for ALL queries, against the exact f32
+    scan (clipmi_topk_ip), which the tests above pin to the oracle."""
+    rng = np.random.default_rng(N + Q + K + 2)
+    db = unit_rows(rng, N, 512)
+    q = unit_rows(rng, Q, 512)
+    D, I = _run_coarse(clipmi, gpu, db, q, K, id_base=7, kind="int8")
+    De, Ie = _run(clipmi, gpu, db, q, K, id_base=7)
+    _assert_exact(D, I, De, Ie, f"wide int8 vs exact scan N={N} Q={Q} K={K}")
+    pick = np.unique(np.concatenate([np.arange(0, Q, max(1, Q // 64)), np.arange(max(0, Q - 32), Q)]))[:96]
+    Ds, Is = topk_oracle.topk(db, q[pick], K, id_base=7)
+    _assert_exact(D[pick], I[pick], Ds, Is, f"wide int8 vs oracle N={N} Q={Q} K={K}")
+
+
+@pytest.mark.parametrize("Q", [256, 1024])
+def test_wide_identical_rows_and_duplicate_cluster(clipmi, gpu, topk_oracle, Q):
+    """The wide pass's per-wave list at its limits: (i) 300 k identical rows - every (query, row) pair of every 32-row block
+    passes, lists overflow their global capacity and the exact fallback answers; (ii) 4096 consecutive duplicates of the row
+    that ranks first for every query - 128 consecutive blocks in which all queries accept all rows, answered by the wide path
+    itself (4096 < 2^15 slots)."""
+    rng = np.random.default_rng(7800 + Q)
+    N = 300000
+    v = unit_rows(rng, 1, 512)
+    db = np.repeat(v, N, axis=0)
+    db[123456] *= np.float32(1.5)
+    q = unit_rows(rng, Q, 512)
+    D, I = _run_coarse(clipmi, gpu, db, q, 20, kind="int8")
+    pick = np.arange(0, Q, Q // 32)
+    Ds, Is = topk_oracle.topk(db, q[pick], 20)
+    _assert_exact(D[pick], I[pick], Ds, Is, f"wide identical rows Q={Q}")
+    assert (I[:, 0] == 123456).sum() >= 1 and (np.sort(I, axis=1)[:, :19] == np.arange(19)[None, :]).all()
+    N = 100000
+    db = unit_rows(rng, N, 512)
+    base = unit_rows(rng, 1, 512)[0]
+    db[30000:34096] = base
+    db[77777] = base
+    q = base[None, :] + 0.02 * unit_rows(rng, Q, 512)
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    D, I = _run_coarse(clipmi, gpu, db, q, 51, kind="int8")
+    Ds, Is = topk_oracle.topk(db, q[pick], 51)
+    _assert_exact(D[pick], I[pick], Ds, Is, f"wide duplicate cluster Q={Q}")
+    assert (I[:, 0] == 30000).all() and (I[:, 50] == 30050).all()
+
+
+def test_wide_pass_useless_threshold_and_anisotropic(clipmi, gpu, topk_oracle):
+    """Q = 200: (i) sample thresholds that filter nothing (the first 40 k rows score ~ -125 against every query): every pair of
+    the later rows survives the first segments; (ii) an anisotropic database (8 dominant dimensions + a shared offset)."""
+    rng = np.random.default_rng(8010)
+    N, Q = 70001, 200
+    q = unit_rows(rng, Q, 512)
+    u = q.sum(axis=0); u /= np.linalg.norm(u)
+    db = unit_rows(rng, N, 512)
+    db[:40000] = (-1000.0 * u)[None, :] * (1.0 + 1e-6 * np.arange(40000, dtype=np.float32))[:, None]
+    D, I = _run_coarse(clipmi, gpu, db, q, 51, kind="int8")
+    De, Ie = _run(clipmi, gpu, db, q, 51)
+    _assert_exact(D, I, De, Ie, "wide useless threshold vs exact scan")
+    Ds, Is = topk_oracle.topk(db, q[:40], 51)
+    _assert_exact(D[:40], I[:40], Ds, Is, "wide useless threshold vs oracle")
+    assert (I >= 40000).all()
+    db = _anisotropic_rows(rng, 150000, 512)
+    q = _anisotropic_rows(rng, Q, 512)
+    D, I = _run_coarse(clipmi, gpu, db, q, 51, kind="int8")
+    De, Ie = _run(clipmi, gpu, db, q, 51)
+    _assert_exact(D, I, De, Ie, "wide anisotropic vs exact scan")
+    Ds, Is = topk_oracle.topk(db, q[::5], 51)
+    _assert_exact(D[::5], I[::5], Ds, Is, "wide anisotropic vs oracle")
+
+
 def test_quantize_rows_i8_matches_numpy(clipmi, gpu):
-    """clipmi_quantize_rows_i8: scale = max|x| / 127, q = rint(x / scale) (round half to even), error norm >= the
-    true one and within 0.2 % of it."""
+    """clipmi_quantize_rows_i8 (include/clipmi.h): blocks of 32 rows share scale = max|x| / 127, q = rint(x / scale)
+    (round half to even), stored as [block][k-step of 32 B][lane][16 B] with lane l = row l & 31, bytes 32 s + 16 (l >> 5);
+    error norm >= the true one and within 0.2 % of it; one (scale, largest error norm) pair per block behind the row meta."""
     import torch
     rng = np.random.default_rng(81)
-    x = (unit_rows(rng, 1000, 512) * rng.uniform(0.1, 3.0, size=(1000, 1))).astype(np.float32)
+    N = 1000
+    x = (unit_rows(rng, N, 512) * rng.uniform(0.1, 3.0, size=(N, 1))).astype(np.float32)
     x[7] = 0.0
+    x[32:64] = 0.0                                     # a whole block of zero rows: scale 1, codes 0
     idx = clipmi.IndexFlatIP(512, device=gpu, coarse="int8")
     idx.add(x)
     q8, meta, amax, rmax = idx.matrix_i8()
     torch.cuda.synchronize()
+    L = clipmi._lib.lib()
+    N32 = (N + 31) // 32 * 32
+    nblk = N32 // 32
+    assert q8.numel() == L.clipmi_i8_copy_bytes(N, 512) == N32 * 512
+    assert meta.numel() * 4 == L.clipmi_i8_meta_bytes(N) == ((N32 + 32) + (nblk + 1)) * 8
     q8, meta = q8.cpu().numpy(), meta.cpu().numpy()
-    s = np.abs(x).max(axis=1) / np.float32(127.0)
+    rmeta = meta[:2 * (N32 + 32)].reshape(-1, 2)
+    bmeta = meta[2 * (N32 + 32):].reshape(-1, 2)
+    xp = np.zeros((N32, 512), np.float32)
+    xp[:N] = x
+    s = np.abs(xp).reshape(nblk, -1).max(axis=1) / np.float32(127.0)
     s[s == 0] = 1.0
-    assert np.array_equal(meta[:1000, 0], s.astype(np.float32))
-    ref = np.clip(np.rint(x * (np.float32(1.0) / s.astype(np.float32))[:, None]), -127, 127).astype(np.int8)
-    assert np.array_equal(q8, ref)
-    err = np.linalg.norm(x.astype(np.float64) - s[:, None].astype(np.float64) * q8.astype(np.float64), axis=1)
-    assert (meta[:1000, 1] >= err).all() and (meta[:1000, 1] <= err * 1.002 + 1e-12).all()
-    assert (meta[1000:] == 0).all() and amax >= meta[:, 1].max() and rmax >= np.linalg.norm(x, axis=1).max()
+    s = s.astype(np.float32)
+    srow = np.repeat(s, 32)
+    assert np.array_equal(rmeta[:N32, 0], srow) and np.array_equal(bmeta[:nblk, 0], s)
+    ref = np.clip(np.rint(xp * (np.float32(1.0) / srow)[:, None]), -127, 127).astype(np.int8)
+    # un-tile: [blk][ks][h][r][16] -> [blk*32 + r][32 ks + 16 h + b]
+    got = q8.reshape(nblk, 16, 2, 32, 16).transpose(0, 3, 1, 2, 4).reshape(N32, 512)
+    assert np.array_equal(got, ref)
+    err = np.linalg.norm(xp.astype(np.float64) - srow[:, None].astype(np.float64) * got.astype(np.float64), axis=1)
+    assert (rmeta[:N, 1] >= err[:N]).all() and (rmeta[:N, 1] <= err[:N] * 1.002 + 1e-12).all()
+    assert (rmeta[N:, 1] == 0).all() and (rmeta[N32:] == 0).all() and (bmeta[nblk:] == 0).all()
+    assert np.array_equal(bmeta[:nblk, 1], rmeta[:N32, 1].reshape(nblk, 32).max(axis=1))
+    assert amax >= rmeta[:, 1].max() and rmax >= np.linalg.norm(x, axis=1).max()
 
 
 @pytest.mark.parametrize("N", [10_000_000, 12_500_000])
