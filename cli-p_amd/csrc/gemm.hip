@@ -1,5 +1,6 @@
 // gemm.hip — instantiation and launch of the bf16 NT GEMM (see gemm.hpp).
 #include "gemm256p.hpp"
+#include "gemm_skinny.hpp"
 #include "gemm256f8.hpp"
 #include <hip/hip_ext.h>
 #include <cstdlib>
@@ -98,6 +99,37 @@ static int launch_epi256p(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
 // other kernel writes acc + bias as f32 into g.tmp_f32 and split_stats_kernel (add form) does the rest in one
 // LayerNorm-sized pass. Both give the same bits (same adds in the same order, canonical statistics: gemm.hpp).
 
+// skinny kernel (gemm_skinny.hpp): M <= 128 rows, one wave per 16 columns x 16 rows
+static bool skinny_ok(const GemmArgs& g) {
+    static const bool off = [] { const char* e = getenv("CLIPMI_GEMM_SKINNY"); return e && atoi(e) == 0; }();   // A/B aid
+    return !off && g.M >= 1 && g.M <= SKINNY_MAX_M && g.N % 16 == 0 && g.K % 32 == 0 && g.K >= 32;
+}
+
+template <int EPI>
+static int launch_skinny_t(const GemmArgs& g, hipStream_t st) {
+    const int nstrips = g.N / 16, mtiles = (g.M + 15) / 16;
+    const int waves = nstrips * mtiles <= 4 * NUM_CU ? 1 : 4;       // one wave per workgroup until every CU has four
+    const dim3 grid((nstrips + waves - 1) / waves, mtiles);
+    if (g.K > 512) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 32>), grid, dim3(waves * 64), 0, st, g);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 16>), grid, dim3(waves * 64), 0, st, g);
+    CLIPMI_CHECK_LAUNCH("gemm_skinny_kernel");
+    return 0;
+}
+
+static int launch_skinny(const GemmArgs& g, int epi, hipStream_t st) {
+    if (!g.A || !g.W || !g.out) return set_err(CLIPMI_EINVAL, "gemm: NULL pointer");
+    switch (epi) {
+        case EPI_BIAS_BF16: return launch_skinny_t<EPI_BIAS_BF16>(g, st);
+        case EPI_BIAS_QGELU_BF16: return launch_skinny_t<EPI_BIAS_QGELU_BF16>(g, st);
+        case EPI_BIAS_RESID_F32: return launch_skinny_t<EPI_BIAS_RESID_F32>(g, st);
+        case EPI_F32: return launch_skinny_t<EPI_F32>(g, st);
+        case EPI_PATCH_F32: return launch_skinny_t<EPI_PATCH_F32>(g, st);
+        case EPI_LN_BIAS_BF16: return launch_skinny_t<EPI_LN_BIAS_BF16>(g, st);
+        case EPI_LN_BIAS_QGELU_BF16: return launch_skinny_t<EPI_LN_BIAS_QGELU_BF16>(g, st);
+    }
+    return set_err(CLIPMI_EINVAL, "gemm_skinny: epilogue %d", epi);
+}
+
 // algo: 0 = choose by shape, 1 = force the 128x128 kernel, 2 = force the 256x256 kernel,
 //       3 = force the persistent 256x256 kernel
 int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmProbe* probe) {
@@ -135,6 +167,10 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmP
                   (tiles > NUM_CU || (epi == EPI_BIAS_RESID_LN_F32 && persist_mode() != 2));
     }
     if (g.M < 1 || !g.A || !g.W || (!g.out && epi != EPI_BIAS_RESID_LN_F32)) return set_err(CLIPMI_EINVAL, "gemm: bad arguments");
+    // a handful of rows (one prompt, one image): the skinny kernel, whatever the epilogue (the residual producer as
+    // acc + bias into the f32 scratch rows + the split / statistics pass, like every non-persistent kernel)
+    const bool skinny = algo == 0 && skinny_ok(g);
+    if (skinny && epi != EPI_BIAS_RESID_LN_F32) return launch_skinny(g, epi, st);
     if (epi == EPI_BIAS_RESID_LN_F32 && !use256p) {
         // not the persistent kernel: acc + bias as f32 into the scratch rows, then the add + split + statistics pass
         GemmArgs t = g;
@@ -142,7 +178,7 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmP
         GemmProbe* pr = (probe && probe->wants(EPI_BIAS_RESID_LN_F32)) ? probe : nullptr;
         const int saved_epi = pr ? pr->epi : -1;
         if (pr) pr->epi = EPI_F32;                       // the probe brackets the GEMM launch itself
-        const int rc = use256 ? launch_epi256<EPI_F32>(t, st, pr) : launch_gemm(t, EPI_F32, st, pr);
+        const int rc = skinny ? launch_skinny(t, EPI_F32, st) : use256 ? launch_epi256<EPI_F32>(t, st, pr) : launch_gemm(t, EPI_F32, st, pr);
         if (pr) pr->epi = saved_epi;
         if (rc) return rc;
         return launch_split_stats(g.tmp_f32, true, g.xhi, g.xlo, g.ln_part, g.M, g.N, st);

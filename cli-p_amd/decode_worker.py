@@ -134,7 +134,8 @@ def decode_full(path, n_px, region):
 
 def serve(fin, fout):
     """Answer requests until stdin closes. Request line (tab separated):
-         n_px | small segment or - | byte offset of the slot | big segment or - | byte offset of the region | its size | path
+         n_px | small segment or - | byte offset of the slot | big segment or - | byte offset of the region | its size |
+         path as hex (file names may contain newlines and tabs)
        Reply: b"0" failed | b"1" the transform's n_px x n_px pixels are in the slot (or follow, when no segment was named) |
               b"2" + <iiq (w, h, bytes)>: the image sits at full size, with its resize plan, in the region (decode_full)."""
     import mmap
@@ -163,7 +164,7 @@ def serve(fin, fout):
         try:
             n_px_s, shm_name, off_s, big_name, big_off_s, big_cap_s, path = line.rstrip(b"\n").split(b"\t", 6)
             n_px, off = int(n_px_s), int(off_s)
-            fname = path.decode("utf-8", "surrogateescape")
+            fname = bytes.fromhex(path.decode("ascii")).decode("utf-8", "surrogateescape")      # hex: see DecodePool._run
             reply = None
             if big_name != b"-":
                 region = np.frombuffer(mapped(big_name.decode()), dtype=np.uint8, count=int(big_cap_s), offset=int(big_off_s))

@@ -290,27 +290,23 @@ class ShardedFlatIP:
         self.nprobe = 1
 
     def _record(self, Q, K, device):
-        """Per-rank packed record [scores f32 Q*K | pad | ids i64 Q*K] and the gather buffer, cached."""
+        """Per-rank packed record [scores f32 Q*K | pad | ids i64 Q*K] and the gather buffer, cached per (Q, K, stream)."""
         skey = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
         key = (Q, K, str(device), skey)
         cache = self.__dict__.setdefault("_rec_cache", {})
-        if key in cache:
-            (self._rec, self._gath, self._rec_s, self._rec_i, self._out_s, self._out_i) = cache[key]
-            self._rec_key = key
-        if getattr(self, "_rec_key", None) != key:
+        ent = cache.get(key)
+        if ent is None:
             ids_off = (Q * K * 4 + 7) // 8 * 8
             nbytes = ids_off + Q * K * 8
-            self._rec = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            self._gath = torch.empty(self.world * nbytes, dtype=torch.uint8, device=device)
-            self._rec_s = self._rec[:Q * K * 4].view(torch.float32).view(Q, K)
-            self._rec_i = self._rec[ids_off:].view(torch.int64).view(Q, K)
-            self._out_s = torch.empty((Q, K), dtype=torch.float32, device=device)
-            self._out_i = torch.empty((Q, K), dtype=torch.int64, device=device)
-            self._rec_key = key
-            cache[key] = (self._rec, self._gath, self._rec_s, self._rec_i, self._out_s, self._out_i)
-        return self._rec, self._gath, self._rec_s, self._rec_i
+            rec = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            gath = torch.empty(self.world * nbytes, dtype=torch.uint8, device=device)
+            ent = cache[key] = (rec, gath, rec[:Q * K * 4].view(torch.float32).view(Q, K), rec[ids_off:].view(torch.int64).view(Q, K))
+        return ent
 
-    def search_device(self, q, K):
+    def search_device(self, q, K, out=None):
+        """-> (scores f32 [Q,K], ids i64 [Q,K]) of the WHOLE index, on every rank. `out` = (scores, ids) to write into;
+        otherwise fresh tensors per call (a caller holding two results keeps both: the record and gather buffers are
+        reused, the results are not)."""
         dist = self.dist
         Q = q.shape[0]
         if self._local_search is None:
@@ -321,7 +317,11 @@ class ShardedFlatIP:
             self.local.search_device(q, K, out=(rec_s, rec_i))
             dist.all_gather_into_tensor(gath, rec, group=self.group)
             L = _lib.lib()
-            out_s, out_i = self._out_s, self._out_i      # reused across calls of the same (Q, K): copy to keep
+            if out is None:
+                out_s = torch.empty((Q, K), dtype=torch.float32, device=dev)
+                out_i = torch.empty((Q, K), dtype=torch.int64, device=dev)
+            else:
+                out_s, out_i = out
             rc = L.clipmi_merge_topk_packed(gath.data_ptr(), rec.numel(), self.world, Q, K, out_s.data_ptr(),
                                             out_i.data_ptr(), _lib.stream_ptr(dev))
             _lib.check(rc, "clipmi_merge_topk_packed")
@@ -339,6 +339,10 @@ class ShardedFlatIP:
         S = np.stack([gath[r * n:r * n + Q * K * 4].view(torch.float32).view(Q, K).numpy() for r in range(self.world)])
         I = np.stack([gath[r * n + ids_off:(r + 1) * n].view(torch.int64).view(Q, K).numpy() for r in range(self.world)])
         ms, mi = merge_lists_host(S, I, K)
+        if out is not None:
+            out[0].copy_(torch.from_numpy(ms))
+            out[1].copy_(torch.from_numpy(mi))
+            return out
         return torch.from_numpy(ms), torch.from_numpy(mi)
 
     def search(self, x, K):

@@ -11,9 +11,13 @@ Multi-GPU (the reference is single-device, build-index.py:17): l
 `python -m torch.distributed.run --nproc-per-node N build-index.py DIR/ ...`, rank 0 owns the store. Per
 directory it lists the files still to encode, SORTS them and broadcasts the list; every rank takes the
 contiguous slice `shard_bounds(len(todo), world, rank)` and encodes it on its own GPU — images are
-independent, so the encode path has no collective. After every round of one batch per rank, the ranks'
-(keys, vectors, failures) are gathered to rank 0 over gloo (host-side ingest I/O, not the data path) and
-committed in rank order; rank 0 alone assembles the matrix and writes `images.index`.
+independent, so the encode path has no collective. Every rank commits its batches to its OWN shard of the
+store (`vectors.lmdb.shard-<rank>`, the packed append-only form); a round of one batch per rank ends with one
+small gloo all-gather of three integers per rank (files done, files failed, "I was asked to stop") — progress
+for rank 0's console and the agreement that lets every rank leave the loop in the SAME round when Ctrl-C
+reached any of them. After the loop rank 0 ingests the shards in rank order (= sorted-list order) into the
+store, assembles the matrix and writes `images.index` ("each rank emits its rows ... rank-0
+ingest of shard outputs"). Shards left behind by a run that died are ingested at the next start.
 
 Weights: $CLIPMI_WEIGHTS (a local ViT-B-32.pt / state-dict), or CLIPMI_RANDOM_WEIGHTS=<seed> for a
 synthetic model. Knobs: CLIPMI_BATCH (default 435 = whole rounds of GEMM tiles on 256 CUs),
@@ -44,9 +48,76 @@ def candidates(base_path, db):
     return todo
 
 
-def encode_directories(dirs, model, db, batch, workers, ranks=None, pool=None):
-    """ranks=None or world 1: the single-GPU loop. Otherwise `db` is only used on rank 0 (others pass None).
-    pool: a pipeline.DecodePool (decode in worker processes) or None (decode on `workers` threads)."""
+class StopFlag:
+    """Ctrl-C under N ranks: SIGINT sets a flag instead of raising inside whatever call it lands in (a collective, the
+    encoder); the build loop reads the flag once per round and the ranks agree on the round to stop in. Main thread only
+    (signal handlers cannot be installed elsewhere); elsewhere the flag can still be set by hand."""
+
+    def __init__(self):
+        self.set = False
+        self._old = None
+
+    def _handler(self, signum, frame):
+        self.set = True
+
+    def __enter__(self):
+        import signal
+        import threading
+        if threading.current_thread() is threading.main_thread():
+            self._old = signal.signal(signal.SIGINT, self._handler)
+        return self
+
+    def __exit__(self, *a):
+        import signal
+        if self._old is not None:
+            signal.signal(signal.SIGINT, self._old)
+            self._old = None
+
+
+def shard_path(store_path, rank):
+    return f"{store_path}.shard-{int(rank)}"
+
+
+def ingest_shards(db, store_path):
+    """Rank 0: move every shard store beside `store_path` into `db`, in rank order, then remove it. Returns the number of
+    vectors ingested. Also run at start-up: a shard that a dead run left behind holds finished work."""
+    import glob
+    import shutil
+    n = 0
+    found = []
+    for p in glob.glob(glob.escape(store_path) + ".shard-*"):
+        try:
+            found.append((int(p.rsplit("-", 1)[1]), p))
+        except ValueError:
+            pass
+    for _, p in sorted(found):
+        sh = vstore.VectorStore(p, dim=db.dim, backend="packed")
+        try:
+            keys, rows = [], []
+            for k, v in sh.b.items_sorted("fn_db"):
+                keys.append(k.decode("utf-8", "surrogateescape"))
+                rows.append(v)
+                if len(keys) >= 4096:
+                    db.b.put_many("fn_db", [(k_.encode("utf-8", "surrogateescape"), r_) for k_, r_ in zip(keys, rows)])
+                    n += len(keys)
+                    keys, rows = [], []
+            if keys:
+                db.b.put_many("fn_db", [(k_.encode("utf-8", "surrogateescape"), r_) for k_, r_ in zip(keys, rows)])
+                n += len(keys)
+            skipped = [kv for kv in sh.b.items_sorted("skip_db")]
+            if skipped:
+                db.b.put_many("skip_db", skipped)
+        finally:
+            sh.close()
+        shutil.rmtree(p, ignore_errors=True)
+    return n
+
+
+def encode_directories(dirs, model, db, batch, workers, ranks=None, pool=None, stop=None, store_path="vectors.lmdb"):
+    """ranks=None or world 1: the single-GPU loop. Otherwise `db` is only used on rank 0 (others pass None), every rank
+    writes `shard_path(store_path, rank)` and rank 0 ingests the shards at the end; returns True when the ranks agreed to
+    stop early (`stop`: a StopFlag). pool: a pipeline.DecodePool (decode in worker processes) or None (decode on `workers`
+    threads)."""
     if ranks is None or ranks.world == 1:
         for base_path in dirs:
             print(f"CLIPing {base_path}...")
@@ -57,27 +128,53 @@ def encode_directories(dirs, model, db, batch, workers, ranks=None, pool=None):
                 db.mark_skipped(bad)
                 print("." * len(ok) + "#" * len(bad), end="", flush=True)
             print(flush=True)
-        return
-    for base_path in dirs:
-        if ranks.leader:
-            print(f"CLIPing {base_path}...")
-        # the same sorted list on every rank (rank 0 is the only one that can see what is already stored)
-        todo = ranks.bcast(sorted(candidates(base_path, db)) if ranks.leader else None)
-        lo, hi = shard_bounds(len(todo), ranks.world, ranks.rank)
-        mine = pipeline.encode_files(model, todo[lo:hi], batch=batch, workers=workers, pool=pool)
-        # every rank walks the same number of rounds: the largest slice decides (slices differ by <= 1 file)
-        rounds = (shard_bounds(len(todo), ranks.world, 0)[1] + batch - 1) // batch
-        for _ in range(rounds):
-            got = next(mine, ([], None, []))
-            parts = ranks.gather(got)
+        return False
+    if ranks.leader:
+        ingest_shards(db, store_path)                 # finished work of a run that died before its ingest
+    ranks.barrier()
+    shard = vstore.VectorStore(shard_path(store_path, ranks.rank), dim=model.embed_dim, backend="packed")
+    stopped = False
+    seen = set()
+    try:
+        for base_path in dirs:
             if ranks.leader:
-                for ok, feats, bad in parts:           # rank order = sorted-list order: deterministic commits
-                    if ok:
-                        db.put_vectors(ok, feats)
-                    db.mark_skipped(bad)
-                    print("." * len(ok) + "#" * len(bad), end="", flush=True)
-        if ranks.leader:
-            print(flush=True)
+                print(f"CLIPing {base_path}...")
+            # the same sorted list on every rank (rank 0 is the only one that can see what is already stored)
+            todo = ranks.bcast(sorted(k for k in candidates(base_path, db) if k not in seen) if ranks.leader else None)
+            seen.update(todo)
+            lo, hi = shard_bounds(len(todo), ranks.world, ranks.rank)
+            mine = pipeline.encode_files(model, todo[lo:hi], batch=batch, workers=workers, pool=pool)
+            # every rank walks the same number of rounds: the largest slice decides (slices differ by <= 1 file)
+            rounds = (shard_bounds(len(todo), ranks.world, 0)[1] + batch - 1) // batch
+            for _ in range(rounds):
+                ok, feats, bad = [], None, []
+                if not (stop is not None and stop.set):
+                    try:
+                        ok, feats, bad = next(mine, ([], None, []))
+                    except KeyboardInterrupt:          # no StopFlag handler installed (not the main thread): same meaning
+                        if stop is not None:
+                            stop.set = True
+                        ok, feats, bad = [], None, []
+                if ok:
+                    shard.put_vectors(ok, feats)       # this rank's own shard: one commit per batch
+                shard.mark_skipped(bad)
+                flags = ranks.all_gather_ints([len(ok), len(bad), 1 if (stop is not None and stop.set) else 0])
+                if ranks.leader:
+                    print("".join("." * f[0] + "#" * f[1] for f in flags), end="", flush=True)   # rank order = list order
+                if any(f[2] for f in flags):
+                    stopped = True                     # every rank sees the same flags: all leave in this round
+                    break
+            mine.close()
+            if ranks.leader:
+                print(flush=True)
+            if stopped:
+                break
+    finally:
+        shard.close()
+    ranks.barrier()                                    # every shard is closed and on disk
+    if ranks.leader:
+        ingest_shards(db, store_path)
+    return stopped
 
 
 def finalise(db, device, out="images.index"):
@@ -120,9 +217,19 @@ def main(argv):
         model, _ = load(os.environ.get("CLIPMI_WEIGHTS", "ViT-B/32"), device=device, jit=False)
         model.eval()
         db = vstore.VectorStore("vectors.lmdb", dim=model.embed_dim) if ranks.leader else None
-        try:
-            encode_directories(argv, model, db, int(os.environ.get("CLIPMI_BATCH", "435")), workers, ranks, pool)
-        except KeyboardInterrupt:
+        batch = int(os.environ.get("CLIPMI_BATCH", "435"))
+        if ranks.world > 1:
+            # Ctrl-C reaches every rank of the launcher's process group at its own moment: the flag + the loop's per-round
+            # agreement make all of them stop in the same round; rank 0 still finalises (build-index.py:63-64)
+            with StopFlag() as stop:
+                interrupted = encode_directories(argv, model, db, batch, workers, ranks, pool, stop=stop)
+        else:
+            interrupted = False
+            try:
+                encode_directories(argv, model, db, batch, workers, ranks, pool)
+            except KeyboardInterrupt:
+                interrupted = True
+        if interrupted and ranks.leader:
             print("Interrupted!")
         if ranks.leader:
             finalise(db, device)

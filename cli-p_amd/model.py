@@ -143,16 +143,27 @@ class CLIP:
             text = torch.as_tensor(text)
         if text.dim() != 2 or text.shape[1] != self.context_length:
             raise ValueError(f"encode_text: expected [Q,{self.context_length}], got {tuple(text.shape)}")
+        # Causal attention: rows behind the EOT token (the pooled row = the first argmax of the ids, as upstream takes it)
+        # cannot reach it, so the tower runs on the first max(EOT) + 1 positions only - the same bits for a fraction of
+        # the rows (a typical prompt is ~10 tokens of the 77). Done when the ids are still on the host (the tokenizer's
+        # output, query-index.py:107): no device round trip is spent on finding the length.
+        tower, Lp = self.text, self.context_length
+        if text.device.type == "cpu" and text.numel():
+            Lp = min(self.context_length, int(text.argmax(dim=1).max()) + 1)
+            if Lp < self.context_length:
+                tower = type(self.text).from_buffer_copy(self.text)
+                tower.tokens = Lp
+                text = text[:, :Lp]
         ids = text.to(device=self.device, dtype=torch.int32).contiguous()
         Q = ids.shape[0]
         out = torch.empty((Q, self.embed_dim), dtype=torch.float32, device=self.device)
         for lo in range(0, Q, self.max_batch):
             hi = min(Q, lo + self.max_batch)
-            need = L.clipmi_encode_text_workspace_bytes(self.text, hi - lo)
+            need = L.clipmi_encode_text_workspace_bytes(tower, hi - lo)
             if need == 0:
                 raise _lib.ClipmiError("encode_text: " + _lib.last_error())
             ws = self._workspace(need, _lib.stream_ptr(self.device).value, "text")
-            rc = L.clipmi_encode_text(self.text, self._tblob.data_ptr(), ids[lo:hi].data_ptr(), hi - lo,
+            rc = L.clipmi_encode_text(tower, self._tblob.data_ptr(), ids[lo:hi].data_ptr(), hi - lo,
                                       out[lo:hi].data_ptr(), int(bool(normalize)), ws.data_ptr(), ws.numel(),
                                       _lib.stream_ptr(self.device))
             _lib.check(rc, "clipmi_encode_text")

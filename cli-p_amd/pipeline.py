@@ -46,13 +46,15 @@ class DecodePool:
 
     @staticmethod
     def shm_room():
-        """Bytes free for shared-memory segments (/dev/shm is a tmpfs whose pages exist only once written: a segment larger
-        than what is free is created without complaint and kills the writer later; containers default to 64 MB)."""
+        """Bytes of /dev/shm THIS process may count on for its segments (/dev/shm is a tmpfs whose pages exist only once
+        written: a segment larger than what is free is created without complaint and kills the writer later; containers
+        default to 64 MB). The ranks of one node all see the same free space before any of them has written a page, so
+        each takes its share: free / LOCAL_WORLD_SIZE."""
         import os
         try:
             st = os.statvfs("/dev/shm")
-            return st.f_bavail * st.f_frsize
-        except OSError:
+            return st.f_bavail * st.f_frsize // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+        except (OSError, ValueError):
             return 0
 
     def pin_segment(self, which):
@@ -116,8 +118,10 @@ class DecodePool:
         if p is not None:
             # the whole share in one write: this thread sleeps in read() while the worker decodes (one request per round
             # trip kept 16 parent threads busy handing the GIL around)
+            # the path travels hex-encoded: a file name may hold '\n' or '\t' (legal on Linux, and os.listdir returns them) -
+            # raw, such a name split into two request lines and shifted every later reply of the worker by one
             req = b"".join(b"%d\t%s\t%d\t%s\t%d\t%d\t" % (n_px, name, slot * per, bname, slot * bcap, bcap) +
-                           path.encode("utf-8", "surrogateescape") + b"\n" for slot, path in jobs)
+                           path.encode("utf-8", "surrogateescape").hex().encode() + b"\n" for slot, path in jobs)
             try:
                 p.stdin.write(req)
                 p.stdin.flush()

@@ -77,6 +77,18 @@ class Ranks:
         self.dist.gather_object(obj, out, dst=dst, group=self.ctl)
         return out
 
+    def all_gather_ints(self, vals):
+        """Every rank's short list of ints on every rank (rank order): ONE small gloo all-gather. The build loop's per-round
+        agreement (progress counts + "a rank was asked to stop") rides on it."""
+        vals = [int(v) for v in vals]
+        if self.world == 1:
+            return [vals]
+        import torch
+        mine = torch.tensor(vals, dtype=torch.int64)
+        out = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine, group=self.ctl)
+        return [o.tolist() for o in out]
+
     def barrier(self):
         if self.world > 1:
             self.dist.barrier(group=self.ctl)

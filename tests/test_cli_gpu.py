@@ -77,6 +77,13 @@ def _nccl_worker(tmp):
         D, I = sh.search(q, 51)
         Ds, Is = TopkOracle().topk(db, q, 51)
         ok = np.array_equal(I, Is) and np.array_equal(D.view(np.uint32), Ds.view(np.uint32))
+        # a caller holding two results keeps both (search_device used to hand out one reused buffer)
+        qa, qb = torch.from_numpy(q).cuda(), torch.from_numpy(q[::-1].copy()).cuda()
+        ra = sh.search_device(qa, 51)
+        rb = sh.search_device(qb, 51)
+        torch.cuda.synchronize()
+        ok = ok and ra[1].data_ptr() != rb[1].data_ptr() and np.array_equal(ra[1].cpu().numpy(), Is) and \
+            np.array_equal(rb[1].cpu().numpy(), Is[::-1])
         open(os.path.join(tmp, "ok"), "w").write("1" if ok else "0")
     finally:
         dist.destroy_process_group()
@@ -176,10 +183,11 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     assert r.returncode != 0 and '"error"' in r.stdout
 
 
-def test_pipeline_resize_on_device_gives_the_same_vectors(clipmi, gpu, tmp_path):
-    """encode_files with the resize on the device (full-size RGB images -> clipmi_resize_crop_rgb8) returns the vectors of
-    the all-host path bit for bit - the device computes the same pixels - for photo-sized, tall, small, already-sized,
-    grey, RGBA and broken files in one batch sequence."""
+def _resize_pipeline_worker(tmp):
+    """Own process, the PRODUCT's start order (indexer.main, bench.py): the decode workers are started BEFORE this process
+    touches the GPU; only then the model is built."""
+    sys.path.insert(0, ROOT)
+    import clipmi
     from PIL import Image
     rng = np.random.default_rng(21)
     specs = [(1024, 768, "RGB", "jpg"), (600, 900, "RGB", "jpg"), (224, 224, "RGB", "jpg"), (224, 400, "RGB", "png"),
@@ -189,15 +197,16 @@ def test_pipeline_resize_on_device_gives_the_same_vectors(clipmi, gpu, tmp_path)
     for i, (w, h, mode, ext) in enumerate(specs):
         ch = {"RGB": 3, "L": 1, "RGBA": 4}[mode]
         a = rng.integers(0, 256, (h, w, ch), dtype=np.uint8)
-        p = str(tmp_path / f"f{i:02d}.{ext}")
+        p = os.path.join(tmp, f"f{i:02d}.{ext}" if i != 1 else "f01 new\nline\tand tab.jpg")    # odd file names
         Image.fromarray(a[:, :, 0] if ch == 1 else a, mode).save(p)
         paths.append(p)
-    bad = str(tmp_path / "f99.jpg")
+    bad = os.path.join(tmp, "f99.jpg")
     with open(bad, "wb") as f:
         f.write(b"broken")
     files = paths[:4] + [bad] + paths[4:]
-    model = clipmi.CLIP(clipmi.weights.random_state_dict("ViT-B/32", seed=0), device=gpu)
-    with clipmi.pipeline.DecodePool(3) as pool:
+    with clipmi.pipeline.DecodePool(3) as pool:                     # before anything initialises the GPU
+        assert not torch.cuda.is_initialized()
+        model = clipmi.CLIP(clipmi.weights.random_state_dict("ViT-B/32", seed=0), device="cuda:0")
         host = list(clipmi.pipeline.encode_files(model, files, batch=4, pool=pool, device_resize_mb=0))
         devr = list(clipmi.pipeline.encode_files(model, files, batch=4, pool=pool, device_resize_mb=8))   # 3000x2000 stays on the host
         (_, _, _, full), _, _ = pool.decode(files[:4], 224, copy=False, full_cap=8 << 20)
@@ -206,3 +215,16 @@ def test_pipeline_resize_on_device_gives_the_same_vectors(clipmi, gpu, tmp_path)
     assert sum(len(h[0]) for h in host) == len(paths) and host[1][2] == [bad]
     for h, d in zip(host, devr):
         assert np.array_equal(h[1], d[1])
+    open(os.path.join(tmp, "ok"), "w").write("1")
+
+
+def test_pipeline_resize_on_device_gives_the_same_vectors(tmp_path):
+    """encode_files with the resize on the device (full-size RGB images -> clipmi_resize_crop_rgb8) returns the vectors of
+    the all-host path bit for bit - the device computes the same pixels - for photo-sized, tall, small, already-sized,
+    grey, RGBA and broken files in one batch sequence, incl. a file whose NAME holds a newline and a tab. Runs in its own
+    process with the product's start order (decode workers first, GPU second)."""
+    code = f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}); " \
+           f"import test_cli_gpu as t; t._resize_pipeline_worker({str(tmp_path)!r})"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert (tmp_path / "ok").read_text() == "1"

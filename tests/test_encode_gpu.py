@@ -174,8 +174,11 @@ def test_encode_text_rows_after_eot_are_ignored(clipmi, gpu):
     ids2 = ids.clone(); ids2[0, 6:] = 11
     b = model.encode_text(ids2).cpu()
     assert torch.equal(a[0], b[0])
-    # Q = 1 (the reference's query shape) equals row 0 of the batch
+    # Q = 1 (the reference's query shape) equals row 0 of the batch: host ids run the tower on EOT + 1 = 6 positions only and
+    # on the skinny GEMM kernel (M = 6 rows), device-resident ids on all 77 positions - the same bits either way
     assert torch.equal(model.encode_text(ids[:1]).cpu()[0], a[0])
+    assert torch.equal(model.encode_text(ids[:1].to(gpu)).cpu()[0], a[0])
+    assert torch.equal(model.encode_text(ids.to(gpu)).cpu(), a)
 
 
 def test_end_to_end_index_and_query(clipmi, gpu, topk_oracle):

@@ -203,18 +203,36 @@ def _make_photo_dir(d, n):
     open(os.path.join(d, "notes.txt"), "w").write("ignored")
 
 
-def _indexer_worker(rank, world, port, tmp):
+def _indexer_worker(rank, world, port, tmp, interrupt_rank=-1):
     sys.path.insert(0, ROOT)
     import clipmi
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.chdir(tmp)
     ranks = clipmi.ranks.Ranks("cpu", rank=rank, world=world, local=rank).init()
-    db = clipmi.store.VectorStore(os.path.join(tmp, "sharded.store"), dim=512, backend="packed") if ranks.leader else None
-    clipmi.indexer.encode_directories([os.path.join(tmp, "lib") + "/"], _FakeModel(), db, 4, 2, ranks)
+    store = os.path.join(tmp, "sharded.store")
+    db = clipmi.store.VectorStore(store, dim=512, backend="packed") if ranks.leader else None
+    model = _FakeModel()
+    if rank == interrupt_rank:
+        # Ctrl-C reaches THIS rank in the middle of its second batch: SIGINT to itself from inside the encoder
+        import signal
+        calls = [0]
+        enc = model.encode_image
+
+        def encode_image(x, normalize=False):
+            calls[0] += 1
+            if calls[0] == 2:
+                os.kill(os.getpid(), signal.SIGINT)
+            return enc(x, normalize=normalize)
+        model.encode_image = encode_image
+    with clipmi.indexer.StopFlag() as stop:
+        stopped = clipmi.indexer.encode_directories([os.path.join(tmp, "lib") + "/"], model, db, 4, 2, ranks, stop=stop,
+                                                    store_path=store)
+    assert stopped == (interrupt_rank >= 0)
     if ranks.leader:
         clipmi.indexer.finalise(db, "cpu", out=os.path.join(tmp, "sharded.index"))
         db.close()
+        open(os.path.join(tmp, "leader.done"), "w").write("stopped" if stopped else "complete")
     ranks.close()
 
 
@@ -237,6 +255,53 @@ def test_sharded_build_gloo_world2(clipmi, tmp_path, capsys):
     # a second sharded run finds nothing left to do (resume semantics, build-index.py:36-44)
     assert clipmi.indexer.candidates(os.path.join(tmp, "lib") + "/", db2) == []
     db1.close(); db2.close()
+    # every rank wrote its own shard store and rank 0 ingested + removed them
+    assert not [f for f in os.listdir(tmp) if ".shard-" in f]
+
+
+def test_sharded_build_ctrl_c_on_one_rank_gloo_world2(clipmi, tmp_path):
+    """ADVICE r02 (medium) / build-index.py:63-64: Ctrl-C that reaches ONE rank (rank 1, inside its second batch) must not
+    hang the others in a collective: the ranks agree on the round to stop in, rank 0 ingests what the shards hold and still
+    finalises. A second, uninterrupted run completes the library; the result equals the single-process build."""
+    import torch.multiprocessing as mp
+    tmp = str(tmp_path)
+    _make_photo_dir(os.path.join(tmp, "lib"), 23)
+    mp.spawn(_indexer_worker, args=(2, 29500 + (os.getpid() + 19) % 2000, tmp, 1), nprocs=2, join=True)
+    assert open(os.path.join(tmp, "leader.done")).read() == "stopped"
+    assert not [f for f in os.listdir(tmp) if ".shard-" in f]
+    db = clipmi.store.VectorStore(os.path.join(tmp, "sharded.store"), dim=512, backend="packed")
+    n_first = db.count()
+    assert 0 < n_first < 23 and os.path.exists(os.path.join(tmp, "sharded.index"))
+    assert clipmi.index.index_rows(os.path.join(tmp, "sharded.index")) == (n_first, 512)
+    db.close()
+    mp.spawn(_indexer_worker, args=(2, 29500 + (os.getpid() + 23) % 2000, tmp), nprocs=2, join=True)
+    assert open(os.path.join(tmp, "leader.done")).read() == "complete"
+    db1 = clipmi.store.VectorStore(os.path.join(tmp, "single.store"), dim=512, backend="packed")
+    clipmi.indexer.encode_directories([os.path.join(tmp, "lib") + "/"], _FakeModel(), db1, 4, 2)
+    clipmi.indexer.finalise(db1, "cpu", out=os.path.join(tmp, "single.index"))
+    db2 = clipmi.store.VectorStore(os.path.join(tmp, "sharded.store"), dim=512, backend="packed")
+    for t in ("fn_db", "skip_db", "idx_db"):
+        assert list(db1.b.items_sorted(t)) == list(db2.b.items_sorted(t)), t
+    assert open(os.path.join(tmp, "single.index"), "rb").read() == open(os.path.join(tmp, "sharded.index"), "rb").read()
+    db1.close(); db2.close()
+
+
+def test_leftover_shard_of_a_dead_run_is_ingested(clipmi, tmp_path):
+    """A run that died between its last batch and rank 0's ingest leaves `<store>.shard-<rank>` behind: finished work. The
+    next start ingests it before listing what is left to do."""
+    tmp = str(tmp_path)
+    store = os.path.join(tmp, "v.store")
+    sh = clipmi.store.VectorStore(clipmi.indexer.shard_path(store, 3), dim=512, backend="packed")
+    rng = np.random.default_rng(5)
+    vec = unit_rows(rng, 2, 512)
+    sh.put_vectors(["lib/a.png", "lib/b.png"], vec)
+    sh.mark_skipped(["lib/bad.jpg"])
+    sh.close()
+    db = clipmi.store.VectorStore(store, dim=512, backend="packed")
+    assert clipmi.indexer.ingest_shards(db, store) == 2
+    assert np.array_equal(db.get_vector("lib/b.png")[0], vec[1]) and db.is_skipped("lib/bad.jpg") and db.count() == 2
+    assert not os.path.exists(clipmi.indexer.shard_path(store, 3))
+    db.close()
 
 
 def _repl_worker(rank, world, port, tmp):

@@ -45,6 +45,30 @@ def test_gemm_epilogues(clipmi, gpu, M, N, K, epi):
     tol = 2e-4 * scale + (2.0 ** -8) * scale * (epi in (0, 1))
     err = (got - ref).abs().max().item()
     assert torch.isfinite(got).all() and err <= tol, f"M={M} N={N} K={K} epi={epi}: err {err} tol {tol}"
+    if M <= 128:
+        # M <= 128 runs on the skinny kernel (gemm_skinny.hpp: one wave per 16 x 16 outputs, no LDS): the same bits as the
+        # 128 x 128 tiled kernel (algo 1) - a row's result does not depend on how many rows travel with it
+        out1 = res.clone() if epi == 2 else torch.full_like(out, float("nan"))
+        clipmi._lib.check(L.clipmi_dbg_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), out1.data_ptr(), M, N, K,
+                                                 epi | (1 << 8), None), "gemm algo 1")
+        torch.cuda.synchronize()
+        assert torch.equal(out1, out), "skinny kernel differs from the tiled kernel's bits"
+
+
+@pytest.mark.parametrize("M,N,K", [(77, 1536, 512), (77, 512, 2048), (50, 768, 3072), (3, 2048, 512), (128, 528, 96)])
+def test_gemm_skinny_shapes(clipmi, gpu, M, N, K):
+    """The text tower's shapes for ONE prompt (query-index.py:108) and one image's, incl. N % 128 != 0 / K % 64 != 0,
+    which only the skinny kernel takes."""
+    L = clipmi._lib.lib()
+    g = torch.Generator(device="cpu"); g.manual_seed(M + N + K)
+    a = _bf16(torch.randn(M, K, generator=g)).to(gpu)
+    w = _bf16(torch.randn(N, K, generator=g) * K ** -0.5).to(gpu)
+    bias = torch.randn(N, generator=g).to(gpu)
+    ref = a.float() @ w.float().t() + bias
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=gpu)
+    clipmi._lib.check(L.clipmi_dbg_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, 3, None), "gemm")
+    torch.cuda.synchronize()
+    assert (out - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
 
 
 def test_gemm_layout_asymmetric(clipmi, gpu):
@@ -396,7 +420,7 @@ def test_gemm_resid_ln_producer(clipmi, gpu, M, N, K):
     hi0, lo0, _ = _split(clipmi, L, x0)
     xold = hi0.float() + lo0.float()
     res = {}
-    for algo in (1, 2, 3):
+    for algo in (0, 1, 2, 3):           # 0: the shape's own choice (M <= 128: the skinny kernel + split_stats)
         buf = torch.empty(2, M, N, dtype=torch.bfloat16, device=gpu)
         buf[0].copy_(hi0); buf[1].copy_(lo0)
         part = torch.full((M, N // 256, 2), float("nan"), dtype=torch.float32, device=gpu)
@@ -413,7 +437,7 @@ def test_gemm_resid_ln_producer(clipmi, gpu, M, N, K):
     assert torch.equal(lo3, (new - hi3.float()).to(torch.bfloat16)) or (lo3.float() - (new - hi3.float())).abs().max().item() < 1e-6
     xs = new.double().reshape(M, N // 256, 256)
     assert (part3[..., 0].double() - xs.sum(-1)).abs().max().item() <= 1e-4 * xs.abs().sum(-1).max().item()
-    for algo in (1, 2):
+    for algo in (0, 1, 2):
         for got, want, what in zip(res[algo], res[3], ("hi", "lo", "part")):
             assert torch.equal(got, want), f"algo {algo} vs the fused store pass: {what} differs"
 

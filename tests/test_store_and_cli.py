@@ -98,6 +98,10 @@ def test_decode_pool_matches_in_process_decode(clipmi, tmp_path):
         p = str(tmp_path / f"img_{i}.{ext}")
         Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(p)
         paths.append(p)
+    # a file NAME with a newline and a tab (legal on Linux): the request protocol must not split on it
+    odd = str(tmp_path / "img 5 new\nline\ttab.png")
+    Image.fromarray(rng.integers(0, 256, (64, 80, 3), dtype=np.uint8)).save(odd)
+    paths.append(odd)
     bad = str(tmp_path / "broken.jpg")
     with open(bad, "wb") as f:
         f.write(b"not an image")
@@ -105,11 +109,11 @@ def test_decode_pool_matches_in_process_decode(clipmi, tmp_path):
     with clipmi.pipeline.DecodePool(3) as pool:
         arr, ok, failed = pool.decode(mixed, 224)
         assert ok == paths and failed == [bad, mixed[-1]]
-        assert arr.shape == (5, 3, 224, 224) and arr.dtype == np.uint8
+        assert arr.shape == (6, 3, 224, 224) and arr.dtype == np.uint8
         for a, p in zip(arr, paths):
             assert np.array_equal(a, clipmi.pipeline.load_uint8(p, 224))
         arr2, ok2, _ = pool.decode(paths[::-1], 224)                       # the segment is reused; order follows the call
-        assert ok2 == paths[::-1] and np.array_equal(arr2[0], arr[4])
+        assert ok2 == paths[::-1] and np.array_equal(arr2[0], arr[5])
         got = list(clipmi.pipeline.encode_files(_StubModel(), mixed, batch=3, workers=2, pool=pool))
         # a worker that dies (a file that crashes the decoder, an OOM kill) costs at most the file it was on: its share is
         # decoded in-process from then on, nothing is spawned

@@ -395,8 +395,9 @@ def test_two_search_batches_in_flight_on_two_streams(clipmi, gpu, topk_oracle):
 
 @pytest.mark.parametrize("kind", ["int8", "bf16"])
 def test_large_query_batch_is_pipelined_and_exact(clipmi, gpu, topk_oracle, kind):
-    """A search of more than 64 queries runs its 64-query passes alternately on the caller's stream and an internal one
-    (index.py _search_pipelined): the oracle's bits, the same bits as the one-stream form, and usable back to back."""
+    """A search of more than 64 queries: the bf16 path runs its 64-query passes alternately on the caller's stream and an
+    internal one (index.py _search_pipelined); the int8 path takes the whole search as wide passes inside the library (one
+    stream). Either way: the oracle's bits, the same bits with batches_in_flight = 1, and usable back to back."""
     rng = np.random.default_rng(4242)
     N, Q, K = 90_000, 200, 51
     db = unit_rows(rng, N, 512)
@@ -407,7 +408,10 @@ def test_large_query_batch_is_pipelined_and_exact(clipmi, gpu, topk_oracle, kind
     assert idx.batches_in_flight == 2
     outs = [idx.search_device(tq, K) for _ in range(3)]
     outs = [(s.clone(), i.clone()) for s, i in outs]
-    assert len(idx._side_streams) == 1 and len(idx._ws) >= 2
+    if kind == "bf16":
+        assert len(idx._side_streams) == 1 and len(idx._ws) >= 2
+    else:
+        assert not hasattr(idx, "_side_streams") and len(idx._ws) == 1
     idx.batches_in_flight = 1
     s1, i1 = idx.search_device(tq, K)
     torch.cuda.synchronize()
@@ -588,5 +592,29 @@ def test_full_size_10m_properties(clipmi, gpu, topk_oracle, N):
         sh.add(db[lo:hi]); sh.id_base = lo
         s_, i_ = sh.search(q, K)
         parts_s.append(s_); parts_i.append(i_)
+    # the merge the product runs after its ONE all-gather: every shard's packed record [scores | pad | ids] side by side
+    # (what all_gather_into_tensor produces), merged by clipmi_merge_topk_packed - and the oracle's merge beside it
+    ids_off = (Q * K * 4 + 7) // 8 * 8
+    rec_bytes = ids_off + Q * K * 8
+    gath = torch.zeros(8 * rec_bytes, dtype=torch.uint8, device=gpu)
+    for r in range(8):
+        gath[r * rec_bytes:r * rec_bytes + Q * K * 4] = torch.from_numpy(parts_s[r].reshape(-1).view(np.uint8).copy()).to(gpu)
+        gath[r * rec_bytes + ids_off:(r + 1) * rec_bytes] = torch.from_numpy(parts_i[r].reshape(-1).view(np.uint8).copy()).to(gpu)
+    out_s = torch.empty((Q, K), dtype=torch.float32, device=gpu)
+    out_i = torch.empty((Q, K), dtype=torch.int64, device=gpu)
+    L = clipmi._lib.lib()
+    clipmi._lib.check(L.clipmi_merge_topk_packed(gath.data_ptr(), rec_bytes, 8, Q, K, out_s.data_ptr(), out_i.data_ptr(), None),
+                      "merge_topk_packed")
+    _assert_exact(out_s.cpu().numpy(), out_i.cpu().numpy(), De, Ie, "8 shards + clipmi_merge_topk_packed vs single at 10M")
     Ms, Mi = topk_oracle.merge(np.stack(parts_s), np.stack(parts_i), K)
-    _assert_exact(Ms, Mi, De, Ie, "8 shards + merge vs single at 10M")
+    _assert_exact(Ms, Mi, De, Ie, "8 shards + oracle merge vs single at 10M")
+    # ONE call of 1024 queries at full size: the wide pass against the 64 queries above (same first 64 rows of the batch) and
+    # against the exact f32 scan on a sample of the rest
+    qw = torch.cat([q, torch.randn((960, 512), generator=g, device=gpu)])
+    qw[64:] = qw[64:] / qw[64:].norm(dim=1, keepdim=True)
+    wide = clipmi.IndexFlatIP(512, device=gpu, coarse="int8"); wide.add(db)
+    Dw, Iw = wide.search(qw, K)
+    _assert_exact(Dw[:64], Iw[:64], De, Ie, "wide pass (Q = 1024) vs exact at full size, first 64 queries")
+    pick = torch.arange(64, 1024, 31, device=gpu)[:32]
+    Dx, Ix = exact.search(qw[pick], K)
+    _assert_exact(Dw[pick.cpu().numpy()], Iw[pick.cpu().numpy()], Dx, Ix, "wide pass (Q = 1024) vs exact at full size, 32 more")
