@@ -426,6 +426,19 @@ def search_leg(L, a, dev, dist, world, rank, rows_total, n_local, seed, steps, w
                                    "frac": ops / (ms_call * 1e-3) / 1e12 / (2 * PEAK_BF16_TFLOPS),
                                    "note": "whole call (sample, scans, exact re-scoring, selects) over the scan's operations"}},
             **sp_big)
+    if large_q > 0:
+        sweep = {}
+        for Qs in (1, 16):
+            qs_ = q[:Qs].contiguous()
+
+            def sweep_step():
+                res[0] = searcher.search_device(qs_, K)
+            dts = timed(sweep_step, 10, 2, dist, world)
+            sweep[str(Qs)] = round(Qs * 10 / dts, 1)
+        sweep[str(Q)] = round(Q * steps / dt_one, 1)
+        if "one_call_many_queries" in out:
+            sweep[str(large_q)] = round(out["one_call_many_queries"]["value"], 1)
+        out["sweep_by_queries"] = sweep              # one call in flight each: the latency view (queries/s = Q / call time)
     del searcher, idx, db
     torch.cuda.empty_cache()
     return out
@@ -500,6 +513,39 @@ def main():
                     "min_cosine_to_bf16_path": float(cos.min()), **sp8,
                     "note": "BASELINE.json configs[4] parity case; not the headline (configs[1] is bf16)"}
         del model8
+
+    # SURVEY.md 8(d) cfg-2 sweep: images/s at B in {64, 128, 256, 512} (compact: 10 synchronised steps each), beside the
+    # headline's B - the number a caller gets without knowing which batch sizes fill whole rounds of GEMM tiles
+    enc_sweep = None
+    if not a.quick:
+        enc_sweep = {}
+        for Bs in (64, 128, 256, 512):
+            imgs_s = images[:Bs] if Bs <= B else torch.randint(0, 256, (Bs, 3, 224, 224), generator=g, device=dev, dtype=torch.uint8)
+
+            def sweep_step():
+                enc_out[0] = model.encode_image(imgs_s, normalize=True)
+            dts = timed(sweep_step, 10, 2, dist, world)
+            enc_sweep[str(Bs)] = round(world * Bs * 10 / dts, 1)
+
+    # ONE prompt through the text tower (the REPL's shape: query-index.py:107-108, Q = 1): latency per query, host ids as the
+    # tokenizer hands them over (EOT at position 9: the tower runs on 10 positions, skinny GEMM kernels), beside the CPU
+    # baseline's text_encode_ms_per_query
+    text_one = None
+    if not a.quick:
+        ids1 = torch.zeros(1, 77, dtype=torch.int64)
+        ids1[0, 0] = 49406; ids1[0, 1:9] = torch.randint(1, 40000, (8,)); ids1[0, 9] = 49407
+        ids77 = ids1.clone(); ids77[0, 9] = 5; ids77[0, 76] = 49407
+
+        def text_step():
+            enc_out[0] = model.encode_text(ids1, normalize=True)
+
+        def text_step77():
+            enc_out[0] = model.encode_text(ids77, normalize=True)
+        dt_t = timed(text_step, 100, 5, dist, world)
+        dt_t77 = timed(text_step77, 100, 5, dist, world)
+        text_one = {"ms_per_query": dt_t / 100 * 1e3, "ms_per_query_full_77_tokens": dt_t77 / 100 * 1e3, "queries": 1,
+                    "what": "encode_text + normalise of ONE prompt, back-to-back calls on one stream (10 tokens incl. SOT / EOT; "
+                            "and a prompt that fills all 77 positions)"}
 
     # dominant encode kernel (MLP c_fc GEMM + bias + QuickGELU, 12 launches per step), timed IN SITU:
     # HIP events recorded by the library around each of its launches on the launch stream
@@ -595,6 +641,11 @@ def main():
                      "whole_step_frac": FLOP_PER_IMAGE * B * a.steps / dt_enc / 1e12 / PEAK_BF16_TFLOPS},
         "search": search,
     }
+    if text_one is not None:
+        out["encode_text_one_prompt"] = text_one
+    if enc_sweep is not None:
+        out["sweeps"] = {"encode_images_per_s_by_batch": enc_sweep,
+                         "search_queries_per_s_by_queries": search.pop("sweep_by_queries", None)}
     if sustained is not None:
         out["encode_sustained"] = sustained
     if fp8_info is not None:

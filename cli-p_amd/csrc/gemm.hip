@@ -99,6 +99,11 @@ static int launch_epi256p(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
 // other kernel writes acc + bias as f32 into g.tmp_f32 and split_stats_kernel (add form) does the rest in one
 // LayerNorm-sized pass. Both give the same bits (same adds in the same order, canonical statistics: gemm.hpp).
 
+static bool split_mode() {      // CLIPMI_GEMM_SPLIT=0: no whole-rounds + remainder split (A/B aid)
+    static const bool on = [] { const char* e = getenv("CLIPMI_GEMM_SPLIT"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
 // skinny kernel (gemm_skinny.hpp): M <= 128 rows, one wave per 16 columns x 16 rows
 static bool skinny_ok(const GemmArgs& g) {
     static const bool off = [] { const char* e = getenv("CLIPMI_GEMM_SKINNY"); return e && atoi(e) == 0; }();   // A/B aid
@@ -165,6 +170,34 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmP
         //  the other kernels need behind them; CLIPMI_GEMM_PERSIST=2 keeps the old rule for A/B runs)
         use256p = use256 && ok256p && persist_mode() != 0 &&
                   (tiles > NUM_CU || (epi == EPI_BIAS_RESID_LN_F32 && persist_mode() != 2));
+        // A ragged last round (M = 25600 at N = 768: 300 tiles = 1.17 rounds; 78 k images/s at B = 512 against 102 k at 435 /
+        // 870): the rows that fill WHOLE rounds of 256 x 256 tiles go to the persistent kernel, the remaining row tiles to
+        // whatever the rule picks for them alone (128 x 128 tiles: a quarter of a big tile's time per round), instead of the
+        // whole GEMM falling back. Same bits either way (every kernel's rows are independent and bit-identical). Not for the
+        // patch GEMM (its epilogue maps the absolute row number).
+        if (!use256 && ok256p && persist_mode() != 0 && tiles > NUM_CU && epi != EPI_PATCH_F32 && split_mode()) {
+            const int ntn = g.N / 256;
+            const long long main_tiles = (tiles / NUM_CU) * NUM_CU;          // whole rounds
+            const int rows_main = (int)(main_tiles / ntn) * 256;             // < M: the last round was ragged
+            if (rows_main >= 256 && rows_main < g.M) {
+                GemmArgs a = g, b = g;
+                a.M = rows_main;
+                b.M = g.M - rows_main;
+                b.A = g.A + (size_t)rows_main * g.K;
+                const size_t oe = (size_t)rows_main * g.N;
+                if (epi == EPI_BIAS_RESID_LN_F32) {
+                    b.xhi = g.xhi + oe; b.xlo = g.xlo + oe; b.tmp_f32 = g.tmp_f32 + oe;
+                    b.ln_part = g.ln_part + (size_t)rows_main * (g.N / 256) * 2;
+                } else if (epi_is_bf16_out(epi)) {
+                    b.out = static_cast<unsigned short*>(g.out) + oe;
+                } else {
+                    b.out = static_cast<float*>(g.out) + oe;
+                }
+                if (b.ln_part_in) b.ln_part_in = g.ln_part_in + (size_t)rows_main * (g.K / 256) * 2;
+                if (int rc = launch_gemm_algo(a, epi, 3, st, probe)) return rc;
+                return launch_gemm_algo(b, epi, 0, st, probe);
+            }
+        }
     }
     if (g.M < 1 || !g.A || !g.W || (!g.out && epi != EPI_BIAS_RESID_LN_F32)) return set_err(CLIPMI_EINVAL, "gemm: bad arguments");
     // a handful of rows (one prompt, one image): the skinny kernel, whatever the epilogue (the residual producer as

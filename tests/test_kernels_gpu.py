@@ -18,7 +18,8 @@ def _qgelu(x):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1, 128, 64), (200, 256, 128), (77, 512, 512),
-                                   (6400, 768, 768), (6401, 2304, 768), (1000, 768, 3072), (196, 768, 3072)])
+                                   (6400, 768, 768), (6401, 2304, 768), (1000, 768, 3072), (196, 768, 3072),
+                                   (25600, 768, 768)])           # 300 tiles of 256 x 256 = 1.17 rounds: whole rounds + remainder
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_gemm_epilogues(clipmi, gpu, M, N, K, epi):
     L = clipmi._lib.lib()
@@ -370,7 +371,7 @@ def test_split_stats(clipmi, gpu, M, W):
 
 
 @pytest.mark.parametrize("M,W,N", [(1, 768, 2304), (77, 512, 1536), (6400, 768, 3072), (6401, 768, 2304), (300, 1024, 4096),
-                                   (70000, 768, 2304), (30000, 1024, 3072)])
+                                   (70000, 768, 2304), (30000, 1024, 3072), (25601, 768, 768)])
 @pytest.mark.parametrize("epi", [5, 6])
 def test_gemm_ln_folded_consumer(clipmi, gpu, M, W, N, epi):
     """out = [quick_gelu](LayerNorm(x; gamma, beta) W^T + bias) through split_stats + the LN-folded epilogue with the
@@ -405,7 +406,7 @@ def test_gemm_ln_folded_consumer(clipmi, gpu, M, W, N, epi):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 768, 768), (300, 512, 2048), (6400, 768, 768), (6401, 768, 3072), (70000, 768, 768),
-                                   (43500, 768, 3072), (1000, 1024, 1024)])
+                                   (43500, 768, 3072), (1000, 1024, 1024), (25600, 768, 768), (25601, 768, 3072)])
 def test_gemm_resid_ln_producer(clipmi, gpu, M, N, K):
     """(hi, lo) += a W^T + bias with the statistics partials of the new rows: the persistent kernel's fused store pass
     (algo 3) and GEMM-into-scratch + split_stats (algos 1, 2) give identical bits in all three outputs; the new rows
