@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--l14-batch", type=int, default=266, help="images per step of the ViT-L/14@336px leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp8", action="store_true", help="skip the FP8 (configs[4]) encode measurement")
+    ap.add_argument("--large-q", type=int, default=-1,
+                    help="queries of the one-call-many-queries leg (default 1024; 0 = skip; --quick skips it unless given)")
     ap.add_argument("--quick", action="store_true",
                     help="headline encode + search only: no sustained / fp8 / ViT-L / shard legs, no CPU baseline "
                          "(profiling passes and tests)")
@@ -76,6 +78,8 @@ def parse():
     if a.quick:
         a.sustained_images = a.shard_rows = a.l14_batch = 0
         a.no_cpu_baseline = a.no_fp8 = True
+    if a.large_q < 0:
+        a.large_q = 0 if a.quick else 1024
     return a
 
 
@@ -602,7 +606,7 @@ def main():
 
     # ---------------- search: 10M x 512 f32 split over the ranks, Q queries, K = k + 1 -----------
     lo, hi = clipmi.shard_bounds(a.rows, world, rank)
-    search = search_leg(L, a, dev, dist, world, rank, a.rows, hi - lo, 1000, a.steps, a.warmup, large_q=0 if a.quick else 1024)
+    search = search_leg(L, a, dev, dist, world, rank, a.rows, hi - lo, 1000, a.steps, a.warmup, large_q=a.large_q)
     search["metric"] = f"queries/sec top-{a.k} over {a.rows}x512 flat IP (exact results, f32 scores)"
     search["scaling"] = "strong"
     # configs[4] search half: 12.5 M rows on every rank (weak): at N = 8 a 100 M x 512 DB

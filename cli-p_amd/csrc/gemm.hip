@@ -99,9 +99,9 @@ static int launch_epi256p(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
 // other kernel writes acc + bias as f32 into g.tmp_f32 and split_stats_kernel (add form) does the rest in one
 // LayerNorm-sized pass. Both give the same bits (same adds in the same order, canonical statistics: gemm.hpp).
 
-static bool split_mode() {      // CLIPMI_GEMM_SPLIT=0: no whole-rounds + remainder split (A/B aid)
-    static const bool on = [] { const char* e = getenv("CLIPMI_GEMM_SPLIT"); return !(e && atoi(e) == 0); }();
-    return on;
+static int split_pct() {        // CLIPMI_GEMM_SPLIT=<pct>: split off the last round when it is less than pct % full (0: never)
+    static const int pct = [] { const char* e = getenv("CLIPMI_GEMM_SPLIT"); return e ? atoi(e) : 40; }();
+    return pct;
 }
 
 // skinny kernel (gemm_skinny.hpp): M <= 128 rows, one wave per 16 columns x 16 rows
@@ -175,7 +175,8 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmP
         // whatever the rule picks for them alone (128 x 128 tiles: a quarter of a big tile's time per round), instead of the
         // whole GEMM falling back. Same bits either way (every kernel's rows are independent and bit-identical). Not for the
         // patch GEMM (its epilogue maps the absolute row number).
-        if (!use256 && ok256p && persist_mode() != 0 && tiles > NUM_CU && epi != EPI_PATCH_F32 && split_mode()) {
+        if (ok256p && persist_mode() != 0 && tiles > NUM_CU && epi != EPI_PATCH_F32 && (tiles % NUM_CU) != 0 &&
+            (tiles % NUM_CU) * 100 < (long long)NUM_CU * split_pct()) {
             const int ntn = g.N / 256;
             const long long main_tiles = (tiles / NUM_CU) * NUM_CU;          // whole rounds
             const int rows_main = (int)(main_tiles / ntn) * 256;             // < M: the last round was ragged

@@ -22,6 +22,7 @@ LABELS = (
     ("scan_coarse", r"scan_coarse_kernel<512, 4, false, false>"),
     ("scan_coarse_i8", r"scan_coarse_kernel<512, 4, false, true>"),          # the last segment (75 % of the rows)
     ("scan_coarse_i8_pre", r"scan_coarse_kernel<512, 4, true, true>"),       # the two earlier segments of the same pass
+    ("scan_wide", r"scan_coarse_wide_kernel<8, 0>"),                          # wide pass (Q > 64): all its segments averaged
     ("rescore", r"rescore_pairs_kernel"),
     ("gemm_c_fc", r"gemm256p_bf16_nt_kernel<(1|6), ?false>"),
     ("gemm_qkv", r"gemm256p_bf16_nt_kernel<(0|5), ?false>"),
@@ -32,7 +33,7 @@ LABELS = (
     ("layernorm", r"layernorm_kernel"),
     ("split_stats", r"split_stats_kernel"),
 )
-OPTIONAL = {"scan", "scan_coarse", "scan_coarse_i8_pre", "gemm128_c_fc", "gemm128_resid", "layernorm", "split_stats"}   # not on every bench path
+OPTIONAL = {"scan", "scan_coarse", "scan_coarse_i8_pre", "scan_wide", "gemm128_c_fc", "gemm128_resid", "layernorm", "split_stats"}   # not on every bench path
 
 
 def per_kernel(d, counter):
