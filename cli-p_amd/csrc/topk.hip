@@ -1846,9 +1846,14 @@ int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta,
         long long S1 = p.stage < 4096 ? 4096 : (p.stage / 16) * 16;
         if (S1 > 12288) S1 = 12288;
         {
+            // grid.y = 16-query groups (up to 64): blocks of the same x read the same rows, and every block first copies a
+            // 32-KiB query image - so few, fat blocks per group (each wave 4+ row tiles) once the groups alone fill the chip
             long long gs = ((S1 + 15) / 16 + 3) / 4;
             if (gs > NUM_CU) gs = NUM_CU;
-            hipLaunchKernelGGL(sample_scores_kernel<512>, dim3((unsigned)gs, (unsigned)((qc + 15) / 16)), dim3(256), lds1, st,
+            const int ngroups = (qc + 15) / 16;
+            static const int sdiv = [] { const char* e = getenv("CLIPMI_WIDE_SAMPLE_DIV"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
+            if (ngroups >= 8 && gs > sdiv) gs = (gs + sdiv - 1) / sdiv;
+            hipLaunchKernelGGL(sample_scores_kernel<512>, dim3((unsigned)gs, (unsigned)ngroups), dim3(256), lds1, st,
                                static_cast<const float*>(db_dev), S1, qg, qc, w.cand_c, (long long)WIDE_CAP, w.gcnt_c);
             CLIPMI_CHECK_LAUNCH("sample_scores_kernel(wide)");
             hipLaunchKernelGGL(select_topk_kernel, dim3(qc), dim3(SEL_THREADS), p.lds_sel, st, w.cand_c, w.gcnt_c, WIDE_CAP, K,
