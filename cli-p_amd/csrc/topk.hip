@@ -15,6 +15,7 @@
 //     a beats b  <=>  a.score > b.score || (a.score == b.score && a.id < b.id); NaN never selected.
 #include "common.hpp"
 #include <float.h>
+#include <math.h>
 #include <stdlib.h>
 #include <type_traits>
 #include <hip/hip_ext.h>
@@ -1711,6 +1712,18 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
         float* os_final = out_score_dev + (size_t)q0 * K;
         long long* oi_final = (long long*)out_id_dev + (size_t)q0 * K;
         long long r_done = 0;
+        // development knob: CLIPMI_COARSE_SEGS=n (>= 4): n geometric segments from 64 k rows, as the wide pass plans them
+        static const int nseg_env = [] { const char* e = getenv("CLIPMI_COARSE_SEGS"); return e ? atoi(e) : 0; }();
+        if (two_level && nseg_env >= 4 && N >= (1 << 20)) {
+            long long b = 65536;
+            const double ratio = pow((double)N / 65536.0, 1.0 / (nseg_env - 1));
+            for (int sgi = 0; sgi + 1 < nseg_env; ++sgi) {
+                const long long r1 = b & ~31ll;
+                if (int rc = coarse_pass(r_done, r1, true, w.thr0, nullptr, nullptr, 0, nullptr, w.last_m, sgi ? 3 : 1)) return rc;
+                r_done = r1;
+                b = (long long)(b * ratio);
+            }
+        } else
         if (two_level) {
             if (int rc = coarse_pass(0, S2, true, w.thr0, nullptr, nullptr, 0, scan_ev ? scan_ev + 2 : nullptr, w.last_m, 1)) return rc;
             r_done = S2;
