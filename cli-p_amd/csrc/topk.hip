@@ -385,7 +385,8 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
                                                                  long long* out_i, float* thr_out,
                                                                  const unsigned* run_if, unsigned* m_out = nullptr,
                                                                  int keep = 0, int stage_cap = -1, float* qmeta = nullptr,
-                                                                 int qs = 64) {
+                                                                 int qs = 64, unsigned* live_keys = nullptr,
+                                                                 float* live_edges = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (run_if && *run_if == 0) return;
     unsigned long long* red = reinterpret_cast<unsigned long long*>(smem);   // [16] min, [16] max
@@ -510,6 +511,10 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
                 out_i[(size_t)q * K + rank] = id_base + (long long)me.y;
             }
             if (thr_out && rank == K - 1) thr_out[q] = __uint_as_float(me.x);
+            if (live_keys) {                                   // the sample's best and K-th best: the live scan's ladder
+                if (rank == 0) ctl[5] = me.x;
+                if (rank == K - 1) ctl[6] = me.x;
+            }
             // coarse search: the next segment's scan threshold, (tau - margin) / t_q (coarse_prep_kernel's qmeta)
             if (qmeta && rank == K - 1) qmeta[2 * qs + q] = (__uint_as_float(me.x) - qmeta[3 * qs + q]) * qmeta[q];
         }
@@ -523,6 +528,27 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
     };
     if (staged) passes([&](long long e) -> uint2 { return lent[e]; });
     else passes([&](long long e) -> uint2 { return src[e]; });
+    if (live_keys) {
+        // live-threshold scan (scan_coarse_live_kernel): exact threshold = the sample's K-th best, ladder of LIVE_NB edges
+        // above it in steps of an eighth of the sample top-K's spread; with fewer than K sample rows nothing is filtered
+        __syncthreads();
+        if (tid == 0) {
+            float e0 = -FLT_MAX, dl = 1.0f, tex = -INFINITY, tsc = -INFINITY;
+            const float best = need >= K ? __uint_as_float(ctl[5]) : 0.f, kth = need >= K ? __uint_as_float(ctl[6]) : 0.f;
+            if (need >= K && fabsf(best) < FLT_MAX && fabsf(kth) < FLT_MAX) {      // finite (NaN compares false)
+                e0 = kth;
+                dl = (best - kth) * 0.125f;
+                const float floor_ = fabsf(kth) * 1e-6f + 1e-12f;
+                if (!(dl > floor_)) dl = floor_;
+                tex = kth;
+                tsc = (kth - qmeta[3 * qs + q]) * qmeta[q];
+            }
+            live_keys[q] = ((__float_as_uint(tsc) & 0x80000000u) ? ~__float_as_uint(tsc) : (__float_as_uint(tsc) | 0x80000000u));
+            live_keys[64 + q] = ((__float_as_uint(tex) & 0x80000000u) ? ~__float_as_uint(tex) : (__float_as_uint(tex) | 0x80000000u));
+            live_edges[q] = e0;
+            live_edges[64 + q] = dl;
+        }
+    }
     // leave the counter zeroed for the next scan of this call (every thread read M at entry; the
     // barriers above order that read before this store) — saves a memset node per scan
     // keep = 1 (segmented coarse scan): the K selected entries stay at the head of the list and the next segment's
@@ -1105,6 +1131,409 @@ __global__ void __launch_bounds__(256) rescore_pairs_kernel(const float* __restr
 }
 
 // =================================================================================================
+// Live-threshold scan (int8 copy, <= 64 queries): ONE launch over all rows, exact re-scoring INSIDE the scan.
+//
+// The segmented form above re-scores and selects between launches: 13 launches per call, ~250 us of latency-bound side
+// kernels beside 0.88 ms of scans at 10 M rows, and 5.8 k exactly re-scored rows per query because a segment's threshold
+// is frozen at its start. Here a workgroup is 4 SCANNER waves (the loop of scan_coarse_kernel) + 4 RE-SCORING waves.
+// Scanners push the pairs that pass the coarse test into a ring in LDS and never wait for anything else; re-scoring waves
+// pop them, drop what a since-risen threshold has made stale (the pair carries its coarse upper bound), gather row and
+// query from global memory, run the score-order fmaf chain (the SAME bits as rescore_pairs_kernel and the oracle), and
+// append (exact score, row) to the query's global candidate list when it reaches the query's exact threshold.
+// Thresholds rise DURING the scan through a per-query ladder in global memory: NB buckets of exact scores above the
+// sample's K-th best (edge_b = e0 + b delta, delta = an eighth of the sample top-K's spread); a re-scored row bumps its
+// bucket, and whoever bumps re-reads the query's 32 counters: the highest edge with >= K rows at or above it IS a lower
+// bound of the final K-th best (K rows score at least that), published with atomicMax as an order-preserving key - the
+// exact threshold for the re-scoring waves, (edge - margin) / t_q for the scanners, who re-read their 64 keys every step.
+// Exactness never depends on the ladder's timing: every published threshold is a valid lower bound, a true top-K row
+// passes the coarse test against any of them and its exact score reaches any of them.
+// Every spin is bounded (a wave that waits too long sets the overflow flag = the exact fallback answers, still exact).
+// =================================================================================================
+constexpr int LIVE_NB = 32;                      // ladder buckets per query
+constexpr int LIVE_QN = 4096;                    // ring entries (32 KiB)
+constexpr unsigned LIVE_EMPTY = 0xffffffffu;
+constexpr int LIVE_ROW_BITS = 26;                // ring entry .y = (query << 26) | row: shards of < 2^26 rows
+constexpr int LIVE_RS = 36;                      // floats per staged 32-float piece (+ 4 pad: conflict-free ds_read_b128)
+constexpr int LIVE_SPIN_LIMIT = 1 << 20;         // polls before a waiting lane gives up (~ tens of ms): overflow -> fallback
+
+__device__ __forceinline__ unsigned fkey(float f) {             // order-preserving key of a float (-0 and +0 differ: harmless)
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+struct LiveArgs {
+    const signed char* dbc;      // int8 copy (32-row blocks)
+    const float2* rmeta;         // per row (block scale, error norm)
+    const float* db;             // f32 [N][512]
+    const float* q;              // f32 [QA][512]
+    const float* qmeta;          // [4][64]: 1/t | Y/t | (unused here) | margin
+    const uint4* qimage;         // 16x16x64 image of the queries (coarse_prep_kernel)
+    long long nrows;             // rows [0, nrows)
+    int QA, K;
+    unsigned* tau_key;           // [64] key of the scaled coarse threshold (live)
+    unsigned* tex_key;           // [64] key of the exact threshold (live)
+    const float* edge0;          // [64] ladder origin = the sample's exact K-th best
+    const float* delta;          // [64] ladder step > 0
+    unsigned* hist;              // [64][LIVE_NB]
+    uint2* cand;                 // [QA][cap] (exact score bits, row)
+    unsigned* gcnt;              // [64]
+    long long cap;
+    unsigned* overflow;
+    unsigned* stats;             // [12] pushed | push spins | popped | stale | re-scored | inserted | batches | ladder rises
+};
+
+template <int QG>
+__global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int E = 512, KS = E / 64, ROWB = E, SLOTS = 2 * KS, NIMG = QG * KS * 64, IMG_BYTES = NIMG * 16;
+    constexpr int NSCAN = 4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, g = lane >> 4;
+
+    uint4* qimg = reinterpret_cast<uint4*>(smem);
+    for (int base = tid; base < NIMG; base += 512) qimg[base] = a.qimage[base];
+    uint2* ring = reinterpret_cast<uint2*>(smem + IMG_BYTES);                      // [LIVE_QN]
+    int* ctl = reinterpret_cast<int*>(ring + LIVE_QN);                             // [0] tail, [1] head, [2] scanners done, [3] abort
+    float* lstage = reinterpret_cast<float*>(ctl + 16);                            // re-scoring waves: [4][rows | queries][64][LIVE_RS]
+    for (int i = tid; i < LIVE_QN; i += 512) ring[i] = make_uint2(0u, LIVE_EMPTY);
+    if (tid < 4) ctl[tid] = 0;
+    __syncthreads();
+
+    if (wave < NSCAN) {
+        // ------------------------------------------------------------------ scanner
+        bool active[QG];
+        float tau[QG], yt[QG];
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) {
+            active[qg] = qg * 16 + col < a.QA;
+            tau[qg] = INFINITY;
+            yt[qg] = active[qg] ? a.qmeta[COARSE_QS + qg * 16 + col] : 0.f;
+        }
+        const long long nsteps = (a.nrows + 31) >> 5;
+        const long long tw = (long long)gridDim.x * NSCAN;
+        const long long last_row = a.nrows - 1;
+        long long step = (long long)blockIdx.x * NSCAN + wave;
+        unsigned st_push = 0, st_spin = 0;
+        if (step < nsteps) {
+            uint4 T[SLOTS];
+            auto frag_ptr = [&](long long st, int rt) {
+                return reinterpret_cast<const char*>(a.dbc) + st * (32 * ROWB) + (g >> 1) * 1024 + ((g & 1) * 32 + rt * 16 + col) * 16;
+            };
+            uint4 M[4];
+            auto load_meta = [&](long long st, uint4* m) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const uint4* mp = reinterpret_cast<const uint4*>(a.rmeta + st * 32 + rt * 16 + 4 * g);
+                    m[2 * rt] = mp[0];
+                    m[2 * rt + 1] = mp[1];
+                }
+            };
+            {
+                const char* p0 = frag_ptr(step, 0);
+                const char* p1 = frag_ptr(step, 1);
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    T[s_] = *reinterpret_cast<const uint4*>(p0 + 2048 * s_);
+                    T[KS + s_] = *reinterpret_cast<const uint4*>(p1 + 2048 * s_);
+                }
+                load_meta(step, M);
+            }
+            // thresholds: the published keys are re-read every step, ONE step ahead of their use (read and used in the same
+            // step, the wave sat out the L2 round trip of the sc1 loads at the head of every step: 2.5 ms instead of 0.9)
+            unsigned tk[QG], tkn[QG];
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg)
+                tk[qg] = active[qg] ? __hip_atomic_load(a.tau_key + qg * 16 + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            while (true) {
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg)
+                    tkn[qg] = active[qg] ? __hip_atomic_load(a.tau_key + qg * 16 + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                const long long nxt = step + tw;
+                const bool has_next = nxt < nsteps;
+                const char* pn[2] = {frag_ptr(has_next ? nxt : step, 0), frag_ptr(has_next ? nxt : step, 1)};
+                uint4 MN[4];
+                load_meta(has_next ? nxt : step, MN);
+
+                i32x4 acc[2][QG];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg) acc[rt][qg] = i32x4{0, 0, 0, 0};
+                uint4 B[2][QG];
+                auto load_b = [&](int s_, uint4* b) {
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg) b[qg] = qimg[(qg * KS + s_) * 64 + lane];
+                };
+                __builtin_amdgcn_sched_barrier(0);
+                load_b(0, B[0]);
+#pragma unroll
+                for (int slot = 0; slot < SLOTS; ++slot) {
+                    const int rt = slot / KS;
+                    if (slot + 1 == KS) asm volatile("" ::: "memory");
+                    if (slot + 1 < SLOTS) load_b((slot + 1) % KS, B[(slot + 1) & 1]);
+                    const uint4* b = B[slot & 1];
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg)
+                        acc[rt][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, T[slot]),
+                                                                            __builtin_bit_cast(i32x4, b[qg]), acc[rt][qg], 0, 0, 0);
+                    T[slot] = *reinterpret_cast<const uint4*>(pn[rt] + 2048 * (slot % KS));
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, QG, 0);
+#pragma unroll
+                for (int slot = 0; slot < SLOTS; ++slot) {
+                    if (slot + 1 < SLOTS) __builtin_amdgcn_sched_group_barrier(0x100, QG, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, QG, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg) tau[qg] = active[qg] ? fkey_inv(tk[qg]) : INFINITY;
+                float val[2][QG][4];
+                int cnt = 0;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const float sr[4] = {__uint_as_float(M[2 * rt].x), __uint_as_float(M[2 * rt].z), __uint_as_float(M[2 * rt + 1].x),
+                                         __uint_as_float(M[2 * rt + 1].z)};
+                    const float ar[4] = {__uint_as_float(M[2 * rt].y), __uint_as_float(M[2 * rt].w), __uint_as_float(M[2 * rt + 1].y),
+                                         __uint_as_float(M[2 * rt + 1].w)};
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            val[rt][qg][r] = fmaf((float)acc[rt][qg][r], sr[r], ar[r] * yt[qg]);
+                            cnt += (step * 32 + rt * 16 + 4 * g + r <= last_row) && (val[rt][qg][r] >= tau[qg]) ? 1 : 0;
+                        }
+                }
+                if (__ballot(cnt > 0)) {
+                    // ONE LDS atomic per step: inclusive scan of the lanes' counts, the wave reserves `total` ring slots
+                    int incl = cnt;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int v = __shfl_up(incl, o);
+                        if (lane >= o) incl += v;
+                    }
+                    const int total = __shfl(incl, 63);
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&ctl[0], total);
+                    base = __shfl(base, 0);
+                    int my = base + incl - cnt;
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                        for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const long long row = step * 32 + rt * 16 + 4 * g + r;
+                                if (row <= last_row && val[rt][qg][r] >= tau[qg]) {
+                                    uint2* sl = ring + (my & (LIVE_QN - 1));
+                                    int spins = 0;
+                                    // ring full: a re-scorer frees the slot. ctl[3] = somebody gave up waiting: the exact
+                                    // fallback will answer, nobody waits any more
+                                    while (*reinterpret_cast<volatile unsigned*>(&sl->y) != LIVE_EMPTY) {
+                                        __builtin_amdgcn_s_sleep(8);
+                                        if (*reinterpret_cast<volatile int*>(&ctl[3]) || ++spins > LIVE_SPIN_LIMIT) {
+                                            *a.overflow = 1u;
+                                            ctl[3] = 1;
+                                            spins = LIVE_SPIN_LIMIT + 1;
+                                            break;
+                                        }
+                                    }
+                                    if (spins <= LIVE_SPIN_LIMIT)
+                                        *sl = make_uint2(__float_as_uint(val[rt][qg][r]),
+                                                         ((unsigned)(qg * 16 + col) << LIVE_ROW_BITS) | (unsigned)row);
+                                    ++my;
+                                    ++st_push;
+                                    st_spin += (unsigned)spins;
+                                }
+                            }
+                }
+                if (!has_next) break;
+                step = nxt;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) M[i] = MN[i];
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg) tk[qg] = tkn[qg];
+            }
+        }
+        wave_lds_sync();                                   // this wave's ring writes are done (LDS is in order per wave)
+        if (lane == 0) atomicAdd(&ctl[2], 1);
+        if (a.stats) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { st_push += __shfl_xor(st_push, o); st_spin += __shfl_xor(st_spin, o); }
+            if (lane == 0) { atomicAdd(a.stats + 0, st_push); atomicAdd(a.stats + 1, st_spin); }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- re-scoring wave
+    volatile int* vctl = ctl;
+    unsigned st_pop = 0, st_stale = 0, st_resc = 0, st_ins = 0, st_batch = 0, st_rise = 0;
+    for (;;) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&ctl[1], 64);
+        base = __shfl(base, 0);
+        {
+            const int dn = vctl[2];                       // read `done` BEFORE `tail`: a finished scanner's reservations are all in
+            const int tail = vctl[0];
+            if ((dn == NSCAN && base >= tail) || (vctl[3] && dn == NSCAN)) break;   // nothing at or behind this index will ever come
+        }
+        const int idx = base + lane;
+        uint2* sl = ring + (idx & (LIVE_QN - 1));
+        bool pend = true;
+        int spins = 0;
+        while (__ballot(pend)) {
+            // wait for this lane's entry - but never with filled lanes in hand for long: a scanner may be waiting for
+            // exactly those slots (phased processing; see the deadlock note in DESIGN.md 4.1e)
+            bool got = false;
+            uint2 e = make_uint2(0u, LIVE_EMPTY);
+            for (int poll = 0; poll < 64; ++poll) {
+                if (pend && !got) {
+                    e.y = *reinterpret_cast<volatile unsigned*>(&sl->y);
+                    if (e.y != LIVE_EMPTY) {
+                        e.x = *reinterpret_cast<volatile unsigned*>(&sl->x);
+                        got = true;
+                    } else {
+                        const int dn = vctl[2];
+                        const int tail = vctl[0];
+                        if (dn == NSCAN && idx >= tail) pend = false;
+                        else if (vctl[3] || ++spins > LIVE_SPIN_LIMIT) { *a.overflow = 1u; ctl[3] = 1; pend = false; }
+                    }
+                }
+                const unsigned long long waiting = __ballot(pend && !got), have = __ballot(got);
+                if (!waiting || (have && poll >= 32)) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (!__ballot(got)) continue;
+            // ---- process the lanes that hold a pair
+            if (got) { *sl = make_uint2(0u, LIVE_EMPTY); pend = false; ++st_pop; }
+            const unsigned qi = got ? (e.y >> LIVE_ROW_BITS) : 0u;
+            const unsigned row = e.y & ((1u << LIVE_ROW_BITS) - 1u);
+            bool live_ = got;
+            if (live_) {
+                const float tnow = fkey_inv(__hip_atomic_load(a.tau_key + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                live_ = __uint_as_float(e.x) >= tnow;     // the threshold has risen past this pair's upper bound: drop it
+                if (!live_) ++st_stale;
+            }
+            if (!__ballot(live_)) continue;
+            if (live_) ++st_resc;
+            if (lane == 0) ++st_batch;
+            // exact score: the score-order fmaf chain (t, c, g), one pair per lane. Rows and query vectors are fetched
+            // COOPERATIVELY in 128-byte pieces - one wave-instruction = 8 lanes' rows x 128 contiguous bytes, groups of 8 lanes
+            // without a live pair skipped - through a padded per-wave LDS tile from which every lane then reads its own
+            // 32 floats. (A first version let every lane gather its own row and query: 512 load instructions per batch with 64
+            // different cache lines each kept the CU's address unit busy for ~16 us per batch and the SCANNERS' streaming loads
+            // waited behind them: 2.5 ms per scan instead of 0.9.)
+            const unsigned long long lm = __ballot(live_);
+            float acc = 0.f;
+            float* trow = lstage + (size_t)(wave - NSCAN) * (2 * 64 * LIVE_RS);
+            float* tqv = trow + 64 * LIVE_RS;
+            const int sub = lane >> 3, piece = lane & 7;
+            const float* rsrc[8];
+            const float* qsrc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned r_ = __shfl(row, 8 * i + sub), q_ = __shfl(qi, 8 * i + sub);
+                const bool on = (lm >> (8 * i + sub)) & 1ull;
+                rsrc[i] = a.db + (size_t)(on ? r_ : 0u) * E + piece * 4;
+                qsrc[i] = a.q + (size_t)(on ? q_ : 0u) * E + piece * 4;
+            }
+            f32x4 nr[8], nq[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if ((lm >> (8 * i)) & 0xffull) { nr[i] = *reinterpret_cast<const f32x4*>(rsrc[i]); nq[i] = *reinterpret_cast<const f32x4*>(qsrc[i]); }
+            for (int hc = 0; hc < E / 32; ++hc) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if ((lm >> (8 * i)) & 0xffull) {
+                        *reinterpret_cast<f32x4*>(trow + (8 * i + sub) * LIVE_RS + piece * 4) = nr[i];
+                        *reinterpret_cast<f32x4*>(tqv + (8 * i + sub) * LIVE_RS + piece * 4) = nq[i];
+                    }
+                if (hc + 1 < E / 32) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if ((lm >> (8 * i)) & 0xffull) {
+                            nr[i] = *reinterpret_cast<const f32x4*>(rsrc[i] + 32 * (hc + 1));
+                            nq[i] = *reinterpret_cast<const f32x4*>(qsrc[i] + 32 * (hc + 1));
+                        }
+                }
+                wave_lds_sync();
+                f32x4 rv[8], qv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    rv[i] = *reinterpret_cast<const f32x4*>(trow + lane * LIVE_RS + 4 * i);
+                    qv[i] = *reinterpret_cast<const f32x4*>(tqv + lane * LIVE_RS + 4 * i);
+                }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int g_ = 0; g_ < 4; ++g_)
+                            acc = __builtin_fmaf(rv[4 * tt + g_][c], qv[4 * tt + g_][c], acc);
+                wave_lds_sync();
+            }
+            bool ins = false;
+            float e0 = 0.f, dl = 1.f;
+            if (live_ && acc == acc) {
+                const float tex = fkey_inv(__hip_atomic_load(a.tex_key + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                ins = acc >= tex;
+            }
+            if (ins) {
+                ++st_ins;
+                const unsigned pos = atomicAdd(&a.gcnt[qi], 1u);
+                if ((long long)pos < a.cap) a.cand[(size_t)qi * a.cap + pos] = make_uint2(__float_as_uint(acc), row);
+                else *a.overflow = 1u;
+                e0 = a.edge0[qi];
+                dl = a.delta[qi];
+                float x = (acc - e0) / dl;
+                x = x < 0.f ? 0.f : (x > (float)(LIVE_NB - 1) ? (float)(LIVE_NB - 1) : x);
+                int b = (int)x;
+                if (b > 0 && !(acc >= fmaf((float)b, dl, e0))) --b;        // the bucket's edge must not exceed the score
+                if (acc >= fmaf((float)b, dl, e0)) atomicAdd(&a.hist[qi * LIVE_NB + b], 1u);
+            }
+            // ladder: for a few of the queries that just received a row, the highest edge with >= K rows at or above it
+            unsigned long long todo = __ballot(ins);
+            for (int round = 0; round < 4 && todo; ++round) {
+                const int src = __builtin_ctzll(todo);
+                const unsigned qs_ = __shfl(qi, src);
+                todo &= ~__ballot(ins && qi == qs_);
+                unsigned v = lane < LIVE_NB ? __hip_atomic_load(a.hist + qs_ * LIVE_NB + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+                for (int o = 1; o < LIVE_NB; o <<= 1) {
+                    const unsigned t_ = __shfl_down(v, o);
+                    if (lane + o < LIVE_NB) v += t_;
+                }
+                const unsigned long long okm = __ballot(lane < LIVE_NB && v >= (unsigned)a.K);
+                if (okm && lane == 0) {
+                    const int bmax = 63 - __builtin_clzll(okm);
+                    const float tnew = fmaf((float)bmax, a.delta[qs_], a.edge0[qs_]);
+                    ++st_rise;
+                    atomicMax(a.tex_key + qs_, fkey(tnew));
+                    atomicMax(a.tau_key + qs_, fkey((tnew - a.qmeta[3 * COARSE_QS + qs_]) * a.qmeta[qs_]));
+                }
+            }
+        }
+    }
+    if (a.stats) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            st_pop += __shfl_xor(st_pop, o); st_stale += __shfl_xor(st_stale, o); st_resc += __shfl_xor(st_resc, o);
+            st_ins += __shfl_xor(st_ins, o); st_batch += __shfl_xor(st_batch, o); st_rise += __shfl_xor(st_rise, o);
+        }
+        if (lane == 0) {
+            atomicAdd(a.stats + 2, st_pop); atomicAdd(a.stats + 3, st_stale); atomicAdd(a.stats + 4, st_resc);
+            atomicAdd(a.stats + 5, st_ins); atomicAdd(a.stats + 6, st_batch); atomicAdd(a.stats + 7, st_rise);
+        }
+    }
+}
+
+// =================================================================================================
 // Wide coarse pass (int8 copy only): ONE stream of the copy for up to WIDE_MAX_Q = 1024 queries of one search call
 // (reference: query-index.py:111 is one index.search call; SURVEY.md §8d "DB streamed once per batch").
 //
@@ -1568,10 +1997,11 @@ int launch_coarse(const CoarseArgs& a, long long nsteps, hipStream_t st, hipEven
     return 0;
 }
 
-constexpr int COARSE_CTL = 2 * COARSE_Q + 4;      // fallback counters | coarse counters | overflow flag
+constexpr int COARSE_CTL = 2 * COARSE_Q + 16 + COARSE_Q * LIVE_NB;     // fallback counters | coarse counters | overflow flag + 12 live-scan statistics | ladder
 struct CoarseWs {
     uint2* cand_e; uint2* cand_c; unsigned* gcnt_e; unsigned* gcnt_c; float* thr0; float* tauc; unsigned* flag;
     unsigned* last_m; float* qmeta; uint4* qimage;
+    unsigned* hist; unsigned* live_keys; float* live_edges;       // live-threshold scan (scan_coarse_live_kernel)
 };
 
 // the plan of the coarse path's side kernels (sample select, fallback scan + select): within COARSE_SIDE_LDS when K allows
@@ -1588,6 +2018,9 @@ size_t carve_coarse(const Plan& p, void* base, size_t cap, CoarseWs* w) {
     x.gcnt_e = ar.take<unsigned>(COARSE_CTL);          // one control block, cleared by coarse_prep_kernel
     x.gcnt_c = x.gcnt_e + COARSE_Q;
     x.flag = x.gcnt_e + 2 * COARSE_Q;
+    x.hist = x.flag + 16;
+    x.live_keys = ar.take<unsigned>(2 * COARSE_Q);
+    x.live_edges = ar.take<float>(2 * COARSE_Q);
     x.thr0 = ar.take<float>(COARSE_Q);
     x.tauc = ar.take<float>(COARSE_Q);
     x.last_m = ar.take<unsigned>(COARSE_Q);
@@ -1617,6 +2050,12 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
     hipStream_t st = as_stream(stream);
     if (int rc = opt_in_lds((const void*)select_topk_kernel, p.lds_sel)) return rc;
     if (int rc = opt_in_lds((const void*)rescore_pairs_kernel<512>, 512 * 4 + 4 * 64 * 68 * 4)) return rc;
+    // int8 copy, shards below 2^26 rows: the live-threshold scan - EXPERIMENTAL, off unless CLIPMI_LIVE=1. Bit-exact, ONE scan
+    // launch, half the re-scored pairs, but 2.3 ms per 10 M-row scan against 0.9 ms for the three segmented scans (r03): its
+    // 138 KB of LDS leave one workgroup = FOUR scanner waves per CU with one 16 KB step in flight each, a quarter of the bytes
+    // in flight the segmented kernel's 16 waves per CU keep, and the scan is HBM-latency bound.
+    static const bool live_on = [] { const char* e = getenv("CLIPMI_LIVE"); return e && atoi(e) == 1; }();
+    const bool live = i8 && live_on && N < (1ll << LIVE_ROW_BITS);
 
     for (int q0 = 0; q0 < Q; q0 += COARSE_Q) {
         const int qa = (Q - q0) < COARSE_Q ? (Q - q0) : COARSE_Q;
@@ -1700,7 +2139,8 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             CLIPMI_CHECK_LAUNCH("sample_scores_kernel");
             hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), p.lds_sel, st, w.cand_c, w.gcnt_c, COARSE_CAP, K,
                                (long long)0, (float*)nullptr, (long long*)nullptr, w.thr0, (const unsigned*)nullptr,
-                               (unsigned*)nullptr, 0, p.stage, w.qmeta);
+                               (unsigned*)nullptr, 0, p.stage, w.qmeta, COARSE_QS, live ? w.live_keys : (unsigned*)nullptr,
+                               live ? w.live_edges : (float*)nullptr);
             CLIPMI_CHECK_LAUNCH("select_topk_kernel(sample 1)");
         }
         // Segments of the copy, each scanned ONCE: [0, S2) (level 2 of the pre-pass, threshold from level 1), then
@@ -1712,9 +2152,37 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
         float* os_final = out_score_dev + (size_t)q0 * K;
         long long* oi_final = (long long*)out_id_dev + (size_t)q0 * K;
         long long r_done = 0;
+        if (live) {
+            // ONE launch over all rows: scanners + re-scoring waves, thresholds rising through the ladder (scan_coarse_live_kernel)
+            LiveArgs la;
+            la.dbc = static_cast<const signed char*>(dbh_dev); la.rmeta = rmeta; la.db = static_cast<const float*>(db_dev);
+            la.q = qg; la.qmeta = w.qmeta; la.qimage = w.qimage; la.nrows = N; la.QA = qa; la.K = K;
+            la.tau_key = w.live_keys; la.tex_key = w.live_keys + COARSE_Q; la.edge0 = w.live_edges; la.delta = w.live_edges + COARSE_Q;
+            la.hist = w.hist; la.cand = w.cand_c; la.gcnt = w.gcnt_c; la.cap = COARSE_CAP; la.overflow = w.flag; la.stats = w.flag + 4;
+            const int QGl = qa <= 16 ? 1 : qa <= 32 ? 2 : 4;
+            size_t lds = (size_t)QGl * 8 * 1024 + (size_t)LIVE_QN * 8 + 64 + (size_t)4 * 2 * 64 * LIVE_RS * 4;
+            if (lds < (size_t)COARSE_MAIN_LDS) lds = COARSE_MAIN_LDS;           // as the segmented form's last segment
+            const void* fn = QGl == 1 ? (const void*)scan_coarse_live_kernel<1> : QGl == 2 ? (const void*)scan_coarse_live_kernel<2>
+                                                                                           : (const void*)scan_coarse_live_kernel<4>;
+            if (int rc = opt_in_lds(fn, lds)) return rc;
+            long long g_ = ((N + 31) / 32 + 3) / 4;
+            const int grid = (int)(g_ < NUM_CU ? g_ : NUM_CU);
+            if (scan_ev) (void)hipEventRecord(scan_ev[0], st);
+            if (QGl == 1) hipLaunchKernelGGL(scan_coarse_live_kernel<1>, dim3(grid), dim3(512), lds, st, la);
+            else if (QGl == 2) hipLaunchKernelGGL(scan_coarse_live_kernel<2>, dim3(grid), dim3(512), lds, st, la);
+            else hipLaunchKernelGGL(scan_coarse_live_kernel<4>, dim3(grid), dim3(512), lds, st, la);
+            if (scan_ev) (void)hipEventRecord(scan_ev[1], st);
+            CLIPMI_CHECK_LAUNCH("scan_coarse_live_kernel");
+            const int scap = p.stage < 4096 ? p.stage : 4096;
+            hipLaunchKernelGGL(select_topk_kernel, dim3(qa), dim3(SEL_THREADS), SEL_FIXED + (size_t)K * 8 + (size_t)scap * 8, st,
+                               w.cand_c, w.gcnt_c, COARSE_CAP, K, (long long)id_base, os_final, oi_final, (float*)nullptr,
+                               (const unsigned*)nullptr, w.last_m, 0, scap, (float*)nullptr);
+            CLIPMI_CHECK_LAUNCH("select_topk_kernel(live)");
+        }
         // development knob: CLIPMI_COARSE_SEGS=n (>= 4): n geometric segments from 64 k rows, as the wide pass plans them
         static const int nseg_env = [] { const char* e = getenv("CLIPMI_COARSE_SEGS"); return e ? atoi(e) : 0; }();
-        if (two_level && nseg_env >= 4 && N >= (1 << 20)) {
+        if (live) {
+        } else if (two_level && nseg_env >= 4 && N >= (1 << 20)) {
             long long b = 65536;
             const double ratio = pow((double)N / 65536.0, 1.0 / (nseg_env - 1));
             for (int sgi = 0; sgi + 1 < nseg_env; ++sgi) {
@@ -1735,8 +2203,9 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             }
         }
         // last segment (its threshold was written by the previous select): scan, exact re-scoring, select into the result
-        if (int rc = coarse_pass(r_done, N, false, nullptr, os_final, oi_final, (long long)id_base, scan_ev, w.last_m, two_level ? 2 : 0))
-            return rc;
+        if (!live)
+            if (int rc = coarse_pass(r_done, N, false, nullptr, os_final, oi_final, (long long)id_base, scan_ev, w.last_m, two_level ? 2 : 0))
+                return rc;
         // 6. fallback: exact scan + select, exiting at once unless a coarse list overflowed
         //    (two launches: the exact scan takes its groups of p.QA queries as blockIdx.y, each with its own lists)
         {
@@ -2028,6 +2497,13 @@ static int dbg_coarse_scan_ms(const void* db_dev, const void* db_bf16_dev, bool 
     }
     for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ev[i]);
     if (rc == 0) *scan_ms = (float)(total / reps);
+    if (rc == 0 && getenv("CLIPMI_LIVE_STATS")) {
+        Plan p; CoarseWs w; coarse_plan(N, E, Q, K, p); carve_coarse(p, ws_dev, ws_bytes, &w);
+        unsigned h[12];
+        if (hipMemcpy(h, w.flag + 4, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "live scan (last call): pushed %u (push spins %u) popped %u stale %u re-scored %u inserted %u batches %u ladder rises %u overflow-flag-read-separately\n",
+                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    }
     if (rc == 0 && survivors) {       // rows that survived the coarse pass, summed over the Q queries of the last call
         Plan p;
         CoarseWs w;

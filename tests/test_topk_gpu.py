@@ -618,3 +618,16 @@ def test_full_size_10m_properties(clipmi, gpu, topk_oracle, N):
     pick = torch.arange(64, 1024, 31, device=gpu)[:32]
     Dx, Ix = exact.search(qw[pick], K)
     _assert_exact(Dw[pick.cpu().numpy()], Iw[pick.cpu().numpy()], Dx, Ix, "wide pass (Q = 1024) vs exact at full size, 32 more")
+
+
+@pytest.mark.gpu
+def test_live_threshold_scan_is_bit_exact_when_enabled():
+    """The experimental one-launch scan (scan_coarse_live_kernel, CLIPMI_LIVE=1, off by default: DESIGN.md 4.1e) returns the
+    exact f32 scan's bits. The switch is read once per process, so the check runs in a child."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CLIPMI_LIVE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "live_check.py"), "300000", "1,16,64"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count("exact: True") == 3 and "exact: False" not in r.stdout, r.stdout
