@@ -1199,9 +1199,11 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
     for (int base = tid; base < NIMG; base += 512) qimg[base] = a.qimage[base];
     uint2* ring = reinterpret_cast<uint2*>(smem + IMG_BYTES);                      // [LIVE_QN]
     int* ctl = reinterpret_cast<int*>(ring + LIVE_QN);                             // [0] tail, [1] head, [2] scanners done, [3] abort
-    float* lstage = reinterpret_cast<float*>(ctl + 16);                            // re-scoring waves: [4][rows | queries][64][LIVE_RS]
+    unsigned* ltau = reinterpret_cast<unsigned*>(ctl + 16);                        // [64] this workgroup's copy of the threshold keys
+    float* lstage = reinterpret_cast<float*>(ltau + 64);                           // re-scoring waves: [4][rows | queries][64][LIVE_RS]
     for (int i = tid; i < LIVE_QN; i += 512) ring[i] = make_uint2(0u, LIVE_EMPTY);
     if (tid < 4) ctl[tid] = 0;
+    if (tid < 64) ltau[tid] = tid < a.QA ? a.tau_key[tid] : 0u;
     __syncthreads();
 
     if (wave < NSCAN) {
@@ -1243,16 +1245,29 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
                 }
                 load_meta(step, M);
             }
-            // thresholds: the published keys are re-read every step, ONE step ahead of their use (read and used in the same
-            // step, the wave sat out the L2 round trip of the sc1 loads at the head of every step: 2.5 ms instead of 0.9)
+            // thresholds: every step reads the WORKGROUP's copy of the keys in LDS; scanner wave 0 refreshes that copy from the
+            // published keys every 4th step (request in one step, LDS update in the next), re-scoring waves raise it when they
+            // raise a key. (All 1024 scanner waves re-reading the published keys - two cache lines, agent scope: served by the
+            // fabric, not the XCD's L2 - every step made those two lines the scan's bottleneck: 7.5 us per step, 2.3 ms per scan.)
             unsigned tk[QG], tkn[QG];
 #pragma unroll
-            for (int qg = 0; qg < QG; ++qg)
-                tk[qg] = active[qg] ? __hip_atomic_load(a.tau_key + qg * 16 + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            for (int qg = 0; qg < QG; ++qg) tkn[qg] = 0u;
+            int it = 0;
             while (true) {
 #pragma unroll
-                for (int qg = 0; qg < QG; ++qg)
-                    tkn[qg] = active[qg] ? __hip_atomic_load(a.tau_key + qg * 16 + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                for (int qg = 0; qg < QG; ++qg) tk[qg] = active[qg] ? *reinterpret_cast<volatile unsigned*>(ltau + qg * 16 + col) : 0u;
+                if (wave == 0) {
+                    if ((it & 3) == 0) {
+#pragma unroll
+                        for (int qg = 0; qg < QG; ++qg)
+                            tkn[qg] = active[qg] ? __hip_atomic_load(a.tau_key + qg * 16 + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    } else if ((it & 3) == 1) {
+#pragma unroll
+                        for (int qg = 0; qg < QG; ++qg)
+                            if (g == 0 && active[qg] && tkn[qg] > tk[qg]) atomicMax(ltau + qg * 16 + col, tkn[qg]);
+                    }
+                }
+                ++it;
                 const long long nxt = step + tw;
                 const bool has_next = nxt < nsteps;
                 const char* pn[2] = {frag_ptr(has_next ? nxt : step, 0), frag_ptr(has_next ? nxt : step, 1)};
@@ -1357,8 +1372,6 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
                 step = nxt;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) M[i] = MN[i];
-#pragma unroll
-                for (int qg = 0; qg < QG; ++qg) tk[qg] = tkn[qg];
             }
         }
         wave_lds_sync();                                   // this wave's ring writes are done (LDS is in order per wave)
@@ -1514,8 +1527,10 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
                     const int bmax = 63 - __builtin_clzll(okm);
                     const float tnew = fmaf((float)bmax, a.delta[qs_], a.edge0[qs_]);
                     ++st_rise;
+                    const unsigned nk = fkey((tnew - a.qmeta[3 * COARSE_QS + qs_]) * a.qmeta[qs_]);
                     atomicMax(a.tex_key + qs_, fkey(tnew));
-                    atomicMax(a.tau_key + qs_, fkey((tnew - a.qmeta[3 * COARSE_QS + qs_]) * a.qmeta[qs_]));
+                    atomicMax(a.tau_key + qs_, nk);
+                    atomicMax(ltau + qs_, nk);
                 }
             }
         }
@@ -2160,7 +2175,7 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             la.tau_key = w.live_keys; la.tex_key = w.live_keys + COARSE_Q; la.edge0 = w.live_edges; la.delta = w.live_edges + COARSE_Q;
             la.hist = w.hist; la.cand = w.cand_c; la.gcnt = w.gcnt_c; la.cap = COARSE_CAP; la.overflow = w.flag; la.stats = w.flag + 4;
             const int QGl = qa <= 16 ? 1 : qa <= 32 ? 2 : 4;
-            size_t lds = (size_t)QGl * 8 * 1024 + (size_t)LIVE_QN * 8 + 64 + (size_t)4 * 2 * 64 * LIVE_RS * 4;
+            size_t lds = (size_t)QGl * 8 * 1024 + (size_t)LIVE_QN * 8 + 64 + 256 + (size_t)4 * 2 * 64 * LIVE_RS * 4;
             if (lds < (size_t)COARSE_MAIN_LDS) lds = COARSE_MAIN_LDS;           // as the segmented form's last segment
             const void* fn = QGl == 1 ? (const void*)scan_coarse_live_kernel<1> : QGl == 2 ? (const void*)scan_coarse_live_kernel<2>
                                                                                            : (const void*)scan_coarse_live_kernel<4>;
