@@ -1153,7 +1153,7 @@ constexpr int LIVE_NB = 32;                      // ladder buckets per query
 constexpr int LIVE_QN = 4096;                    // ring entries (32 KiB)
 constexpr unsigned LIVE_EMPTY = 0xffffffffu;
 constexpr int LIVE_ROW_BITS = 26;                // ring entry .y = (query << 26) | row: shards of < 2^26 rows
-constexpr int LIVE_RS = 36;                      // floats per staged 32-float piece (+ 4 pad: conflict-free ds_read_b128)
+constexpr int LIVE_CH = 16;                      // 32-row steps per unit of scanner work
 constexpr int LIVE_SPIN_LIMIT = 1 << 20;         // polls before a waiting lane gives up (~ tens of ms): overflow -> fallback
 
 __device__ __forceinline__ unsigned fkey(float f) {             // order-preserving key of a float (-0 and +0 differ: harmless)
@@ -1182,28 +1182,36 @@ struct LiveArgs {
     unsigned* gcnt;              // [64]
     long long cap;
     unsigned* overflow;
+    unsigned* chunk_ctr;         // work counter of the scanner waves (zero at launch)
+    int abl;                     // development ablation (CLIPMI_LIVE_ABL): 1 scanners push nothing, 2 re-scoring waves drop every pair
     unsigned* stats;             // [12] pushed | push spins | popped | stale | re-scored | inserted | batches | ladder rises
 };
 
-template <int QG>
+template <int QG, int NSCAN = 4>
 __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int E = 512, KS = E / 64, ROWB = E, SLOTS = 2 * KS, NIMG = QG * KS * 64, IMG_BYTES = NIMG * 16;
-    constexpr int NSCAN = 4;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, g = lane >> 4;
 
+    const unsigned long long t_begin = a.stats ? wall_clock64() : 0ull;
     uint4* qimg = reinterpret_cast<uint4*>(smem);
     for (int base = tid; base < NIMG; base += 512) qimg[base] = a.qimage[base];
     uint2* ring = reinterpret_cast<uint2*>(smem + IMG_BYTES);                      // [LIVE_QN]
-    int* ctl = reinterpret_cast<int*>(ring + LIVE_QN);                             // [0] tail, [1] head, [2] scanners done, [3] abort
+    int* ctl = reinterpret_cast<int*>(ring + LIVE_QN);                             // [0] tail, [1] head, [2] scanners done, [3] abort, [4] batches released
     unsigned* ltau = reinterpret_cast<unsigned*>(ctl + 16);                        // [64] this workgroup's copy of the threshold keys
-    float* lstage = reinterpret_cast<float*>(ltau + 64);                           // re-scoring waves: [4][rows | queries][64][LIVE_RS]
+    unsigned* ltex = ltau + 64;                                                    // [64] ... and of the exact thresholds' keys
+    f32x4* lcon = reinterpret_cast<f32x4*>(ltex + 64);                             // [64] ladder origin, ladder step, query scale, query slack
     for (int i = tid; i < LIVE_QN; i += 512) ring[i] = make_uint2(0u, LIVE_EMPTY);
-    if (tid < 4) ctl[tid] = 0;
-    if (tid < 64) ltau[tid] = tid < a.QA ? a.tau_key[tid] : 0u;
+    if (tid < 8) ctl[tid] = 0;
+    if (tid < 64) {
+        const bool on = tid < a.QA;
+        ltau[tid] = on ? a.tau_key[tid] : 0u;
+        ltex[tid] = on ? a.tex_key[tid] : 0u;
+        lcon[tid] = on ? f32x4{a.edge0[tid], a.delta[tid], a.qmeta[tid], a.qmeta[3 * COARSE_QS + tid]} : f32x4{0.f, 1.f, 1.f, 0.f};
+    }
     __syncthreads();
 
     if (wave < NSCAN) {
@@ -1216,11 +1224,18 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
             tau[qg] = INFINITY;
             yt[qg] = active[qg] ? a.qmeta[COARSE_QS + qg * 16 + col] : 0.f;
         }
+        // work: chunks of LIVE_CH 32-row steps. The first chunk of a wave is its index in the grid, every further one comes
+        // from a counter (zeroed with the call's control words), requested one chunk ahead: CUs and XCDs stream at different
+        // rates, and with a fixed interleave the last wave finished ~90 us (10 %) after the average one.
         const long long nsteps = (a.nrows + 31) >> 5;
+        const long long nchunks = (nsteps + LIVE_CH - 1) / LIVE_CH;
         const long long tw = (long long)gridDim.x * NSCAN;
-        const long long last_row = a.nrows - 1;
-        long long step = (long long)blockIdx.x * NSCAN + wave;
-        unsigned st_push = 0, st_spin = 0;
+        long long step = ((long long)blockIdx.x * NSCAN + wave) * LIVE_CH;
+        int in_chunk = 0;
+        unsigned grabbed = 0u;
+        if (lane == 0) grabbed = atomicAdd(a.chunk_ctr, 1u);
+        unsigned st_push = 0, st_spin = 0, tm_a = 0, tm_b = 0, tm_c = 0;
+        const bool timed = a.stats != nullptr;
         if (step < nsteps) {
             uint4 T[SLOTS];
             auto frag_ptr = [&](long long st, int rt) {
@@ -1268,8 +1283,16 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
                     }
                 }
                 ++it;
-                const long long nxt = step + tw;
-                const bool has_next = nxt < nsteps;
+                long long nxt = step + 1;
+                bool has_next = true;
+                int in_next = in_chunk + 1;
+                if (in_next == LIVE_CH || nxt >= nsteps) {
+                    const long long c_ = (long long)__builtin_amdgcn_readfirstlane(grabbed) + tw;
+                    has_next = c_ < nchunks;
+                    nxt = c_ * LIVE_CH;
+                    in_next = 0;
+                    if (has_next && lane == 0) grabbed = atomicAdd(a.chunk_ctr, 1u);
+                }
                 const char* pn[2] = {frag_ptr(has_next ? nxt : step, 0), frag_ptr(has_next ? nxt : step, 1)};
                 uint4 MN[4];
                 load_meta(has_next ? nxt : step, MN);
@@ -1284,33 +1307,40 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
 #pragma unroll
                     for (int qg = 0; qg < QG; ++qg) b[qg] = qimg[(qg * KS + s_) * 64 + lane];
                 };
+                const unsigned long long tk0 = timed ? wall_clock64() : 0ull;
                 __builtin_amdgcn_sched_barrier(0);
                 load_b(0, B[0]);
+                // one query fragment from LDS feeds BOTH 16-row tiles (the LDS pipe is the scanner's second bound: read per
+                // MFMA, 4 scanner waves keep it ~70 % busy)
 #pragma unroll
-                for (int slot = 0; slot < SLOTS; ++slot) {
-                    const int rt = slot / KS;
-                    if (slot + 1 == KS) asm volatile("" ::: "memory");
-                    if (slot + 1 < SLOTS) load_b((slot + 1) % KS, B[(slot + 1) & 1]);
-                    const uint4* b = B[slot & 1];
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    if (s_ + 1 < KS) load_b(s_ + 1, B[(s_ + 1) & 1]);
+                    const uint4* b = B[s_ & 1];
 #pragma unroll
-                    for (int qg = 0; qg < QG; ++qg)
-                        acc[rt][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, T[slot]),
-                                                                            __builtin_bit_cast(i32x4, b[qg]), acc[rt][qg], 0, 0, 0);
-                    T[slot] = *reinterpret_cast<const uint4*>(pn[rt] + 2048 * (slot % KS));
+                    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                        for (int qg = 0; qg < QG; ++qg)
+                            acc[rt][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, T[rt * KS + s_]),
+                                                                                __builtin_bit_cast(i32x4, b[qg]), acc[rt][qg], 0, 0, 0);
+                    T[s_] = *reinterpret_cast<const uint4*>(pn[0] + 2048 * s_);
+                    T[KS + s_] = *reinterpret_cast<const uint4*>(pn[1] + 2048 * s_);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x100, QG, 0);
 #pragma unroll
-                for (int slot = 0; slot < SLOTS; ++slot) {
-                    if (slot + 1 < SLOTS) __builtin_amdgcn_sched_group_barrier(0x100, QG, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, QG, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    if (s_ + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, QG, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * QG, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                unsigned long long tk1 = 0ull;
+                if (timed) { asm volatile("" :: "v"(acc[1][QG - 1][0])); tk1 = wall_clock64(); tm_a += (unsigned)(tk1 - tk0); }
 
 #pragma unroll
                 for (int qg = 0; qg < QG; ++qg) tau[qg] = active[qg] ? fkey_inv(tk[qg]) : INFINITY;
                 float val[2][QG][4];
-                int cnt = 0;
+                int total = 0;
+                const int lim = (int)(a.nrows - step * 32);           // rows of this step that exist (32 except in the last block)
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
                     const float sr[4] = {__uint_as_float(M[2 * rt].x), __uint_as_float(M[2 * rt].z), __uint_as_float(M[2 * rt + 1].x),
@@ -1322,54 +1352,58 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             val[rt][qg][r] = fmaf((float)acc[rt][qg][r], sr[r], ar[r] * yt[qg]);
-                            cnt += (step * 32 + rt * 16 + 4 * g + r <= last_row) && (val[rt][qg][r] >= tau[qg]) ? 1 : 0;
+                            if (lim < 32 && rt * 16 + 4 * g + r >= lim) val[rt][qg][r] = __uint_as_float(0x7fc00000u);   // NaN: passes no test
+                            total += __popcll(__ballot(val[rt][qg][r] >= tau[qg]));
                         }
                 }
-                if (__ballot(cnt > 0)) {
-                    // ONE LDS atomic per step: inclusive scan of the lanes' counts, the wave reserves `total` ring slots
-                    int incl = cnt;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const int v = __shfl_up(incl, o);
-                        if (lane >= o) incl += v;
-                    }
-                    const int total = __shfl(incl, 63);
+                if (a.abl == 1) total = 0;
+                unsigned long long tk2 = 0ull;
+                if (timed) { asm volatile("" :: "s"(total)); tk2 = wall_clock64(); tm_b += (unsigned)(tk2 - tk1); }
+                if (total) {
+                    // ONE LDS atomic per step reserves `total` ring slots; the pairs go in by ballot prefix (scalar masks)
                     int base = 0;
                     if (lane == 0) base = atomicAdd(&ctl[0], total);
-                    base = __shfl(base, 0);
-                    int my = base + incl - cnt;
-#pragma unroll
-                    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                        for (int qg = 0; qg < QG; ++qg)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const long long row = step * 32 + rt * 16 + 4 * g + r;
-                                if (row <= last_row && val[rt][qg][r] >= tau[qg]) {
-                                    uint2* sl = ring + (my & (LIVE_QN - 1));
-                                    int spins = 0;
-                                    // ring full: a re-scorer frees the slot. ctl[3] = somebody gave up waiting: the exact
-                                    // fallback will answer, nobody waits any more
-                                    while (*reinterpret_cast<volatile unsigned*>(&sl->y) != LIVE_EMPTY) {
-                                        __builtin_amdgcn_s_sleep(8);
-                                        if (*reinterpret_cast<volatile int*>(&ctl[3]) || ++spins > LIVE_SPIN_LIMIT) {
-                                            *a.overflow = 1u;
-                                            ctl[3] = 1;
-                                            spins = LIVE_SPIN_LIMIT + 1;
-                                            break;
-                                        }
-                                    }
-                                    if (spins <= LIVE_SPIN_LIMIT)
-                                        *sl = make_uint2(__float_as_uint(val[rt][qg][r]),
-                                                         ((unsigned)(qg * 16 + col) << LIVE_ROW_BITS) | (unsigned)row);
-                                    ++my;
-                                    ++st_push;
-                                    st_spin += (unsigned)spins;
-                                }
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    // room: re-scoring waves release their 64-slot batches IN ORDER (ctl[4] = batches released), so every slot
+                    // below 64 * ctl[4] is free again. One LDS read per step instead of one read-and-wait per pushed pair.
+                    bool room = true;
+                    {
+                        int spins = 0;
+                        while (base + total > 64 * *reinterpret_cast<volatile int*>(&ctl[4]) + LIVE_QN) {
+                            __builtin_amdgcn_s_sleep(8);
+                            ++st_spin;
+                            if (*reinterpret_cast<volatile int*>(&ctl[3]) || ++spins > LIVE_SPIN_LIMIT) {
+                                *a.overflow = 1u;          // somebody gave up waiting: the exact fallback answers
+                                ctl[3] = 1;
+                                room = false;
+                                break;
                             }
+                        }
+                    }
+                    if (room) {
+                        const unsigned row0 = (unsigned)(step * 32) + 4 * g;
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                            for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const unsigned long long m_ = __ballot(val[rt][qg][r] >= tau[qg]);
+                                    if (m_) {
+                                        if ((m_ >> lane) & 1ull)
+                                            ring[(base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_, 0u))) &
+                                                 (LIVE_QN - 1)] = make_uint2(__float_as_uint(val[rt][qg][r]),
+                                                                             ((unsigned)(qg * 16 + col) << LIVE_ROW_BITS) | (row0 + rt * 16 + r));
+                                        base += __popcll(m_);
+                                    }
+                                }
+                        st_push += (unsigned)total;
+                    }
                 }
+                if (timed) { wave_lds_sync(); tm_c += (unsigned)(wall_clock64() - tk2); }
                 if (!has_next) break;
                 step = nxt;
+                in_chunk = in_next;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) M[i] = MN[i];
             }
@@ -1378,15 +1412,29 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
         if (lane == 0) atomicAdd(&ctl[2], 1);
         if (a.stats) {
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) { st_push += __shfl_xor(st_push, o); st_spin += __shfl_xor(st_spin, o); }
-            if (lane == 0) { atomicAdd(a.stats + 0, st_push); atomicAdd(a.stats + 1, st_spin); }
+            for (int o = 32; o >= 1; o >>= 1) st_spin += __shfl_xor(st_spin, o);
+            st_spin >>= 6;
+            if (lane == 0) {
+                atomicAdd(a.stats + 0, st_push); atomicAdd(a.stats + 1, st_spin);
+                const unsigned dt = (unsigned)(wall_clock64() - t_begin);
+                atomicMax(a.stats + 8, dt); atomicAdd(a.stats + 10, dt >> 10);
+                atomicAdd(a.stats + 15, 1u);
+                atomicAdd(a.stats + 12, tm_a >> 4); atomicAdd(a.stats + 13, tm_b >> 4); atomicAdd(a.stats + 14, tm_c >> 4);
+            }
         }
         return;
     }
 
     // ---------------------------------------------------------------------- re-scoring wave
+    // Claims 64 ring slots at a time, drops the pairs whose upper bound the threshold has passed since, and re-scores the rest
+    // EIGHT pairs per round: 8 lanes per pair request the pair's whole row and query vector (2 x 2 KB, 32 loads of 16 B per
+    // lane, ALL in flight together: one memory round trip per round), the wave transposes them through LDS in two halves and
+    // lanes 0..7 walk one pair each through the score-order fmaf chain (t, c, g). (Earlier forms: per-lane gathers kept the
+    // CU's address unit busy; 64 pairs per batch in 16 dependent 128-byte stages took ~100 us per batch - the scan waited
+    // 340 us for the re-scoring waves to drain.)
     volatile int* vctl = ctl;
-    unsigned st_pop = 0, st_stale = 0, st_resc = 0, st_ins = 0, st_batch = 0, st_rise = 0;
+    unsigned st_pop = 0, st_stale = 0, st_resc = 0, st_ins = 0, st_batch = 0, st_rise = 0, st_phase = 0;
+    const int pslot = lane >> 3, piece = lane & 7;
     for (;;) {
         int base = 0;
         if (lane == 0) base = atomicAdd(&ctl[1], 64);
@@ -1423,116 +1471,130 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
                 __builtin_amdgcn_s_sleep(4);
             }
             if (!__ballot(got)) continue;
-            // ---- process the lanes that hold a pair
+            // ---- the lanes that hold a pair
             if (got) { *sl = make_uint2(0u, LIVE_EMPTY); pend = false; ++st_pop; }
             const unsigned qi = got ? (e.y >> LIVE_ROW_BITS) : 0u;
             const unsigned row = e.y & ((1u << LIVE_ROW_BITS) - 1u);
-            bool live_ = got;
-            if (live_) {
-                const float tnow = fkey_inv(__hip_atomic_load(a.tau_key + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                live_ = __uint_as_float(e.x) >= tnow;     // the threshold has risen past this pair's upper bound: drop it
-                if (!live_) ++st_stale;
-            }
-            if (!__ballot(live_)) continue;
-            if (live_) ++st_resc;
-            if (lane == 0) ++st_batch;
-            // exact score: the score-order fmaf chain (t, c, g), one pair per lane. Rows and query vectors are fetched
-            // COOPERATIVELY in 128-byte pieces - one wave-instruction = 8 lanes' rows x 128 contiguous bytes, groups of 8 lanes
-            // without a live pair skipped - through a padded per-wave LDS tile from which every lane then reads its own
-            // 32 floats. (A first version let every lane gather its own row and query: 512 load instructions per batch with 64
-            // different cache lines each kept the CU's address unit busy for ~16 us per batch and the SCANNERS' streaming loads
-            // waited behind them: 2.5 ms per scan instead of 0.9.)
-            const unsigned long long lm = __ballot(live_);
-            float acc = 0.f;
-            float* trow = lstage + (size_t)(wave - NSCAN) * (2 * 64 * LIVE_RS);
-            float* tqv = trow + 64 * LIVE_RS;
-            const int sub = lane >> 3, piece = lane & 7;
-            const float* rsrc[8];
-            const float* qsrc[8];
+            bool live_ = got && a.abl != 2;
+            bool scored = false;
+            float myscore = 0.f;
+            if (lane == 0) ++st_phase;
+            while (true) {
+                // (re-)check against the workgroup's threshold copy: it may have risen during the previous round
+                if (live_ && !(__uint_as_float(e.x) >= fkey_inv(*reinterpret_cast<volatile unsigned*>(ltau + qi)))) { live_ = false; ++st_stale; }
+                unsigned long long t_ = __ballot(live_);
+                if (!t_) break;
+                int mysrc = -1, mygrp = -1;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const unsigned r_ = __shfl(row, 8 * i + sub), q_ = __shfl(qi, 8 * i + sub);
-                const bool on = (lm >> (8 * i + sub)) & 1ull;
-                rsrc[i] = a.db + (size_t)(on ? r_ : 0u) * E + piece * 4;
-                qsrc[i] = a.q + (size_t)(on ? q_ : 0u) * E + piece * 4;
-            }
-            f32x4 nr[8], nq[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if ((lm >> (8 * i)) & 0xffull) { nr[i] = *reinterpret_cast<const f32x4*>(rsrc[i]); nq[i] = *reinterpret_cast<const f32x4*>(qsrc[i]); }
-            for (int hc = 0; hc < E / 32; ++hc) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if ((lm >> (8 * i)) & 0xffull) {
-                        *reinterpret_cast<f32x4*>(trow + (8 * i + sub) * LIVE_RS + piece * 4) = nr[i];
-                        *reinterpret_cast<f32x4*>(tqv + (8 * i + sub) * LIVE_RS + piece * 4) = nq[i];
+                for (int p_ = 0; p_ < 8; ++p_)
+                    if (t_) {
+                        const int s_ = __builtin_ctzll(t_);
+                        if (pslot == p_) mysrc = s_;
+                        if (lane == s_) { live_ = false; mygrp = p_; }          // taken by this round
+                        t_ &= t_ - 1;
                     }
-                if (hc + 1 < E / 32) {
+                if (lane == 0) ++st_batch;
+                unsigned prow = __shfl(row, mysrc < 0 ? 0 : mysrc), pq = __shfl(qi, mysrc < 0 ? 0 : mysrc);
+                if (mysrc < 0) { prow = 0u; pq = 0u; }          // idle lane groups re-read row 0 / query 0 (cache hits), stored nowhere
+                f32x4 R[16], QV[16];
+                {
+                    const float* rp = a.db + (size_t)prow * E + piece * 4;
+                    const float* qp = a.q + (size_t)pq * E + piece * 4;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if ((lm >> (8 * i)) & 0xffull) {
-                            nr[i] = *reinterpret_cast<const f32x4*>(rsrc[i] + 32 * (hc + 1));
-                            nq[i] = *reinterpret_cast<const f32x4*>(qsrc[i] + 32 * (hc + 1));
-                        }
+                    for (int j = 0; j < 16; ++j) R[j] = *reinterpret_cast<const f32x4*>(rp + 32 * j);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) QV[j] = *reinterpret_cast<const f32x4*>(qp + 32 * j);
                 }
-                wave_lds_sync();
-                f32x4 rv[8], qv[8];
+                // the chain walks the pair's 8 lanes: a 16-float block lives in one quad (4 lanes x float4), element order
+                // (c, g) = component-major across the quad's lanes, so the running sum hops lane g-1 -> g by a quad rotation
+                // (DPP) before every fmaf; all lanes execute every step, the TRUE sum is the one travelling. Between blocks
+                // the true sum is broadcast to the group (one ds_bpermute per 16 elements). No LDS staging.
+                float acc = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    rv[i] = *reinterpret_cast<const f32x4*>(trow + lane * LIVE_RS + 4 * i);
-                    qv[i] = *reinterpret_cast<const f32x4*>(tqv + lane * LIVE_RS + 4 * i);
-                }
+                for (int j = 0; j < 16; ++j)
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
+                    for (int tt = 0; tt < 2; ++tt) {
+                        if (j || tt) acc = __shfl(acc, (lane & ~7) | (tt ? 3 : 7));
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
+                        for (int c = 0; c < 4; ++c)
 #pragma unroll
-                        for (int g_ = 0; g_ < 4; ++g_)
-                            acc = __builtin_fmaf(rv[4 * tt + g_][c], qv[4 * tt + g_][c], acc);
-                wave_lds_sync();
+                            for (int g_ = 0; g_ < 4; ++g_) {
+                                const float rot = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x93, 0xf, 0xf, true));
+                                acc = __builtin_fmaf(R[j][c], QV[j][c], rot);
+                            }
+                    }
+                // lane 7 of every group holds its pair's exact score: back to the lane the pair came from
+                const float res = __shfl(acc, mygrp < 0 ? 0 : 8 * mygrp + 7);
+                if (mygrp >= 0) { myscore = res; scored = true; ++st_resc; }
             }
-            bool ins = false;
-            float e0 = 0.f, dl = 1.f;
-            if (live_ && acc == acc) {
-                const float tex = fkey_inv(__hip_atomic_load(a.tex_key + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                ins = acc >= tex;
-            }
+            // ---- the phase's scores, all lanes at once: list + ladder histogram (the constants come from LDS; the only
+            // dependent fabric round trips of a phase are the counters' returns and the ladder rows)
+            const unsigned kt = lane < a.QA ? __hip_atomic_load(a.tau_key + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const unsigned kx = lane < a.QA ? __hip_atomic_load(a.tex_key + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const bool ins = scored && myscore == myscore && myscore >= fkey_inv(*reinterpret_cast<volatile unsigned*>(ltex + qi));
             if (ins) {
                 ++st_ins;
-                const unsigned pos = atomicAdd(&a.gcnt[qi], 1u);
-                if ((long long)pos < a.cap) a.cand[(size_t)qi * a.cap + pos] = make_uint2(__float_as_uint(acc), row);
-                else *a.overflow = 1u;
-                e0 = a.edge0[qi];
-                dl = a.delta[qi];
-                float x = (acc - e0) / dl;
+                const f32x4 cn = lcon[qi];
+                float x = (myscore - cn.x) / cn.y;
                 x = x < 0.f ? 0.f : (x > (float)(LIVE_NB - 1) ? (float)(LIVE_NB - 1) : x);
                 int b = (int)x;
-                if (b > 0 && !(acc >= fmaf((float)b, dl, e0))) --b;        // the bucket's edge must not exceed the score
-                if (acc >= fmaf((float)b, dl, e0)) atomicAdd(&a.hist[qi * LIVE_NB + b], 1u);
+                if (b > 0 && !(myscore >= fmaf((float)b, cn.y, cn.x))) --b;        // the bucket's edge must not exceed the score
+                if (myscore >= fmaf((float)b, cn.y, cn.x)) atomicAdd(&a.hist[qi * LIVE_NB + b], 1u);
+                const unsigned pos = atomicAdd(&a.gcnt[qi], 1u);
+                if ((long long)pos < a.cap) a.cand[(size_t)qi * a.cap + pos] = make_uint2(__float_as_uint(myscore), row);
+                else *a.overflow = 1u;
             }
-            // ladder: for a few of the queries that just received a row, the highest edge with >= K rows at or above it
+            if (lane < a.QA) { atomicMax(ltau + lane, kt); atomicMax(ltex + lane, kx); }
+            // ladder: for up to four of the queries that just received a row, the highest edge with >= K rows at or above it
             unsigned long long todo = __ballot(ins);
-            for (int round = 0; round < 4 && todo; ++round) {
-                const int src = __builtin_ctzll(todo);
-                const unsigned qs_ = __shfl(qi, src);
-                todo &= ~__ballot(ins && qi == qs_);
-                unsigned v = lane < LIVE_NB ? __hip_atomic_load(a.hist + qs_ * LIVE_NB + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            unsigned lq[4];
+            unsigned hv[4];
+            int nl = 0;
 #pragma unroll
-                for (int o = 1; o < LIVE_NB; o <<= 1) {
-                    const unsigned t_ = __shfl_down(v, o);
-                    if (lane + o < LIVE_NB) v += t_;
-                }
-                const unsigned long long okm = __ballot(lane < LIVE_NB && v >= (unsigned)a.K);
-                if (okm && lane == 0) {
-                    const int bmax = 63 - __builtin_clzll(okm);
-                    const float tnew = fmaf((float)bmax, a.delta[qs_], a.edge0[qs_]);
-                    ++st_rise;
-                    const unsigned nk = fkey((tnew - a.qmeta[3 * COARSE_QS + qs_]) * a.qmeta[qs_]);
-                    atomicMax(a.tex_key + qs_, fkey(tnew));
-                    atomicMax(a.tau_key + qs_, nk);
-                    atomicMax(ltau + qs_, nk);
+            for (int r_ = 0; r_ < 4; ++r_) {
+                lq[r_] = 0u;
+                hv[r_] = 0u;
+                if (todo) {
+                    const int src = __builtin_ctzll(todo);
+                    lq[r_] = __shfl(qi, src);
+                    todo &= ~__ballot(ins && qi == lq[r_]);
+                    hv[r_] = lane < LIVE_NB ? __hip_atomic_load(a.hist + lq[r_] * LIVE_NB + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    nl = r_ + 1;
                 }
             }
+#pragma unroll
+            for (int r_ = 0; r_ < 4; ++r_)
+                if (r_ < nl) {
+                    unsigned v = hv[r_];
+#pragma unroll
+                    for (int o = 1; o < LIVE_NB; o <<= 1) {
+                        const unsigned t2 = __shfl_down(v, o);
+                        if (lane + o < LIVE_NB) v += t2;
+                    }
+                    const unsigned long long okm = __ballot(lane < LIVE_NB && v >= (unsigned)a.K);
+                    if (okm && lane == 0) {
+                        const int bmax = 63 - __builtin_clzll(okm);
+                        const f32x4 cn = lcon[lq[r_]];
+                        const float tnew = fmaf((float)bmax, cn.y, cn.x);
+                        const unsigned nk = fkey((tnew - cn.w) * cn.z), nx = fkey(tnew);
+                        if (nx > *reinterpret_cast<volatile unsigned*>(ltex + lq[r_])) {
+                            ++st_rise;
+                            atomicMax(a.tex_key + lq[r_], nx);
+                            atomicMax(a.tau_key + lq[r_], nk);
+                            atomicMax(ltex + lq[r_], nx);
+                            atomicMax(ltau + lq[r_], nk);
+                        }
+                    }
+                }
+        }
+        // release the batch in claim order: scanners may then reuse every slot below 64 * ctl[4]
+        if (lane == 0) {
+            int sp = 0;
+            while (vctl[4] != (base >> 6)) {
+                __builtin_amdgcn_s_sleep(2);
+                if (vctl[3] || ++sp > LIVE_SPIN_LIMIT) { *a.overflow = 1u; ctl[3] = 1; break; }
+            }
+            ctl[4] = (base >> 6) + 1;
         }
     }
     if (a.stats) {
@@ -1544,6 +1606,8 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
         if (lane == 0) {
             atomicAdd(a.stats + 2, st_pop); atomicAdd(a.stats + 3, st_stale); atomicAdd(a.stats + 4, st_resc);
             atomicAdd(a.stats + 5, st_ins); atomicAdd(a.stats + 6, st_batch); atomicAdd(a.stats + 7, st_rise);
+            atomicMax(a.stats + 9, (unsigned)(wall_clock64() - t_begin));
+            atomicAdd(a.stats + 11, st_phase);
         }
     }
 }
@@ -2012,7 +2076,7 @@ int launch_coarse(const CoarseArgs& a, long long nsteps, hipStream_t st, hipEven
     return 0;
 }
 
-constexpr int COARSE_CTL = 2 * COARSE_Q + 16 + COARSE_Q * LIVE_NB;     // fallback counters | coarse counters | overflow flag + 12 live-scan statistics | ladder
+constexpr int COARSE_CTL = 2 * COARSE_Q + 32 + COARSE_Q * LIVE_NB;     // fallback counters | coarse counters | overflow flag + 28 live-scan statistics | ladder
 struct CoarseWs {
     uint2* cand_e; uint2* cand_c; unsigned* gcnt_e; unsigned* gcnt_c; float* thr0; float* tauc; unsigned* flag;
     unsigned* last_m; float* qmeta; uint4* qimage;
@@ -2033,7 +2097,7 @@ size_t carve_coarse(const Plan& p, void* base, size_t cap, CoarseWs* w) {
     x.gcnt_e = ar.take<unsigned>(COARSE_CTL);          // one control block, cleared by coarse_prep_kernel
     x.gcnt_c = x.gcnt_e + COARSE_Q;
     x.flag = x.gcnt_e + 2 * COARSE_Q;
-    x.hist = x.flag + 16;
+    x.hist = x.flag + 32;
     x.live_keys = ar.take<unsigned>(2 * COARSE_Q);
     x.live_edges = ar.take<float>(2 * COARSE_Q);
     x.thr0 = ar.take<float>(COARSE_Q);
@@ -2173,16 +2237,28 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             la.dbc = static_cast<const signed char*>(dbh_dev); la.rmeta = rmeta; la.db = static_cast<const float*>(db_dev);
             la.q = qg; la.qmeta = w.qmeta; la.qimage = w.qimage; la.nrows = N; la.QA = qa; la.K = K;
             la.tau_key = w.live_keys; la.tex_key = w.live_keys + COARSE_Q; la.edge0 = w.live_edges; la.delta = w.live_edges + COARSE_Q;
-            la.hist = w.hist; la.cand = w.cand_c; la.gcnt = w.gcnt_c; la.cap = COARSE_CAP; la.overflow = w.flag; la.stats = w.flag + 4;
+            la.hist = w.hist; la.cand = w.cand_c; la.gcnt = w.gcnt_c; la.cap = COARSE_CAP; la.overflow = w.flag; la.chunk_ctr = w.flag + 1;
+            static const bool live_stats = getenv("CLIPMI_LIVE_STATS") != nullptr;
+            la.stats = live_stats ? w.flag + 4 : nullptr;
+            static const int live_abl = [] { const char* e = getenv("CLIPMI_LIVE_ABL"); return e ? atoi(e) : 0; }();
+            la.abl = live_abl;
             const int QGl = qa <= 16 ? 1 : qa <= 32 ? 2 : 4;
-            size_t lds = (size_t)QGl * 8 * 1024 + (size_t)LIVE_QN * 8 + 64 + 256 + (size_t)4 * 2 * 64 * LIVE_RS * 4;
+            size_t lds = (size_t)QGl * 8 * 1024 + (size_t)LIVE_QN * 8 + 64 + 512 + 1024;
             if (lds < (size_t)COARSE_MAIN_LDS) lds = COARSE_MAIN_LDS;           // as the segmented form's last segment
             const void* fn = QGl == 1 ? (const void*)scan_coarse_live_kernel<1> : QGl == 2 ? (const void*)scan_coarse_live_kernel<2>
                                                                                            : (const void*)scan_coarse_live_kernel<4>;
             if (int rc = opt_in_lds(fn, lds)) return rc;
             long long g_ = ((N + 31) / 32 + 3) / 4;
             const int grid = (int)(g_ < NUM_CU ? g_ : NUM_CU);
+            static const int live_nscan = [] { const char* e = getenv("CLIPMI_LIVE_NSCAN"); return e ? atoi(e) : 4; }();
             if (scan_ev) (void)hipEventRecord(scan_ev[0], st);
+            if (QGl == 4 && live_nscan == 5) {
+                if (int rc = opt_in_lds((const void*)scan_coarse_live_kernel<4, 5>, lds)) return rc;
+                hipLaunchKernelGGL((scan_coarse_live_kernel<4, 5>), dim3(grid), dim3(512), lds, st, la);
+            } else if (QGl == 4 && live_nscan == 6) {
+                if (int rc = opt_in_lds((const void*)scan_coarse_live_kernel<4, 6>, lds)) return rc;
+                hipLaunchKernelGGL((scan_coarse_live_kernel<4, 6>), dim3(grid), dim3(512), lds, st, la);
+            } else
             if (QGl == 1) hipLaunchKernelGGL(scan_coarse_live_kernel<1>, dim3(grid), dim3(512), lds, st, la);
             else if (QGl == 2) hipLaunchKernelGGL(scan_coarse_live_kernel<2>, dim3(grid), dim3(512), lds, st, la);
             else hipLaunchKernelGGL(scan_coarse_live_kernel<4>, dim3(grid), dim3(512), lds, st, la);
@@ -2514,10 +2590,13 @@ static int dbg_coarse_scan_ms(const void* db_dev, const void* db_bf16_dev, bool 
     if (rc == 0) *scan_ms = (float)(total / reps);
     if (rc == 0 && getenv("CLIPMI_LIVE_STATS")) {
         Plan p; CoarseWs w; coarse_plan(N, E, Q, K, p); carve_coarse(p, ws_dev, ws_bytes, &w);
-        unsigned h[12];
-        if (hipMemcpy(h, w.flag + 4, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
-            fprintf(stderr, "live scan (last call): pushed %u (push spins %u) popped %u stale %u re-scored %u inserted %u batches %u ladder rises %u overflow-flag-read-separately\n",
-                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+        unsigned h[28];
+        if (hipMemcpy(h, w.flag + 4, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "scanner wave time, mean us: matrix loop (incl. waiting for rows) %.1f | bounds + compare %.1f | push %.1f\n",
+                    h[12] * 16 * 0.01 / (h[15] ? h[15] : 1), h[13] * 16 * 0.01 / (h[15] ? h[15] : 1), h[14] * 16 * 0.01 / (h[15] ? h[15] : 1));
+            fprintf(stderr, "live scan (last call): pushed %u (push spins %u) popped %u stale %u re-scored %u inserted %u rounds %u (phases %u) ladder rises %u | last scanner wave done at %.1f us (mean %.1f), last re-scoring wave at %.1f us\n",
+                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[11], h[7], h[8] * 0.01, h[10] * 1024.0 * 0.01 / (h[15] ? h[15] : 1), h[9] * 0.01);
+        }
     }
     if (rc == 0 && survivors) {       // rows that survived the coarse pass, summed over the Q queries of the last call
         Plan p;
