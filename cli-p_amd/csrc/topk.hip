@@ -2530,6 +2530,69 @@ extern "C" int clipmi_quantize_rows_i8(const float* db_dev, int64_t N, int E, vo
     return 0;
 }
 
+// ---- build-side helpers of the coarse copies (index load time, reference build-index.py:75-89 / query-index.py:60-75:
+// the vectors are read once and kept): the bounds the coarse passes need and the bf16 copy, computed on the device by
+// the library itself (r02 did these with framework tensor ops).
+// stats2[0] = largest row norm, accumulated in f64 and rounded UP to f32 (a valid `rmax`); stats2[1] = largest a_r of
+// the int8 copy's row meta (0 when meta is null). Non-negative floats order as their bit patterns: atomicMax on uint.
+__global__ void __launch_bounds__(256) rows_stats_kernel(const float* __restrict__ db, long long N, int E, const float2* __restrict__ meta,
+                                                         unsigned* __restrict__ stats2) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    float best = 0.f, abest = 0.f;
+    for (long long r = wave0; r < N; r += nw) {
+        const float* row = db + (size_t)r * E;
+        double acc = 0.0;
+        for (int k = lane * 4; k < E; k += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + k);
+            acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+        const double nd = sqrt(acc);
+        float nf = (float)nd;
+        if ((double)nf < nd) nf = nextafterf(nf, INFINITY);
+        best = nf > best ? nf : best;
+        if (meta && lane == 0) {
+            const float a_ = meta[r].y;
+            abest = a_ > abest ? a_ : abest;
+        }
+    }
+    if (lane == 0) {
+        atomicMax(stats2, __float_as_uint(best));
+        if (meta) atomicMax(stats2 + 1, __float_as_uint(abest));
+    }
+}
+
+__global__ void __launch_bounds__(256) rows_to_bf16_kernel(const float* __restrict__ db, long long n4, uint2* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(db)[i];
+        out[i] = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
+    }
+}
+
+extern "C" int clipmi_rows_stats(const float* db_dev, int64_t N, int E, const float* meta_dev, float* stats2_dev, void* stream) {
+    if (!db_dev || !stats2_dev || N < 1 || E < 4 || E % 4 != 0)
+        return set_err(CLIPMI_EINVAL, "rows_stats: bad arguments (N=%lld E=%d; E must be a multiple of 4)", (long long)N, E);
+    if (hipMemsetAsync(stats2_dev, 0, 2 * sizeof(float), as_stream(stream)) != hipSuccess) return set_err(CLIPMI_EHIP, "rows_stats: memset");
+    const long long want = (N + 3) / 4;
+    const unsigned grid = (unsigned)(want < 8 * NUM_CU ? want : 8 * NUM_CU);
+    hipLaunchKernelGGL(rows_stats_kernel, dim3(grid), dim3(256), 0, as_stream(stream), db_dev, (long long)N, E,
+                       reinterpret_cast<const float2*>(meta_dev), reinterpret_cast<unsigned*>(stats2_dev));
+    CLIPMI_CHECK_LAUNCH("rows_stats_kernel");
+    return 0;
+}
+
+extern "C" int clipmi_rows_to_bf16(const float* db_dev, int64_t N, int E, void* out_bf16_dev, void* stream) {
+    if (!db_dev || !out_bf16_dev || N < 1 || E < 4 || E % 4 != 0)
+        return set_err(CLIPMI_EINVAL, "rows_to_bf16: bad arguments (N=%lld E=%d; E must be a multiple of 4)", (long long)N, E);
+    const long long n4 = (long long)N * E / 4, want = (n4 + 255) / 256;
+    const unsigned grid = (unsigned)(want < 16 * NUM_CU ? want : 16 * NUM_CU);
+    hipLaunchKernelGGL(rows_to_bf16_kernel, dim3(grid), dim3(256), 0, as_stream(stream), db_dev, n4, static_cast<uint2*>(out_bf16_dev));
+    CLIPMI_CHECK_LAUNCH("rows_to_bf16_kernel");
+    return 0;
+}
+
 extern "C" int clipmi_topk_ip_coarse_i8(const void* db_dev, const void* db_i8_dev, const float* meta_dev, float amax, int64_t N,
                                         int E, float rmax, const float* q_dev, int Q, int K, int64_t id_base,
                                         float* out_score_dev, int64_t* out_id_dev, void* ws_dev, size_t ws_bytes, void* stream) {

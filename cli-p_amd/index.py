@@ -117,32 +117,38 @@ class IndexFlatIP:
         return self._db
 
     def matrix_bf16(self):
-        """(bf16 copy [N][d], upper bound of the largest row norm) for the coarse path; built once."""
+        """(bf16 copy [N][d], upper bound of the largest row norm) for the coarse path; built once (clipmi_rows_to_bf16)."""
         if self._dbh is None:
             db = self.matrix()
             dbh = torch.empty(db.shape, dtype=torch.bfloat16, device=db.device)
-            rmax = 0.0
-            step = 1 << 20
-            for lo in range(0, db.shape[0], step):
-                blk = db[lo:lo + step]
-                dbh[lo:lo + step] = blk.to(torch.bfloat16)
-                rmax = max(rmax, float(torch.linalg.vector_norm(blk, dim=1).max()))
-            self._dbh, self._rmax = dbh, rmax * (1.0 + 1e-6)
+            if db.shape[0]:
+                _lib.check(_lib.lib().clipmi_rows_to_bf16(db.data_ptr(), db.shape[0], self.d, dbh.data_ptr(),
+                                                          _lib.stream_ptr(self.device)), "clipmi_rows_to_bf16")
+            self._dbh = dbh
         return self._dbh, self._row_norm_max()
+
+    def _stats(self, meta=None):
+        """(largest row norm, largest error norm of the int8 copy's meta) by clipmi_rows_stats, each with a 1e-6 margin."""
+        db = self.matrix()
+        if db.shape[0] == 0:
+            return 0.0, 0.0
+        if self.device.type != "cuda":
+            raise _lib.ClipmiError("the coarse copies need the HIP path (device is not a GPU); no CPU fallback")
+        out = torch.empty(2, dtype=torch.float32, device=db.device)
+        _lib.check(_lib.lib().clipmi_rows_stats(db.data_ptr(), db.shape[0], self.d, meta.data_ptr() if meta is not None else None,
+                                                out.data_ptr(), _lib.stream_ptr(self.device)), "clipmi_rows_stats")
+        rmax, amax = (float(v) for v in out.cpu())
+        return rmax * (1.0 + 1e-6), amax * (1.0 + 1e-6)
 
     def _row_norm_max(self):
         if self._rmax is None:
-            db = self.matrix()
-            rmax, step = 0.0, 1 << 20
-            for lo in range(0, db.shape[0], step):
-                rmax = max(rmax, float(torch.linalg.vector_norm(db[lo:lo + step], dim=1).max()))
-            self._rmax = rmax * (1.0 + 1e-6)
+            self._rmax = self._stats()[0]
         return self._rmax
 
     def matrix_i8(self):
         """(int8 copy in 32-row blocks of [d / 32][64][16 B] - include/clipmi.h clipmi_quantize_rows_i8 -, f32 meta:
         (block scale, error norm) per row padded to 32 rows (+32) then (scale, largest error norm) per block, largest
-        error norm, largest row norm) for the int8 coarse path; built once by clipmi_quantize_rows_i8."""
+        error norm, largest row norm) for the int8 coarse path; built once by clipmi_quantize_rows_i8 + clipmi_rows_stats."""
         if self._db8 is None:
             L = _lib.lib()
             db = self.matrix()
@@ -151,7 +157,7 @@ class IndexFlatIP:
             meta = torch.zeros(L.clipmi_i8_meta_bytes(N) // 4, dtype=torch.float32, device=db.device)
             _lib.check(L.clipmi_quantize_rows_i8(db.data_ptr(), N, self.d, q8.data_ptr(), meta.data_ptr(),
                                                  _lib.stream_ptr(self.device)), "clipmi_quantize_rows_i8")
-            amax = float(meta[1:2 * N:2].max()) * (1.0 + 1e-6)
+            self._rmax, amax = self._stats(meta)
             self._db8 = (q8, meta, amax)
         return self._db8 + (self._row_norm_max(),)
 

@@ -175,6 +175,12 @@ int clipmi_topk_ip_coarse(const void* db_dev, const void* db_bf16_dev, int64_t N
  * copy (v_mfma_i32_16x16x64_i8, HBM-bound); MORE than 64 queries (query-index.py:111 is one call whatever Q) are taken
  * in chunks of <= 1024 as ONE pass each (v_mfma_i32_32x32x32_i8, query tiles of 256 resident in LDS, matrix-bound).
  * Workspace: clipmi_topk_ip_coarse_workspace_bytes. */
+/* Build-side helpers of the coarse copies (index load: query-index.py:60-75 reads every vector once and keeps the
+ * matrix). clipmi_rows_stats writes stats2_dev[0] = the largest row norm of db (f64 accumulation, rounded up: a valid
+ * `rmax`) and stats2_dev[1] = the largest a_r of an int8 copy's meta (`meta_dev` may be NULL: 0). clipmi_rows_to_bf16
+ * writes the bf16 copy (round to nearest even) clipmi_topk_ip_coarse scans. E a multiple of 4. Asynchronous on `stream`. */
+int clipmi_rows_stats(const float* db_dev, int64_t N, int E, const float* meta_dev, float* stats2_dev, void* stream);
+int clipmi_rows_to_bf16(const float* db_dev, int64_t N, int E, void* out_bf16_dev, void* stream);
 size_t clipmi_i8_copy_bytes(int64_t N, int E);
 size_t clipmi_i8_meta_bytes(int64_t N);
 int clipmi_quantize_rows_i8(const float* db_dev, int64_t N, int E, void* out_i8_dev, float* meta_dev, void* stream);

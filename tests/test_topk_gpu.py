@@ -537,6 +537,39 @@ def test_quantize_rows_i8_matches_numpy(clipmi, gpu):
     assert amax >= rmeta[:, 1].max() and rmax >= np.linalg.norm(x, axis=1).max()
 
 
+def test_rows_stats_and_bf16_copy_match_numpy(clipmi, gpu):
+    """clipmi_rows_stats / clipmi_rows_to_bf16 (include/clipmi.h; the index's build side): the largest row norm is an
+    upper bound of the f64 norm within one f32 ulp, the largest error norm is the meta's maximum, the bf16 copy is the
+    round-to-nearest-even conversion (torch's) bit for bit - NaN / inf / denormals included."""
+    rng = np.random.default_rng(83)
+    N = 3001
+    x = (unit_rows(rng, N, 512) * rng.uniform(0.05, 7.0, size=(N, 1))).astype(np.float32)
+    x[5, :4] = [np.float32(1e-40), np.float32(-1e-40), 0.0, np.float32(3.3895e38)]
+    idx = clipmi.IndexFlatIP(512, device=gpu, coarse="int8")
+    idx.add(x)
+    q8, meta, amax, rmax = idx.matrix_i8()
+    torch.cuda.synchronize()
+    true = np.sqrt((x.astype(np.float64) ** 2).sum(axis=1)).max()
+    assert rmax >= true and rmax <= float(np.nextafter(np.float32(true), np.float32(np.inf))) * (1 + 2e-6)
+    a_all = meta.cpu().numpy()[:2 * N].reshape(-1, 2)[:, 1]
+    assert amax >= a_all.max() and amax <= float(a_all.max()) * (1 + 2e-6)
+    y = x.copy()
+    y[9, 0], y[9, 1], y[9, 2] = np.nan, np.inf, -np.inf
+    idb = clipmi.IndexFlatIP(512, device=gpu, coarse="bf16")
+    idb.add(y)
+    dbh, _ = idb.matrix_bf16()
+    want = torch.from_numpy(y).to(torch.bfloat16)
+    got = dbh.cpu()
+    nan = torch.isnan(want)
+    assert torch.equal(torch.isnan(got), nan)                       # (a NaN's payload is not part of the contract)
+    bad = (got.view(torch.int16) != want.view(torch.int16)) & ~nan
+    assert not bad.any(), (torch.from_numpy(y)[bad][:8], got[bad][:8], want[bad][:8])
+    out = torch.empty(2, dtype=torch.float32, device=gpu)
+    L = clipmi._lib.lib()
+    assert L.clipmi_rows_stats(idx.matrix().data_ptr(), N, 510, None, out.data_ptr(), None) != 0      # E % 4 != 0
+    assert b"multiple of 4" in L.clipmi_last_error()
+
+
 @pytest.mark.parametrize("N", [10_000_000, 12_500_000])
 def test_full_size_10m_properties(clipmi, gpu, topk_oracle, N):
     """BASELINE.json's full sizes (configs[1]/[2]: 10 M x 512; configs[4]: 12.5 M rows = one rank's share of the
