@@ -1153,7 +1153,7 @@ constexpr int LIVE_NB = 32;                      // ladder buckets per query
 constexpr int LIVE_QN = 4096;                    // ring entries (32 KiB)
 constexpr unsigned LIVE_EMPTY = 0xffffffffu;
 constexpr int LIVE_ROW_BITS = 26;                // ring entry .y = (query << 26) | row: shards of < 2^26 rows
-constexpr int LIVE_CH = 16;                      // 32-row steps per unit of scanner work
+constexpr int LIVE_WB = 24;                      // 32-row steps per batch of scanner work a workgroup draws (>= its scanner waves)
 constexpr int LIVE_SPIN_LIMIT = 1 << 20;         // polls before a waiting lane gives up (~ tens of ms): overflow -> fallback
 
 __device__ __forceinline__ unsigned fkey(float f) {             // order-preserving key of a float (-0 and +0 differ: harmless)
@@ -1183,6 +1183,7 @@ struct LiveArgs {
     long long cap;
     unsigned* overflow;
     unsigned* chunk_ctr;         // work counter of the scanner waves (zero at launch)
+    int wb;                      // 32-row steps per work batch (>= the scanner waves of a workgroup)
     int abl;                     // development ablation (CLIPMI_LIVE_ABL): 1 scanners push nothing, 2 re-scoring waves drop every pair
     unsigned* stats;             // [12] pushed | push spins | popped | stale | re-scored | inserted | batches | ladder rises
 };
@@ -1204,8 +1205,16 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
     unsigned* ltau = reinterpret_cast<unsigned*>(ctl + 16);                        // [64] this workgroup's copy of the threshold keys
     unsigned* ltex = ltau + 64;                                                    // [64] ... and of the exact thresholds' keys
     f32x4* lcon = reinterpret_cast<f32x4*>(ltex + 64);                             // [64] ladder origin, ladder step, query scale, query slack
+    int* wqb = reinterpret_cast<int*>(lcon + 64);                                  // [8] first step of work batch b (slot b & 7); tags in ctl[8..15]
     for (int i = tid; i < LIVE_QN; i += 512) ring[i] = make_uint2(0u, LIVE_EMPTY);
-    if (tid < 8) ctl[tid] = 0;
+    if (tid < 8) { ctl[tid] = 0; ctl[8 + tid] = tid == 0 ? 0 : -1; }
+    if (tid == 0) {
+        // scanner work: batches of a.wb steps. Batch 0 of a workgroup is its index in the grid, every further one comes from
+        // a counter (zeroed with the call's control words); batch 1 is drawn here, batch b + 2 by the wave that takes the first
+        // step of batch b (ctl[5] = the workgroup's step tickets)
+        wqb[0] = (int)blockIdx.x * a.wb;
+        wqb[1] = (int)(gridDim.x + atomicAdd(a.chunk_ctr, 1u)) * a.wb;
+    }
     if (tid < 64) {
         const bool on = tid < a.QA;
         ltau[tid] = on ? a.tau_key[tid] : 0u;
@@ -1213,6 +1222,7 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
         lcon[tid] = on ? f32x4{a.edge0[tid], a.delta[tid], a.qmeta[tid], a.qmeta[3 * COARSE_QS + tid]} : f32x4{0.f, 1.f, 1.f, 0.f};
     }
     __syncthreads();
+    if (tid == 0) ctl[9] = 1;                       // batch 1's base is in place (written before the barrier)
 
     if (wave < NSCAN) {
         // ------------------------------------------------------------------ scanner
@@ -1224,19 +1234,45 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
             tau[qg] = INFINITY;
             yt[qg] = active[qg] ? a.qmeta[COARSE_QS + qg * 16 + col] : 0.f;
         }
-        // work: chunks of LIVE_CH 32-row steps. The first chunk of a wave is its index in the grid, every further one comes
-        // from a counter (zeroed with the call's control words), requested one chunk ahead: CUs and XCDs stream at different
-        // rates, and with a fixed interleave the last wave finished ~90 us (10 %) after the average one.
+        // work: the workgroup's waves take 32-row steps one by one from its current batch (an LDS ticket); batches come from a
+        // device-wide counter two ahead. CUs and XCDs stream at different rates: with a fixed interleave the last wave finished
+        // ~90 us (10 %) after the average one; per-wave draws from the counter queue a slow returning atomic in front of the
+        // wave's row loads (vmcnt is in order) - here a wave publishes the batch it drew at its NEXT visit.
         const long long nsteps = (a.nrows + 31) >> 5;
-        const long long nchunks = (nsteps + LIVE_CH - 1) / LIVE_CH;
-        const long long tw = (long long)gridDim.x * NSCAN;
-        long long step = ((long long)blockIdx.x * NSCAN + wave) * LIVE_CH;
-        int in_chunk = 0;
+        int pend_b = -1;
         unsigned grabbed = 0u;
-        if (lane == 0) grabbed = atomicAdd(a.chunk_ctr, 1u);
+        auto take = [&]() -> long long {
+            if (pend_b >= 0) {
+                if (lane == 0) {
+                    wqb[pend_b & 7] = (int)(gridDim.x + grabbed) * a.wb;
+                    *reinterpret_cast<volatile int*>(&ctl[8 + (pend_b & 7)]) = pend_b;
+                }
+                pend_b = -1;
+            }
+            int t_ = 0;
+            if (lane == 0) t_ = atomicAdd(&ctl[5], 1);
+            t_ = __builtin_amdgcn_readfirstlane(t_);
+            const int b_ = t_ / a.wb, o_ = t_ - b_ * a.wb;
+            if (o_ == 0) {
+                if (lane == 0) grabbed = atomicAdd(a.chunk_ctr, 1u);
+                pend_b = b_ + 2;
+            }
+            int sp_ = 0;
+            while (*reinterpret_cast<volatile int*>(&ctl[8 + (b_ & 7)]) != b_) {
+                __builtin_amdgcn_s_sleep(2);
+                if (*reinterpret_cast<volatile int*>(&ctl[3]) || ++sp_ > LIVE_SPIN_LIMIT) {
+                    *a.overflow = 1u;                      // the exact fallback answers
+                    ctl[3] = 1;
+                    return -1;
+                }
+            }
+            const long long s_ = (long long)*reinterpret_cast<volatile int*>(&wqb[b_ & 7]) + o_;
+            return s_ < nsteps ? s_ : -1;
+        };
+        long long step = take();
         unsigned st_push = 0, st_spin = 0, tm_a = 0, tm_b = 0, tm_c = 0;
         const bool timed = a.stats != nullptr;
-        if (step < nsteps) {
+        if (step >= 0) {
             uint4 T[SLOTS];
             auto frag_ptr = [&](long long st, int rt) {
                 return reinterpret_cast<const char*>(a.dbc) + st * (32 * ROWB) + (g >> 1) * 1024 + ((g & 1) * 32 + rt * 16 + col) * 16;
@@ -1283,16 +1319,8 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
                     }
                 }
                 ++it;
-                long long nxt = step + 1;
-                bool has_next = true;
-                int in_next = in_chunk + 1;
-                if (in_next == LIVE_CH || nxt >= nsteps) {
-                    const long long c_ = (long long)__builtin_amdgcn_readfirstlane(grabbed) + tw;
-                    has_next = c_ < nchunks;
-                    nxt = c_ * LIVE_CH;
-                    in_next = 0;
-                    if (has_next && lane == 0) grabbed = atomicAdd(a.chunk_ctr, 1u);
-                }
+                const long long nxt = take();
+                const bool has_next = nxt >= 0;
                 const char* pn[2] = {frag_ptr(has_next ? nxt : step, 0), frag_ptr(has_next ? nxt : step, 1)};
                 uint4 MN[4];
                 load_meta(has_next ? nxt : step, MN);
@@ -1403,7 +1431,6 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
                 if (timed) { wave_lds_sync(); tm_c += (unsigned)(wall_clock64() - tk2); }
                 if (!has_next) break;
                 step = nxt;
-                in_chunk = in_next;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) M[i] = MN[i];
             }
@@ -2238,19 +2265,21 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             la.q = qg; la.qmeta = w.qmeta; la.qimage = w.qimage; la.nrows = N; la.QA = qa; la.K = K;
             la.tau_key = w.live_keys; la.tex_key = w.live_keys + COARSE_Q; la.edge0 = w.live_edges; la.delta = w.live_edges + COARSE_Q;
             la.hist = w.hist; la.cand = w.cand_c; la.gcnt = w.gcnt_c; la.cap = COARSE_CAP; la.overflow = w.flag; la.chunk_ctr = w.flag + 1;
+            static const int live_wb = [] { const char* e = getenv("CLIPMI_LIVE_WB"); const int v = e ? atoi(e) : LIVE_WB; return v < 8 ? 8 : v; }();
+            la.wb = live_wb;
             static const bool live_stats = getenv("CLIPMI_LIVE_STATS") != nullptr;
             la.stats = live_stats ? w.flag + 4 : nullptr;
             static const int live_abl = [] { const char* e = getenv("CLIPMI_LIVE_ABL"); return e ? atoi(e) : 0; }();
             la.abl = live_abl;
             const int QGl = qa <= 16 ? 1 : qa <= 32 ? 2 : 4;
-            size_t lds = (size_t)QGl * 8 * 1024 + (size_t)LIVE_QN * 8 + 64 + 512 + 1024;
+            size_t lds = (size_t)QGl * 8 * 1024 + (size_t)LIVE_QN * 8 + 64 + 512 + 1024 + 64;
             if (lds < (size_t)COARSE_MAIN_LDS) lds = COARSE_MAIN_LDS;           // as the segmented form's last segment
             const void* fn = QGl == 1 ? (const void*)scan_coarse_live_kernel<1> : QGl == 2 ? (const void*)scan_coarse_live_kernel<2>
                                                                                            : (const void*)scan_coarse_live_kernel<4>;
             if (int rc = opt_in_lds(fn, lds)) return rc;
             long long g_ = ((N + 31) / 32 + 3) / 4;
             const int grid = (int)(g_ < NUM_CU ? g_ : NUM_CU);
-            static const int live_nscan = [] { const char* e = getenv("CLIPMI_LIVE_NSCAN"); return e ? atoi(e) : 4; }();
+            static const int live_nscan = [] { const char* e = getenv("CLIPMI_LIVE_NSCAN"); return e ? atoi(e) : 6; }();
             if (scan_ev) (void)hipEventRecord(scan_ev[0], st);
             if (QGl == 4 && live_nscan == 5) {
                 if (int rc = opt_in_lds((const void*)scan_coarse_live_kernel<4, 5>, lds)) return rc;
