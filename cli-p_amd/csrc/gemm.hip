@@ -1,6 +1,7 @@
 // gemm.hip — instantiation and launch of the bf16 NT GEMM (see gemm.hpp).
 #include "gemm256p.hpp"
 #include "gemm_skinny.hpp"
+#include "gemm2w.hpp"
 #include "gemm256f8.hpp"
 #include <hip/hip_ext.h>
 #include <cstdlib>
@@ -135,6 +136,21 @@ static int launch_skinny(const GemmArgs& g, int epi, hipStream_t st) {
     return set_err(CLIPMI_EINVAL, "gemm_skinny: epilogue %d", epi);
 }
 
+// the residual producer as two co-resident workgroups per CU (gemm2w.hpp)
+static bool g2w_ok(const GemmArgs& g) { return g.N % 256 == 0 && g.N <= 1024 && g.K % 32 == 0 && g.K >= 64 && g.M >= 1; }
+static int launch_g2w(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
+    static thread_local int opted[64];
+    if (!lds_opted(opted)) {
+        if (hipFuncSetAttribute((const void*)gemm2w_resid_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G2W_LDS) != hipSuccess)
+            return set_err(CLIPMI_EHIP, "hipFuncSetAttribute(gemm2w, %d B LDS)", G2W_LDS);
+    }
+    const int grid = (g.N / 256) * ((g.M + 127) / 128);
+    (void)probe;
+    hipLaunchKernelGGL(gemm2w_resid_ln_kernel, dim3(grid), dim3(256), G2W_LDS, st, g);
+    CLIPMI_CHECK_LAUNCH("gemm2w_resid_ln_kernel");
+    return 0;
+}
+
 // algo: 0 = choose by shape, 1 = force the 128x128 kernel, 2 = force the 256x256 kernel,
 //       3 = force the persistent 256x256 kernel
 int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmProbe* probe) {
@@ -144,6 +160,14 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmP
         (!g.xhi || !g.xlo || !g.ln_part || !g.tmp_f32 || g.N % 256 != 0 || g.N > 1024 ||
          (const char*)g.xlo < (const char*)g.xhi || (const char*)g.xlo - (const char*)g.xhi >= (1ll << 31) - (long long)256 * g.N * 2))
         return set_err(CLIPMI_EINVAL, "gemm: EPI_BIAS_RESID_LN_F32 needs xhi <= xlo < xhi + 2 GiB, ln_part, tmp_f32 and N %% 256 == 0, N <= 1024");
+    if (algo == 4) {
+        if (epi != EPI_BIAS_RESID_LN_F32 || !g2w_ok(g) || !g.A || !g.W)
+            return set_err(CLIPMI_EINVAL, "gemm2w: the residual producer only (N %% 256 == 0, N <= 1024, K %% 32 == 0, K >= 64)");
+        return launch_g2w(g, st, probe);
+    }
+    // development A/B: CLIPMI_GEMM_G2W=<max K> sends the residual producer with K <= that to gemm2w (measured slower: DESIGN 4.4g)
+    static const int g2w_maxk = [] { const char* e = getenv("CLIPMI_GEMM_G2W"); return e ? atoi(e) : 0; }();
+    if (algo == 0 && epi == EPI_BIAS_RESID_LN_F32 && g.K <= g2w_maxk && g.M >= 1024 && g2w_ok(g)) return launch_g2w(g, st, probe);
     const bool ok256 = g.N % 256 == 0 && g.K % 64 == 0 && g.K >= 128;
     if (algo == 2 && !ok256) return set_err(CLIPMI_EINVAL, "gemm256: N=%d K=%d (need N %% 256 == 0, K %% 64 == 0, K >= 128)", g.N, g.K);
     const bool store_only = epi == EPI_BIAS_BF16 || epi == EPI_BIAS_QGELU_BF16 || epi == EPI_BIAS_RESID_F32 || epi_is_ln(epi) ||
@@ -343,7 +367,8 @@ extern "C" int clipmi_dbg_gemm_resid_ln(const void* a_dev, const void* w_dev, co
     g.xhi = static_cast<unsigned short*>(xhi_dev); g.xlo = static_cast<unsigned short*>(xlo_dev);
     g.ln_part = part_dev; g.tmp_f32 = tmp_dev;
     g.M = M; g.N = N; g.K = K;
-    return launch_gemm_algo(g, EPI_BIAS_RESID_LN_F32, algo & 3, as_stream(stream));
+    if (const char* e = getenv("CLIPMI_GEMM_DBG")) g.dbg = atoi(e);
+    return launch_gemm_algo(g, EPI_BIAS_RESID_LN_F32, algo & 7, as_stream(stream));
 }
 
 extern "C" int clipmi_dbg_gemm_fp8(const void* a8_dev, const void* w8_dev, const float* a_scale_dev, const float* w_scale_dev,

@@ -20,9 +20,12 @@ for (M, N, K) in ((43500, 768, 768), (43500, 768, 3072)):
     def rln():
         clipmi._lib.check(L.clipmi_dbg_gemm_resid_ln(a.data_ptr(), w.data_ptr(), bias.data_ptr(), hl[0].data_ptr(), hl[1].data_ptr(),
                                                      part.data_ptr(), tmp.data_ptr(), M, N, K, 3, None), "rln")
-    res = {"plain": [], "rln": []}
+    def g2w():
+        clipmi._lib.check(L.clipmi_dbg_gemm_resid_ln(a.data_ptr(), w.data_ptr(), bias.data_ptr(), hl[0].data_ptr(), hl[1].data_ptr(),
+                                                     part.data_ptr(), tmp.data_ptr(), M, N, K, 4, None), "g2w")
+    res = {"plain": [], "rln": [], "g2w": []}
     for rnd in range(5):
-        for name, fn in (("plain", plain), ("rln", rln)):
+        for name, fn in (("plain", plain), ("rln", rln), ("g2w", g2w)):
             for _ in range(3): fn()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,4 +34,4 @@ for (M, N, K) in ((43500, 768, 768), (43500, 768, 3072)):
             e1.record(); torch.cuda.synchronize()
             res[name].append(e0.elapsed_time(e1) / 20 * 1e3)
             x.zero_(); hl.zero_()
-    print(f"M={M} N={N} K={K}: plain {min(res['plain']):.1f} us   split-residual + stats {min(res['rln']):.1f} us", flush=True)
+    print(f"M={M} N={N} K={K}: plain {min(res['plain']):.1f} us   split-residual + stats {min(res['rln']):.1f} us   two workgroups per CU {min(res['g2w']):.1f} us", flush=True)
