@@ -279,11 +279,34 @@ static int launch_epi256f8(const GemmArgs& g, hipStream_t st) {
     return 0;
 }
 
+// block-scaled activations (gemm256f8.hpp BSA): the tile's 256 x K/32 scale bytes sit behind the K-tile buffers
+constexpr int G256F8_BSA_MAX_K = 4096;           // 32 KiB of scale bytes per tile: 160 KiB of LDS in all
+template <int EPI>
+static int launch_epi256f8_bsa(const GemmArgs& g, hipStream_t st) {
+    const int grid = (g.N / 256) * ((g.M + 255) / 256);
+    const int lds = G256_LDS + 256 * (g.K / 32);
+    static thread_local int opted[64];
+    if (!lds_opted(opted)) {
+        if (hipFuncSetAttribute((const void*)gemm256f8_nt_kernel<EPI, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G256_LDS + 256 * (G256F8_BSA_MAX_K / 32)) != hipSuccess)
+            return set_err(CLIPMI_EHIP, "hipFuncSetAttribute(gemm256f8 block-scaled)");
+    }
+    hipLaunchKernelGGL((gemm256f8_nt_kernel<EPI, true, true>), dim3(grid), dim3(512), lds, st, g);
+    CLIPMI_CHECK_LAUNCH("gemm256f8_nt_kernel(block-scaled A)");
+    return 0;
+}
+
 // mx: 1 = the block-scaled MFMA form with unit scales (twice the rate), 0 = plain FP8 MFMA (f32 accumulation)
 int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st, int mx) {
     if (g.M < 1 || g.N % 256 != 0 || g.K % 128 != 0 || g.K < 256)
         return set_err(CLIPMI_EINVAL, "gemm_fp8: M=%d N=%d K=%d (need N %% 256 == 0, K %% 128 == 0, K >= 256)", g.M, g.N, g.K);
-    if (!g.A || !g.W || !g.out || !g.a_scale || !g.w_scale) return set_err(CLIPMI_EINVAL, "gemm_fp8: NULL pointer");
+    if (!g.A || !g.W || !g.out || (!g.a_scale && !g.a_bscale) || !g.w_scale) return set_err(CLIPMI_EINVAL, "gemm_fp8: NULL pointer");
+    if (g.a_bscale) {            // MX activations: per-32-block e8m0 scales instead of a row scale
+        if (g.K > G256F8_BSA_MAX_K) return set_err(CLIPMI_EINVAL, "gemm_fp8: block-scaled A needs K <= %d", G256F8_BSA_MAX_K);
+        if (epi == EPI_BIAS_RESID_F32) return launch_epi256f8_bsa<EPI_BIAS_RESID_F32>(g, st);
+        if (epi == EPI_F32) return launch_epi256f8_bsa<EPI_F32>(g, st);
+        return set_err(CLIPMI_EINVAL, "gemm_fp8: block-scaled A with epilogue %d", epi);
+    }
     // more than one round of tiles: the persistent role-split kernel on FP8 operands (mx = 2 keeps gemm256f8 for tests)
     const long long tiles = (long long)(g.N / 256) * ((g.M + 255) / 256);
     if (mx == 1 && tiles > NUM_CU && g.K % 256 == 0 && g.N <= 3840 && persist_mode() != 0) {
@@ -369,6 +392,19 @@ extern "C" int clipmi_dbg_gemm_resid_ln(const void* a_dev, const void* w_dev, co
     g.M = M; g.N = N; g.K = K;
     if (const char* e = getenv("CLIPMI_GEMM_DBG")) g.dbg = atoi(e);
     return launch_gemm_algo(g, EPI_BIAS_RESID_LN_F32, algo & 7, as_stream(stream));
+}
+
+// block-scaled activations: a_bscale_dev = e8m0 bytes [ceil(M / 256) * 256][K / 32]; epi 2 (residual) or 3 (plain f32)
+extern "C" int clipmi_dbg_gemm_fp8_bsa(const void* a8_dev, const void* w8_dev, const void* a_bscale_dev, const float* w_scale_dev,
+                                       const float* bias_dev, void* out_dev, int M, int N, int K, int epi, void* stream) {
+    GemmArgs g{};
+    g.A = static_cast<const unsigned short*>(a8_dev);
+    g.W = static_cast<const unsigned short*>(w8_dev);
+    g.a_bscale = static_cast<const unsigned char*>(a_bscale_dev); g.w_scale = w_scale_dev;
+    g.bias = bias_dev;
+    g.out = out_dev;
+    g.M = M; g.N = N; g.K = K;
+    return launch_gemm_fp8(g, epi, as_stream(stream), 1);
 }
 
 extern "C" int clipmi_dbg_gemm_fp8(const void* a8_dev, const void* w8_dev, const float* a_scale_dev, const float* w_scale_dev,

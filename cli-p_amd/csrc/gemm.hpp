@@ -148,6 +148,9 @@ struct GemmArgs {
     // FP8 path (gemm256f8.hpp): A and W point at e4m3 bytes; per-row / per-output-channel dequantisation scales
     const float* a_scale;      // [M]
     const float* w_scale;      // [N]
+    // block-scaled activations (MX; gemm256f8.hpp BSA): one e8m0 byte per 32 consecutive k, rows padded to 256
+    const unsigned char* a_bscale;   // consumer: [ceil(M / 256) * 256][K / 32]
+    unsigned char* out_bscale;       // producer epilogues that emit e4m3 + block scales: [..][N / 32]
     // LN-folded layers: consumers (EPI_LN_*) read ln_part_in [M][K/256][2] (per-segment sum / sum of squares of the
     // f32 rows whose hi halves are A) and colsum [N] (bias = cb); the producer (EPI_BIAS_RESID_LN_F32) updates the
     // split residual (xhi, xlo) [M][N] bf16 each, xlo - xhi < 2^31 bytes, and writes ln_part [M][N/256][2];

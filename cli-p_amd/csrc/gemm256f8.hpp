@@ -20,8 +20,18 @@ namespace clipmi {
 typedef long i64x2v __attribute__((ext_vector_type(2)));
 typedef int i32x8v __attribute__((ext_vector_type(8)));
 
-template <int EPI, bool MX>
+// BSA ("block-scaled A", round 3): the activations carry one e8m0 scale per 32 consecutive k (the MX format; written by
+// the PRODUCING kernel's epilogue or by quantize_rows_fp8mx_kernel - a row scale would need the whole row before the first
+// byte can be written, a 32-block is local to any column tile) in g.a_bscale [rows padded to 256][K / 32]. The scaled MFMA
+// takes it as its per-lane scale operand, so the block scales cost no
+// matrix cycles; the tile's 256 x K/32 scale bytes arrive once by LDS-DMA behind the K-tile buffers. a_scale is unused.
+// Which k a lane's scale reaches was measured (tools/bsa_probe.py): the instruction orders its 128 k as [first 16 bytes of
+// lane groups 0..3 | second 16 bytes of groups 0..3], cuts THAT into four blocks of 32 and takes block s's scale from lane
+// group s - so with this kernel's fragment layout (a lane holds the 16-byte chunks fg and 4 + fg of the 128-byte row) the
+// hardware's block s is k = 32 s .. 32 s + 31 of the K-tile, and lane (fr, fg) supplies the scale of (row fr, block fg).
+template <int EPI, bool MX, bool BSA = false>
 __global__ void __launch_bounds__(512, 2) gemm256f8_nt_kernel(GemmArgs g) {
+    static_assert(!BSA || MX, "block scales need the scaled MFMA form");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -79,6 +89,19 @@ __global__ void __launch_bounds__(512, 2) gemm256f8_nt_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // BSA: the tile's scale bytes [256][K / 32] behind the K-tile buffers (rows past M: the array is padded to 256 rows)
+    const int KB32 = K >> 5;
+    const unsigned char* slab = reinterpret_cast<const unsigned char*>(smem) + G256_LDS;
+    if (BSA) {
+        const unsigned char* sg = g.a_bscale + (size_t)m0 * KB32 + lane * 16;
+        for (int pc = wave; pc < (KB32 >> 2); pc += 8)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sg + pc * 1024),
+                                             (__attribute__((address_space(3))) void*)(smem + G256_LDS + pc * 1024), 16, 0, 0);
+    }
+    int sb[4] = {0x7f, 0x7f, 0x7f, 0x7f};      // e8m0 scale of this lane's (row, k-block) per mt of the current A half
+    int kt_cur = 0;
+    const int sb_off = (wm * 64 + fr) * KB32 + fg;
+
     i64x2v af[4][2];           // current A half: [mt][16-byte fragment]
     i64x2v bl[2][2], bh[2][2]; // B-lo / B-hi: [nt][16-byte fragment]
 
@@ -86,6 +109,7 @@ __global__ void __launch_bounds__(512, 2) gemm256f8_nt_kernel(GemmArgs g) {
     _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                               \
         af[t_][0] = *reinterpret_cast<const i64x2v*>((base) + (half) * G256_HALF + offA + t_ * 2048 + c0); \
         af[t_][1] = *reinterpret_cast<const i64x2v*>((base) + (half) * G256_HALF + offA + t_ * 2048 + c1); \
+        if (BSA) sb[t_] = slab[sb_off + ((half) * 128 + t_ * 16) * KB32 + kt_cur * 4];               \
     }
 #define G256_READ_B(dst, base, half)                                                                 \
     _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {                                               \
@@ -112,7 +136,7 @@ __global__ void __launch_bounds__(512, 2) gemm256f8_nt_kernel(GemmArgs g) {
                     const i64x4v_ bw_ = {b0_.x, b0_.y, b1_.x, b1_.y}, aw_ = {a0_.x, a0_.y, a1_.x, a1_.y}; \
                     acc[a][i_][b][j_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(            \
                         __builtin_bit_cast(i32x8v, bw_), __builtin_bit_cast(i32x8v, aw_), acc[a][i_][b][j_], 0, 0, 0, \
-                        0x7f7f7f7f, 0, 0x7f7f7f7f);                                                  \
+                        0x7f7f7f7f, 0, BSA ? sb[i_] : 0x7f7f7f7f);                                   \
                 }                                                                                    \
         } else {                                                                                     \
             _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                      \
@@ -140,6 +164,7 @@ __global__ void __launch_bounds__(512, 2) gemm256f8_nt_kernel(GemmArgs g) {
     for (int t = 0; t < nk - 1; ++t) {
         const char* cur = smem + (t & 1) * G256_BUF;
         const int nb = (t + 1) & 1;
+        kt_cur = t;
         // P0: A-lo x B-lo
         G256_READ_B(bl, cur, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -167,6 +192,7 @@ __global__ void __launch_bounds__(512, 2) gemm256f8_nt_kernel(GemmArgs g) {
     }
     {   // last K-tile: nothing left to prefetch, the counts shrink
         const char* cur = smem + ((nk - 1) & 1) * G256_BUF;
+        kt_cur = nk - 1;
         G256_READ_B(bl, cur, 0);
         __builtin_amdgcn_sched_barrier(0);
         G256_READ_A(cur, 0);
@@ -212,7 +238,7 @@ __global__ void __launch_bounds__(512, 2) gemm256f8_nt_kernel(GemmArgs g) {
         for (int mt = 0; mt < 4; ++mt) {
             int m = m0 + a * 128 + wm * 64 + mt * 16 + fr;
             m = m < g.M ? m : g.M - 1;
-            as[a][mt] = g.a_scale[m];
+            as[a][mt] = BSA ? 1.0f : g.a_scale[m];
         }
     __syncthreads();
     if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16) {

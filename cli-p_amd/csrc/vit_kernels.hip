@@ -92,6 +92,14 @@ int launch_quantize_rows_fp8(const unsigned short* in, unsigned char* out, float
     return 0;
 }
 
+int launch_quantize_rows_fp8mx(const unsigned short* in, unsigned char* out, unsigned char* bscale, int M, int K, hipStream_t st) {
+    if (M < 1) return 0;
+    if (K < 32 || K % 32 != 0 || !in || !out || !bscale) return set_err(CLIPMI_EINVAL, "quantize_rows_fp8mx: K=%d", K);
+    hipLaunchKernelGGL(quantize_rows_fp8mx_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, in, out, bscale, M, K);
+    CLIPMI_CHECK_LAUNCH("quantize_rows_fp8mx_kernel");
+    return 0;
+}
+
 int launch_patchify(const PatchArgs& a, hipStream_t st) {
     if (a.dtype == CLIPMI_U8 && a.P % 16 == 0 && a.R % 16 == 0 && a.patch_k == 3 * a.P * a.P && a.P * a.R <= 48 * 1024) {
         hipLaunchKernelGGL(patchify_strip_u8_kernel, dim3((unsigned)((long long)a.B * 3 * a.grid)), dim3(256), (size_t)a.P * a.R + 512, st, a);
@@ -128,6 +136,11 @@ extern "C" int clipmi_dbg_quantize_rows_fp8(const void* in_bf16_dev, void* out_f
                                             void* stream) {
     return launch_quantize_rows_fp8(static_cast<const unsigned short*>(in_bf16_dev), static_cast<unsigned char*>(out_fp8_dev),
                                     scale_dev, M, K, as_stream(stream));
+}
+
+extern "C" int clipmi_dbg_quantize_rows_fp8mx(const void* in_bf16_dev, void* out_fp8_dev, void* bscale_dev, int M, int K, void* stream) {
+    return launch_quantize_rows_fp8mx(static_cast<const unsigned short*>(in_bf16_dev), static_cast<unsigned char*>(out_fp8_dev),
+                                      static_cast<unsigned char*>(bscale_dev), M, K, as_stream(stream));
 }
 
 extern "C" int clipmi_dbg_split_stats(const float* x_dev, int add, void* xhi_dev, void* xlo_dev, float* part_dev, int M, int W,

@@ -528,6 +528,69 @@ static __global__ void __launch_bounds__(256) quantize_rows_fp8_kernel(const uns
 }
 
 // ---------------------------------------------------------------------------------------------
+// MX block scales for e4m3 activations (gemm256f8.hpp BSA; round 3): 32 consecutive values of a row share the e8m0
+// scale 2^(e - 7), e = floor(log2(largest |x| of the block)) - the scaled values then lie below 256 (e4m3 holds 448),
+// a block of zeros takes 2^0. fp8mx_scale_byte gives the scale's e8m0 byte from the block's largest magnitude (a
+// non-negative float: its exponent field - 7, clamped at 0), fp8mx_inv the exact reciprocal of the scale as a float.
+// Every producer (the stand-alone pass below, the QuickGELU epilogue of gemm256p, attention52x4's output stage) uses
+// these two, so the bytes do not depend on who produced them.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned fp8mx_scale_byte(float amax) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    if (amax == 0.f) return 127u;
+    return (unsigned)(e > 7 ? e - 7 : 0);
+}
+__device__ __forceinline__ float fp8mx_inv(unsigned sb) { return __uint_as_float((254u - sb) << 23); }
+// 8 floats -> 8 e4m3 bytes (round to nearest even, saturating: v_cvt_pk_fp8_f32)
+__device__ __forceinline__ uint2 fp8_pack8(const float* f) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    return make_uint2((unsigned)lo, (unsigned)hi);
+}
+
+// quantize_rows_fp8mx_kernel: bf16 [M][K] -> e4m3 [M][K] + e8m0 block scales [M][K / 32]; one wave per row, a lane
+// takes 8 consecutive values per step, the four lanes of a quad make one block. K % 32 == 0. The fallback producer
+// (shapes whose producing kernel has no fused form) and the reference the fused producers are tested against.
+static __global__ void __launch_bounds__(256) quantize_rows_fp8mx_kernel(const unsigned short* __restrict__ in,
+                                                                         unsigned char* __restrict__ out,
+                                                                         unsigned char* __restrict__ bscale, int M, int K) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const unsigned short* x = in + (size_t)r * K;
+    for (int k0 = 0; k0 < K; k0 += 512) {
+        const int k = k0 + lane * 8;
+        const bool on = k < K;
+        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (on) {
+            const uint4 v = *reinterpret_cast<const uint4*>(x + k);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f[2 * j] = __uint_as_float(w[j] << 16);
+                f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+            }
+        }
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(f[j]));
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
+        const unsigned sb = fp8mx_scale_byte(mx);
+        const float inv = fp8mx_inv(sb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] *= inv;
+        if (on) {
+            *reinterpret_cast<uint2*>(out + (size_t)r * K + k) = fp8_pack8(f);
+            if ((lane & 3) == 0) bscale[(size_t)r * (K >> 5) + (k >> 5)] = (unsigned char)sb;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // attention52_kernel: the ViT-B/32 shape (49 <= L <= 52, 4 key/query tiles, no mask) with the query tiles
 // walked in a LOOP instead of all at once. attention_kernel<4,...> keeps 16 score tiles + 16 output tiles +
 // 16 fragments live (~120 registers with the AGPRs: 4 waves per SIMD) and stages 64 V rows per wave (32 KiB per
@@ -1039,5 +1102,6 @@ int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int 
                      hipStream_t st);
 int launch_patchify(const PatchArgs& a, hipStream_t st);
 int launch_quantize_rows_fp8(const unsigned short* in, unsigned char* out, float* scale, int M, int K, hipStream_t st);
+int launch_quantize_rows_fp8mx(const unsigned short* in, unsigned char* out, unsigned char* bscale, int M, int K, hipStream_t st);
 
 }  // namespace clipmi

@@ -283,6 +283,14 @@ int clipmi_dbg_split_stats(const float* x_dev, int add, void* xhi_dev, void* xlo
                            void* stream);
 int clipmi_dbg_gemm_ln(const void* xhi_dev, const void* wg_dev, const float* cb_dev, const float* colsum_dev,
                        const float* part_dev, void* out_dev, int M, int N, int K, int epi, void* stream);
+/* MX block scales (round 3): e4m3 activations with one e8m0 scale per 32 consecutive values of a row, 2^(e - 7) with
+ * e = floor(log2(largest magnitude of the block)). clipmi_dbg_quantize_rows_fp8mx: bf16 [M][K] -> e4m3 [M][K] + scale
+ * bytes [M][K / 32] (K a multiple of 32). clipmi_dbg_gemm_fp8_bsa: out = w_scale[n] * sum_k (scaled A8)[m][k] W8[n][k]
+ * + bias (+ out for epi 2; epi 3 = plain f32) on the block-scaled matrix-core instruction; a_bscale_dev holds
+ * ceil(M / 256) * 256 rows of K / 32 bytes. */
+int clipmi_dbg_quantize_rows_fp8mx(const void* in_bf16_dev, void* out_fp8_dev, void* bscale_dev, int M, int K, void* stream);
+int clipmi_dbg_gemm_fp8_bsa(const void* a8_dev, const void* w8_dev, const void* a_bscale_dev, const float* w_scale_dev,
+                            const float* bias_dev, void* out_dev, int M, int N, int K, int epi, void* stream);
 int clipmi_dbg_gemm_resid_ln(const void* a_dev, const void* w_dev, const float* bias_dev, void* xhi_dev, void* xlo_dev,
                              float* part_dev, float* tmp_dev, int M, int N, int K, int algo, void* stream);
 

@@ -103,6 +103,90 @@ def test_gemm_fp8_epilogues(clipmi, gpu, M, N, K, epi, plain):
     assert torch.equal(outs[0], outs[1])
 
 
+def _quant_mx(t):
+    """torch restatement of the MX rule (vit_kernels.hpp): 32 consecutive values share 2^(e - 7), e = floor(log2(block max));
+    -> (uint8 e4m3 bytes [M][K], uint8 e8m0 scale bytes [M][K / 32])."""
+    M, K = t.shape
+    x = t.float().reshape(M, K // 32, 32)
+    amax = x.abs().amax(-1)
+    e_biased = ((amax.view(torch.int32) >> 23) & 0xff)
+    sb = torch.where(amax == 0, torch.full_like(e_biased, 127), (e_biased - 7).clamp(min=0))
+    inv = torch.ldexp(torch.ones_like(amax), 127 - sb)
+    q = (x * inv[..., None]).to(torch.float8_e4m3fn).view(torch.uint8).reshape(M, K)
+    return q, sb.to(torch.uint8)
+
+
+def _dequant_mx(q, sb):
+    M, K = q.shape
+    s = torch.ldexp(torch.ones(M, K // 32), sb.to(torch.int32) - 127)
+    return (q.view(torch.float8_e4m3fn).float().reshape(M, K // 32, 32) * s[..., None]).reshape(M, K)
+
+
+def test_quantize_rows_fp8mx_matches_torch(clipmi, gpu):
+    L = clipmi._lib.lib()
+    g = torch.Generator(device="cpu"); g.manual_seed(4)
+    M, K = 333, 768
+    x = _bf16(torch.randn(M, K, generator=g) * torch.rand(M, 1, generator=g) * 5)
+    x[5] = 0
+    x[6, 3] = 1e-30
+    x[7, 32:64] = 0                                     # one block of zeros inside a row
+    x[8] = _bf16(torch.full((K,), 448.0))
+    x[9, 100] = 3.0e38
+    xd = x.to(gpu)
+    out = torch.zeros(M, K, dtype=torch.uint8, device=gpu)
+    sc = torch.zeros(M, K // 32, dtype=torch.uint8, device=gpu)
+    clipmi._lib.check(L.clipmi_dbg_quantize_rows_fp8mx(xd.data_ptr(), out.data_ptr(), sc.data_ptr(), M, K, None), "qmx")
+    torch.cuda.synchronize()
+    q_ref, s_ref = _quant_mx(x)
+    assert torch.equal(sc.cpu(), s_ref)
+    got = out.cpu()
+    same = got == q_ref
+    assert (same | (((got & 0x7f) == 0) & ((q_ref & 0x7f) == 0))).all(), f"{(~same).sum().item()} bytes differ"
+    # the scaled values use the top of e4m3's range without reaching its limit
+    deq = _dequant_mx(got, sc.cpu())
+    assert (deq - x.float()).abs().max().item() <= 2.0 ** -3 * x.float().abs().reshape(M, K // 32, 32).amax(-1).max().item()
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(256, 256, 256, 3), (1, 256, 384, 3), (300, 512, 768, 2), (2501, 768, 3072, 2),
+                                       (2500, 768, 768, 2), (777, 256, 4096, 3)])
+def test_gemm_fp8_block_scaled_activations(clipmi, gpu, M, N, K, epi):
+    """gemm256f8 with MX activations (one e8m0 scale per 32 k, taken by the scaled MFMA as its per-lane scale operand)
+    against an f64 matmul of the dequantised operands; rows with very different block scales inside one row."""
+    L = clipmi._lib.lib()
+    g = torch.Generator(device="cpu"); g.manual_seed(M + N + K + epi)
+    a = torch.randn(M, K, generator=g) * (0.2 + 3 * torch.rand(M, 1, generator=g))
+    a = _bf16(a * torch.exp2(torch.randint(-6, 7, (M, K // 32), generator=g).float()).repeat_interleave(32, dim=1))
+    w = _bf16(torch.randn(N, K, generator=g) * K ** -0.5 * (0.5 + torch.rand(N, 1, generator=g)))
+    bias = torch.randn(N, generator=g)
+    a8, sb = _quant_mx(a)
+    w8, sw = _quant_rows(w)
+    ad = _dequant_mx(a8, sb)
+    wd = w8.view(torch.float8_e4m3fn).float() * sw[:, None]
+    ref = (ad.to(gpu).double() @ wd.to(gpu).double().t()).float() + bias.to(gpu)
+    res = torch.randn(M, N, generator=g).to(gpu) if epi == 2 else None
+    if epi == 2:
+        ref = ref + res
+    Mp = (M + 255) // 256 * 256
+    sbd = torch.zeros(Mp, K // 32, dtype=torch.uint8, device=gpu)
+    sbd[:M] = sb.to(gpu)
+    a8d, w8d, swd, biasd = a8.to(gpu), w8.to(gpu), sw.to(gpu), bias.to(gpu)
+    outs = []
+    for _ in range(2):
+        out = torch.full((M + 1, N), float("nan"), dtype=torch.float32, device=gpu)
+        if epi == 2:
+            out[:M] = res
+        rc = L.clipmi_dbg_gemm_fp8_bsa(a8d.data_ptr(), w8d.data_ptr(), sbd.data_ptr(), swd.data_ptr(), biasd.data_ptr(),
+                                       out.data_ptr(), M, N, K, epi, None)
+        clipmi._lib.check(rc, "gemm_fp8_bsa")
+        torch.cuda.synchronize()
+        assert torch.isnan(out[M]).all(), "wrote past row M"
+        outs.append(out[:M].clone())
+    scale = ref.abs().max().item()
+    err = (outs[0] - ref).abs().max().item()
+    assert torch.isfinite(outs[0]).all() and err <= 4e-4 * scale, f"M={M} N={N} K={K} epi={epi}: err {err} scale {scale}"
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_gemm_fp8_rejects(clipmi, gpu):
     L = clipmi._lib.lib()
     x = torch.zeros(1 << 20, dtype=torch.uint8, device=gpu)
