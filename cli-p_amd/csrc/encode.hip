@@ -27,6 +27,7 @@ struct Ws {
     int* rowidx;
     unsigned char* a8;        // weight_format 1: the current GEMM's A operand as e4m3 [B*L][<= 4W]
     float* a_scale;           //                  and its row scales [B*L]
+    unsigned char* a_bs;      //                  or (A produced by attention / QuickGELU) its MX block scales, rows padded to 256
     unsigned short* xhi;      // ln_fold: the residual stream kept split, x = hi + lo (bf16 [B*L][W] each, contiguous);
     unsigned short* xlo;      //          hi is also the A operand of the LN-folded qkv / c_fc GEMMs
     float* ln_part;           //          row statistics of x as per-256-column (sum, sum of squares) [B*L][W/256][2]
@@ -46,6 +47,7 @@ size_t carve(const clipmi_tower* t, int B, void* base, size_t cap, Ws* out) {
     if (t->weight_format == 1) {
         w.a8 = ar.take<unsigned char>(rows * 4 * W);
         w.a_scale = ar.take<float>(rows);
+        w.a_bs = ar.take<unsigned char>((rows + 255) / 256 * 256 * (size_t)(4 * W / 32));
     }
     if (t->ln_fold) {
         w.xhi = ar.take<unsigned short>(2 * rows * W);
@@ -96,11 +98,14 @@ int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int 
         GemmArgs g{};
         g.bias = at<float>(blob, b_off); g.out = out; g.M = M; g.N = N; g.K = K;
         if (fp8) {
+            // A given as bf16 (attention's output, the QuickGELU rows): e4m3 with MX block scales - a 32-block is local to
+            // any producer's column tile, a row scale is not (gemm256f8.hpp BSA); LayerNorm's rows keep their row scale
             if (A)
-                if (int rc = launch_quantize_rows_fp8(A, w.a8, w.a_scale, M, K, st)) return rc;
+                if (int rc = launch_quantize_rows_fp8mx(A, w.a8, w.a_bs, M, K, st)) return rc;
             g.A = reinterpret_cast<const unsigned short*>(w.a8);
             g.W = at<unsigned short>(blob, w_off);
-            g.a_scale = w.a_scale; g.w_scale = at<float>(blob, s_off);
+            if (A) g.a_bscale = w.a_bs; else g.a_scale = w.a_scale;
+            g.w_scale = at<float>(blob, s_off);
             return launch_gemm_fp8(g, epi, st);
         }
         g.A = A; g.W = at<unsigned short>(blob, w_off);
