@@ -92,22 +92,9 @@ const T* at(const void* blob, uint64_t off) {
 int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int causal, hipStream_t st, GemmProbe* probe) {
     const int W = t->width, L = t->tokens, M = B * L;
     const bool fp8 = t->weight_format == 1;
-    // A == nullptr: the A operand is already in w.a8 / w.a_scale (LayerNorm wrote it as e4m3)
-    auto linear = [&](const unsigned short* A, int K, uint64_t w_off, uint64_t s_off, uint64_t b_off, void* out, int N,
-                      int epi) -> int {
+    auto linear = [&](const unsigned short* A, int K, uint64_t w_off, uint64_t b_off, void* out, int N, int epi) -> int {
         GemmArgs g{};
         g.bias = at<float>(blob, b_off); g.out = out; g.M = M; g.N = N; g.K = K;
-        if (fp8) {
-            // A given as bf16 (attention's output, the QuickGELU rows): e4m3 with MX block scales - a 32-block is local to
-            // any producer's column tile, a row scale is not (gemm256f8.hpp BSA); LayerNorm's rows keep their row scale
-            if (A)
-                if (int rc = launch_quantize_rows_fp8mx(A, w.a8, w.a_bs, M, K, st)) return rc;
-            g.A = reinterpret_cast<const unsigned short*>(w.a8);
-            g.W = at<unsigned short>(blob, w_off);
-            if (A) g.a_bscale = w.a_bs; else g.a_scale = w.a_scale;
-            g.w_scale = at<float>(blob, s_off);
-            return launch_gemm_fp8(g, epi, st);
-        }
         g.A = A; g.W = at<unsigned short>(blob, w_off);
         return launch_gemm_algo(g, epi, 0, st, probe);
     };
@@ -142,19 +129,61 @@ int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int 
         }
         return 0;
     }
+    if (fp8) {
+        // FP8 blocks. LayerNorm writes its rows as e4m3 with a row scale (it sees whole rows); the two activations that a
+        // GEMM consumes straight from a producing kernel - attention's output and the QuickGELU rows - travel as e4m3 with
+        // MX block scales written by the producer itself where it has the fused form (attention52x4; the persistent
+        // QuickGELU GEMM), else by quantize_rows_fp8mx_kernel over the producer's bf16 rows: the same bytes either way.
+        auto gemm8 = [&](const unsigned char* A8, const float* a_scale, const unsigned char* a_bs, int K, uint64_t w_off,
+                         uint64_t s_off, uint64_t b_off, void* out, unsigned char* out_bs, int N, int epi) -> int {
+            GemmArgs g{};
+            g.bias = at<float>(blob, b_off); g.out = out; g.M = M; g.N = N; g.K = K;
+            g.A = reinterpret_cast<const unsigned short*>(A8);
+            g.W = at<unsigned short>(blob, w_off);
+            g.a_scale = a_scale; g.a_bscale = a_bs; g.out_bscale = out_bs;
+            g.w_scale = at<float>(blob, s_off);
+            return launch_gemm_fp8(g, epi, st);
+        };
+        static const bool fuse_off = [] { const char* e = getenv("CLIPMI_FP8_FUSE"); return e && atoi(e) == 0; }();   // A/B aid
+        const bool fc_mx = !fuse_off && gemm_fp8_emits_mx(M, 4 * W, W);
+        unsigned char* const big8 = reinterpret_cast<unsigned char*>(w.big);
+        for (int l = 0; l < t->layers; ++l) {
+            const uint64_t lb = t->off_layers + (uint64_t)l * t->layer_stride;
+            LnArgs ln{w.x, at<float>(blob, lb + t->lo_ln1_w), at<float>(blob, lb + t->lo_ln1_b), w.h, nullptr, 1, M, W, 1};
+            ln.out8 = w.a8; ln.scale8 = w.a_scale;
+            if (int rc = launch_layernorm(ln, st)) return rc;
+            if (int rc = gemm8(w.a8, w.a_scale, nullptr, W, lb + t->lo_qkv_w, lb + t->lo_qkv_s, lb + t->lo_qkv_b, w.big, nullptr, 3 * W, EPI_BIAS_BF16)) return rc;
+            bool fused = false;
+            if (int rc = launch_attention(w.big, w.h, B, L, t->heads, causal, 1, st, fuse_off ? nullptr : w.a8, w.a_bs, &fused)) return rc;
+            if (!fused)
+                if (int rc = launch_quantize_rows_fp8mx(w.h, w.a8, w.a_bs, M, W, st)) return rc;
+            if (int rc = gemm8(w.a8, nullptr, w.a_bs, W, lb + t->lo_out_w, lb + t->lo_out_s, lb + t->lo_out_b, w.x, nullptr, W, EPI_BIAS_RESID_F32)) return rc;
+            ln.w = at<float>(blob, lb + t->lo_ln2_w); ln.b = at<float>(blob, lb + t->lo_ln2_b);
+            if (int rc = launch_layernorm(ln, st)) return rc;
+            const unsigned char* h8 = w.a8;
+            if (fc_mx) {
+                // the QuickGELU rows leave the GEMM as e4m3 + block scales, into the bf16 buffer's bytes
+                if (int rc = gemm8(w.a8, w.a_scale, nullptr, W, lb + t->lo_fc_w, lb + t->lo_fc_s, lb + t->lo_fc_b, big8, w.a_bs, 4 * W, EPI_BIAS_QGELU_BF16)) return rc;
+                h8 = big8;
+            } else {
+                if (int rc = gemm8(w.a8, w.a_scale, nullptr, W, lb + t->lo_fc_w, lb + t->lo_fc_s, lb + t->lo_fc_b, w.big, nullptr, 4 * W, EPI_BIAS_QGELU_BF16)) return rc;
+                if (int rc = launch_quantize_rows_fp8mx(w.big, w.a8, w.a_bs, M, 4 * W, st)) return rc;
+            }
+            if (int rc = gemm8(h8, nullptr, w.a_bs, 4 * W, lb + t->lo_proj_w, lb + t->lo_proj_s, lb + t->lo_proj_b, w.x, nullptr, W, EPI_BIAS_RESID_F32)) return rc;
+        }
+        return 0;
+    }
     for (int l = 0; l < t->layers; ++l) {
         const uint64_t lb = t->off_layers + (uint64_t)l * t->layer_stride;
         LnArgs ln{w.x, at<float>(blob, lb + t->lo_ln1_w), at<float>(blob, lb + t->lo_ln1_b), w.h, nullptr, 1, M, W, 1};
-        if (fp8) { ln.out8 = w.a8; ln.scale8 = w.a_scale; }       // LayerNorm output straight to e4m3 + row scale
         if (int rc = launch_layernorm(ln, st)) return rc;
-        if (int rc = linear(fp8 ? nullptr : w.h, W, lb + t->lo_qkv_w, lb + t->lo_qkv_s, lb + t->lo_qkv_b, w.big, 3 * W, EPI_BIAS_BF16)) return rc;
+        if (int rc = linear(w.h, W, lb + t->lo_qkv_w, lb + t->lo_qkv_b, w.big, 3 * W, EPI_BIAS_BF16)) return rc;
         if (int rc = launch_attention(w.big, w.h, B, L, t->heads, causal, 1, st)) return rc;
-        if (int rc = linear(w.h, W, lb + t->lo_out_w, lb + t->lo_out_s, lb + t->lo_out_b, w.x, W, EPI_BIAS_RESID_F32)) return rc;
+        if (int rc = linear(w.h, W, lb + t->lo_out_w, lb + t->lo_out_b, w.x, W, EPI_BIAS_RESID_F32)) return rc;
         ln.w = at<float>(blob, lb + t->lo_ln2_w); ln.b = at<float>(blob, lb + t->lo_ln2_b);
         if (int rc = launch_layernorm(ln, st)) return rc;
-        if (int rc = linear(fp8 ? nullptr : w.h, W, lb + t->lo_fc_w, lb + t->lo_fc_s, lb + t->lo_fc_b, w.big, 4 * W, EPI_BIAS_QGELU_BF16)) return rc;
-        if (int rc = linear(w.big, 4 * W, lb + t->lo_proj_w, lb + t->lo_proj_s, lb + t->lo_proj_b, w.x, W, EPI_BIAS_RESID_F32))
-            return rc;
+        if (int rc = linear(w.h, W, lb + t->lo_fc_w, lb + t->lo_fc_b, w.big, 4 * W, EPI_BIAS_QGELU_BF16)) return rc;
+        if (int rc = linear(w.big, 4 * W, lb + t->lo_proj_w, lb + t->lo_proj_b, w.x, W, EPI_BIAS_RESID_F32)) return rc;
     }
     return 0;
 }

@@ -296,6 +296,13 @@ static int launch_epi256f8_bsa(const GemmArgs& g, hipStream_t st) {
     return 0;
 }
 
+// true when launch_gemm_fp8(.., EPI_BIAS_QGELU_BF16, ..) of this shape runs on the persistent kernel, whose store pass can
+// emit e4m3 + MX block scales (GemmArgs::out_bscale) instead of bf16
+bool gemm_fp8_emits_mx(int M, int N, int K) {
+    const long long tiles = (long long)(N / 256) * ((M + 255) / 256);
+    return M >= 1 && N % 256 == 0 && K % 256 == 0 && K >= 256 && tiles > NUM_CU && N <= 3840 && persist_mode() != 0;
+}
+
 // mx: 1 = the block-scaled MFMA form with unit scales (twice the rate), 0 = plain FP8 MFMA (f32 accumulation)
 int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st, int mx) {
     if (g.M < 1 || g.N % 256 != 0 || g.K % 128 != 0 || g.K < 256)
@@ -309,6 +316,8 @@ int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st, int mx) {
     }
     // more than one round of tiles: the persistent role-split kernel on FP8 operands (mx = 2 keeps gemm256f8 for tests)
     const long long tiles = (long long)(g.N / 256) * ((g.M + 255) / 256);
+    if (g.out_bscale && !(mx == 1 && epi == EPI_BIAS_QGELU_BF16 && gemm_fp8_emits_mx(g.M, g.N, g.K)))
+        return set_err(CLIPMI_EINVAL, "gemm_fp8: e4m3 + block-scale output exists for the persistent QuickGELU form only");
     if (mx == 1 && tiles > NUM_CU && g.K % 256 == 0 && g.N <= 3840 && persist_mode() != 0) {
         if (epi == EPI_BIAS_BF16) return launch_epi256p<EPI_BIAS_BF16, true>(g, st, nullptr);
         if (epi == EPI_BIAS_QGELU_BF16) return launch_epi256p<EPI_BIAS_QGELU_BF16, true>(g, st, nullptr);

@@ -131,6 +131,23 @@ __device__ __forceinline__ void split_make(f32x4 o, uint2& hi, uint2& lo) {
     const f32x4 d = o - hf;
     lo = make_uint2(pack_bf16x2(d.x, d.y), pack_bf16x2(d.z, d.w));
 }
+// MX block scales of e4m3 activations (vit_kernels.hpp quantize_rows_fp8mx_kernel, gemm256f8.hpp BSA): shared by every producer
+__device__ __forceinline__ unsigned fp8mx_scale_byte(float amax) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    if (amax == 0.f) return 127u;
+    return (unsigned)(e > 7 ? e - 7 : 0);
+}
+__device__ __forceinline__ float fp8mx_inv(unsigned sb) { return __uint_as_float((254u - sb) << 23); }
+// 8 floats -> 8 e4m3 bytes (round to nearest even, saturating: v_cvt_pk_fp8_f32)
+__device__ __forceinline__ uint2 fp8_pack8(const float* f) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    return make_uint2((unsigned)lo, (unsigned)hi);
+}
+
 constexpr bool epi_is_ln(int e) { return e == EPI_LN_BIAS_BF16 || e == EPI_LN_BIAS_QGELU_BF16; }
 constexpr bool epi_is_qgelu(int e) { return e == EPI_BIAS_QGELU_BF16 || e == EPI_LN_BIAS_QGELU_BF16; }
 constexpr bool epi_is_bf16_out(int e) { return e == EPI_BIAS_BF16 || e == EPI_BIAS_QGELU_BF16 || epi_is_ln(e); }
@@ -372,6 +389,7 @@ struct GemmProbe {
 int launch_gemm(const GemmArgs& g, int epi, hipStream_t st, GemmProbe* probe = nullptr);
 int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmProbe* probe = nullptr);
 int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st, int mx = 1);      // gemm256f8.hpp: e4m3 operands + scales
+bool gemm_fp8_emits_mx(int M, int N, int K);     // the QuickGELU form of this shape can write e4m3 + MX block scales (out_bscale)
 // vit_kernels.hip: f32 rows -> split residual (hi, lo) + canonical statistics partials [M][W/256][2]; with `add`
 // (the non-persistent form of EPI_BIAS_RESID_LN_F32) the rows are add[m][:] + (hi + lo)[m][:], updated in place
 int launch_split_stats(const float* x_or_add, bool add, unsigned short* xhi, unsigned short* xlo, float* part, int M, int W,

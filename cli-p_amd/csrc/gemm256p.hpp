@@ -661,6 +661,39 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                             : "v"(ra)
                             : "memory");
                         const uint4 xs[8] = {x0, x1, x2, x3, x4, x5, x6, x7};
+                        if constexpr (FP8 && EPI == EPI_BIAS_QGELU_BF16) {
+                            if (g.out_bscale) {
+                                // the rows leave as e4m3 with MX block scales (the next GEMM's A operand: gemm256f8.hpp BSA)
+                                // instead of bf16: a lane holds 8 consecutive columns, the 4 lanes of a quad one 32-block -
+                                // the same bytes quantize_rows_fp8mx_kernel makes of the bf16 rows (vit_kernels.hpp)
+                                unsigned char* const out8 = static_cast<unsigned char*>(g.out);
+    #pragma unroll
+                                for (int k = 0; k < 8; ++k) {
+                                    const unsigned w_[4] = {xs[k].x, xs[k].y, xs[k].z, xs[k].w};
+                                    float f[8];
+                                    float mx = 0.f;
+    #pragma unroll
+                                    for (int j = 0; j < 4; ++j) {
+                                        f[2 * j] = __uint_as_float(w_[j] << 16);
+                                        f[2 * j + 1] = __uint_as_float(w_[j] & 0xffff0000u);
+                                        mx = fmaxf(mx, fmaxf(fabsf(f[2 * j]), fabsf(f[2 * j + 1])));
+                                    }
+                                    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xB1, 0xf, 0xf, false)));  // quad_perm [1,0,3,2]
+                                    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x4E, 0xf, 0xf, false)));  // quad_perm [2,3,0,1]
+                                    const unsigned sb_ = fp8mx_scale_byte(mx);
+                                    const float inv_ = fp8mx_inv(sb_);
+    #pragma unroll
+                                    for (int j = 0; j < 8; ++j) f[j] *= inv_;
+                                    const int m = m0 + a * 128 + k * 16 + rlow;
+                                    if (m < g.M) {
+                                        const int col = n0 + (lane & 31) * 8;
+                                        *reinterpret_cast<uint2*>(out8 + (size_t)m * g.N + col) = fp8_pack8(f);
+                                        if ((lane & 3) == 0) g.out_bscale[(size_t)m * (g.N >> 5) + (col >> 5)] = (unsigned char)sb_;
+                                    }
+                                }
+                                continue;
+                            }
+                        }
     #pragma unroll
                         for (int k = 0; k < 8; ++k) {
                             const int m = m0 + a * 128 + k * 16 + rlow;

@@ -36,7 +36,8 @@ static int launch_attn_t(const unsigned short* qkv, unsigned short* out, int B, 
 }
 
 int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int L, int heads, int causal, int tr,
-                     hipStream_t st) {
+                     hipStream_t st, unsigned char* out8, unsigned char* out_bs, bool* fused) {
+    if (fused) *fused = false;
     if (B < 1) return 0;
     if (L < 1) return set_err(CLIPMI_EINVAL, "attention: L=%d", L);
     if (L > 80) {
@@ -59,8 +60,14 @@ int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int 
         // one workgroup per (image, head), one query tile per wave
         const long long items = (long long)B * heads;
         const long long resident = (long long)NUM_CU * 5;               // 5 workgroups (20 waves, <= 96 VGPRs) per CU
-        hipLaunchKernelGGL(attention52x4_kernel, dim3((unsigned)(items < resident ? items : resident)), dim3(256),
-                           64 * 128 + 52 * 128, st, qkv, out, B, L, heads);
+        if (out8 && out_bs && fused) {
+            hipLaunchKernelGGL(attention52x4_kernel<true>, dim3((unsigned)(items < resident ? items : resident)), dim3(256),
+                               64 * 128 + 52 * 128, st, qkv, out, B, L, heads, out8, out_bs);
+            *fused = true;
+        } else {
+            hipLaunchKernelGGL(attention52x4_kernel<false>, dim3((unsigned)(items < resident ? items : resident)), dim3(256),
+                               64 * 128 + 52 * 128, st, qkv, out, B, L, heads, (unsigned char*)nullptr, (unsigned char*)nullptr);
+        }
         CLIPMI_CHECK_LAUNCH("attention52x4_kernel");
         return 0;
     }

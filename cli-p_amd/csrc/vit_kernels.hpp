@@ -535,22 +535,6 @@ static __global__ void __launch_bounds__(256) quantize_rows_fp8_kernel(const uns
 // Every producer (the stand-alone pass below, the QuickGELU epilogue of gemm256p, attention52x4's output stage) uses
 // these two, so the bytes do not depend on who produced them.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned fp8mx_scale_byte(float amax) {
-    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
-    if (amax == 0.f) return 127u;
-    return (unsigned)(e > 7 ? e - 7 : 0);
-}
-__device__ __forceinline__ float fp8mx_inv(unsigned sb) { return __uint_as_float((254u - sb) << 23); }
-// 8 floats -> 8 e4m3 bytes (round to nearest even, saturating: v_cvt_pk_fp8_f32)
-__device__ __forceinline__ uint2 fp8_pack8(const float* f) {
-    int lo = 0, hi = 0;
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
-    return make_uint2((unsigned)lo, (unsigned)hi);
-}
-
 // quantize_rows_fp8mx_kernel: bf16 [M][K] -> e4m3 [M][K] + e8m0 block scales [M][K / 32]; one wave per row, a lane
 // takes 8 consecutive values per step, the four lanes of a quad make one block. K % 32 == 0. The fallback producer
 // (shapes whose producing kernel has no fused form) and the reference the fused producers are tested against.
@@ -732,9 +716,10 @@ static __global__ void __launch_bounds__(256, 6) attention52_kernel(const unsign
 // attention52_kernel's query-tile loop: same MFMA sequence, same softmax: bit-identical output, a quarter of the serial
 // chain. 14.5 KiB of LDS per workgroup, 8 workgroups (32 waves) per CU.
 // ---------------------------------------------------------------------------------------------
+template <bool OUT8>
 static __global__ void __launch_bounds__(256, 5) attention52x4_kernel(const unsigned short* __restrict__ qkv,
                                                                       unsigned short* __restrict__ out, int B, int L,
-                                                                      int heads) {
+                                                                      int heads, unsigned char* __restrict__ out8, unsigned char* __restrict__ out_bs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 4, ROWS = 52;
     const int lane = threadIdx.x & 63;
@@ -873,7 +858,37 @@ static __global__ void __launch_bounds__(256, 5) attention52x4_kernel(const unsi
         mine[j] = odd ? pk[2 * j + 1] : pk[2 * j];
         theirs[j] = make_uint2(__shfl_xor(give.x, 16), __shfl_xor(give.y, 16));
     }
-    if (qi < L) {
+    if (OUT8) {
+        // FP8 towers: the rows leave as e4m3 with MX block scales (the A operand of out_proj, gemm256f8.hpp BSA) - the bytes
+        // quantize_rows_fp8mx_kernel makes of the bf16 rows. A head's 64 columns are two 32-blocks; block j of row qi is
+        // the 8 columns of tile 2 j (even fg) or 2 j + 1 (odd fg) in the four lanes fr, fr + 16, fr + 32, fr + 48.
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int dt = 2 * j + (odd ? 1 : 0);
+            const uint4 v = odd ? make_uint4(theirs[j].x, theirs[j].y, mine[j].x, mine[j].y)
+                                : make_uint4(mine[j].x, mine[j].y, theirs[j].x, theirs[j].y);
+            const unsigned w_[4] = {v.x, v.y, v.z, v.w};
+            float f[8];
+            float mxa = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f[2 * i] = __uint_as_float(w_[i] << 16);
+                f[2 * i + 1] = __uint_as_float(w_[i] & 0xffff0000u);
+                mxa = fmaxf(mxa, fmaxf(fabsf(f[2 * i]), fabsf(f[2 * i + 1])));
+            }
+            mxa = fmaxf(mxa, __shfl_xor(mxa, 16));
+            mxa = fmaxf(mxa, __shfl_xor(mxa, 32));
+            const unsigned sb_ = fp8mx_scale_byte(mxa);
+            const float inv_ = fp8mx_inv(sb_);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] *= inv_;
+            if (qi < L) {
+                const size_t row_ = (size_t)b * L + qi;
+                *reinterpret_cast<uint2*>(out8 + row_ * W + h * 64 + 4 * (fg & ~1) + dt * 16) = fp8_pack8(f);
+                if (fg == 0) out_bs[row_ * (W >> 5) + h * 2 + j] = (unsigned char)sb_;
+            }
+        }
+    } else if (qi < L) {
         // even fg: tiles 0, 2 at columns 16 dt + 4 fg .. + 7 (own 4, then the partner's); odd fg: tiles 1, 3 at 16 dt + 4 (fg - 1)
         unsigned short* dst = out + ((size_t)b * L + qi) * W + h * 64 + 4 * (fg & ~1);
 #pragma unroll
@@ -1098,8 +1113,10 @@ __global__ void __launch_bounds__(WPB * 64, QT == 2 ? 4 : 2) attention_flash_ker
 
 // host launchers (vit_kernels.hip)
 int launch_layernorm(const LnArgs& a, hipStream_t st);
+// out8 / out_bs / fused (FP8 towers): when the shape's kernel has the fused form, the rows are written as e4m3 + MX block
+// scales into out8 / out_bs INSTEAD of bf16 into out and *fused is set; otherwise bf16 into out as always
 int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int L, int heads, int causal, int tr,
-                     hipStream_t st);
+                     hipStream_t st, unsigned char* out8 = nullptr, unsigned char* out_bs = nullptr, bool* fused = nullptr);
 int launch_patchify(const PatchArgs& a, hipStream_t st);
 int launch_quantize_rows_fp8(const unsigned short* in, unsigned char* out, float* scale, int M, int K, hipStream_t st);
 int launch_quantize_rows_fp8mx(const unsigned short* in, unsigned char* out, unsigned char* bscale, int M, int K, hipStream_t st);
