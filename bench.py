@@ -515,7 +515,9 @@ def main():
         fp8_info = {"metric": "images/sec ViT-B/32 encode, FP8 (e4m3) linear layers", "value": world * B * steps8 / dt8,
                     "unit": "images/s", "ms_per_step": dt8 / steps8 * 1e3, "steps": steps8, "dtype": "fp8 e4m3 x e4m3 -> f32",
                     "min_cosine_to_bf16_path": float(cos.min()), **sp8,
-                    "note": "BASELINE.json configs[4] parity case; not the headline (configs[1] is bf16)"}
+                    "ratio_to_bf16_headline": world * B * steps8 / dt8 / img_per_s,
+                    "note": "BASELINE.json configs[4] parity case; not the headline (configs[1] is bf16). e4m3 activations carry MX "
+                            "block scales written by the producing kernels (DESIGN.md 4.4c)"}
         del model8
 
     # SURVEY.md 8(d) cfg-2 sweep: images/s at B in {64, 128, 256, 512} (compact: 10 synchronised steps each), beside the

@@ -281,3 +281,20 @@ def test_encode_image_fp8_other_geometry(clipmi, gpu, B):
     cos = torch.nn.functional.cosine_similarity(got.double(), ref.double(), dim=-1).min().item()
     print(f"toy-256 B={B}: fp8 err {err:.4g} (emulation noise {noise:.4g}), cosine {cos:.5f}")
     assert torch.isfinite(got).all() and err <= 3 * noise + 1e-3 and cos >= 0.99
+
+
+def test_fp8_fused_producers_write_the_standalone_quantizers_bytes(clipmi, gpu, tmp_path):
+    """attention52x4's output stage and the persistent QuickGELU GEMM's store pass write e4m3 + MX block scales themselves
+    (csrc/encode.hip FP8 blocks); CLIPMI_FP8_FUSE=0 routes the same rows through quantize_rows_fp8mx_kernel instead. The
+    embeddings of 300 images (59 row tiles x 12 column tiles: the persistent kernel) must be bit-identical. The switch is read
+    once per process: two children."""
+    import subprocess
+    outs = []
+    for k, fuse in enumerate(("1", "0")):
+        f = str(tmp_path / f"e{k}.pt")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fp8_fuse_check.py"), "300", f],
+                           env=dict(os.environ, CLIPMI_FP8_FUSE=fuse), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f))
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
