@@ -1,5 +1,5 @@
 """Kernel timeline of encode_image steps: busy time, idle gaps between kernels (development aid).
-run:    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/etl -- python3 tools/encode_timeline.py run [B]
+run:    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/etl -- python3 tools/encode_timeline.py run [B] [fp8]
 report: python3 tools/encode_timeline.py report gpurun_out/etl"""
 import sys, os, glob, csv
 if sys.argv[1] == "run":
@@ -8,7 +8,8 @@ if sys.argv[1] == "run":
     import clipmi
     dev = torch.device("cuda:0")
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 870
-    model = clipmi.CLIP(clipmi.weights.random_state_dict("ViT-B/32", seed=0), device=dev)
+    fp8 = len(sys.argv) > 3 and sys.argv[3] == "fp8"
+    model = clipmi.CLIP(clipmi.weights.random_state_dict("ViT-B/32", seed=0), device=dev, **({"vision_weights": "fp8"} if fp8 else {}))
     x = torch.randint(0, 256, (B, 3, 224, 224), device=dev, dtype=torch.uint8)
     for _ in range(12):
         model.encode_image(x, normalize=True)
