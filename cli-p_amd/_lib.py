@@ -7,9 +7,12 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libclipmi.so")
+# CLIPMI_DEV_LIB=1 (tools/, two child-process tests): the development build, which alone reads the CLIPMI_* A/B knobs and
+# holds the laboratory kernels (cli-p_amd/build.py --dev). Everything else loads the product library.
+DEV_LIB = os.environ.get("CLIPMI_DEV_LIB", "") not in ("", "0")
+LIB_PATH = os.path.join(HERE, "libclipmi_dev.so" if DEV_LIB else "libclipmi.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 F32, BF16, U8 = 0, 1, 2
 
 # every symbol include/clipmi.h declares (tests check the .so exports all of them)
@@ -61,7 +64,7 @@ def lib():
             f"{LIB_PATH} is missing: build the HIP library first "
             "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
     from . import build as _build
-    if os.path.isdir(_build.CSRC) and not _build.is_current():
+    if os.path.isdir(_build.CSRC) and not _build.is_current(_build.DEV if DEV_LIB else _build.PRODUCT):
         raise ClipmiError(
             f"{LIB_PATH} does not match the sources under csrc/ (content stamp mismatch): rebuild "
             "(python cli-p_amd/build.py). A stale HIP library is never loaded silently.")

@@ -18,12 +18,26 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "csrc", "_obj")
-LIB = os.path.join(HERE, "libclipmi.so")
-STAMP = LIB + ".stamp"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]
+
+
+class Variant:
+    """One library built from csrc/: the product (libclipmi.so) or the development build (libclipmi_dev.so, -DCLIPMI_DEV:
+    the CLIPMI_* A/B environment knobs and the laboratory kernels that no product path selects - tools/ and two
+    child-process tests load it by setting CLIPMI_DEV_LIB=1; the product library reads no environment variable)."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.obj = os.path.join(CSRC, "_obj_dev" if dev else "_obj")
+        self.lib = os.path.join(HERE, "libclipmi_dev.so" if dev else "libclipmi.so")
+        self.stamp = self.lib + ".stamp"
+        self.flags = BASE_FLAGS + (["-DCLIPMI_DEV"] if dev else [])
+
+
+PRODUCT, DEV = Variant(False), Variant(True)
+OBJ, LIB, STAMP, FLAGS = PRODUCT.obj, PRODUCT.lib, PRODUCT.stamp, PRODUCT.flags
 
 
 def _sources():
@@ -50,26 +64,28 @@ def _read(path):
         return None
 
 
-def source_digest():
-    """Digest of everything libclipmi.so is made from (sources, headers, flags)."""
+def source_digest(variant=PRODUCT):
+    """Digest of everything the library is made from (sources, headers, flags)."""
     headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))
     headers.append(os.path.join(HERE, "..", "include", "clipmi.h"))
     srcs = [os.path.join(CSRC, s) for s in _sources()]
-    return _sha(srcs + headers, FLAGS + LINK_FLAGS)
+    return _sha(srcs + headers, variant.flags + LINK_FLAGS)
 
 
-def is_current():
-    """True when libclipmi.so exists and its stamp matches the sources in the tree."""
-    st = _read(STAMP)
-    if st is None or not os.path.exists(LIB):
+def is_current(variant=PRODUCT):
+    """True when the library exists and its stamp matches the sources in the tree."""
+    st = _read(variant.stamp)
+    if st is None or not os.path.exists(variant.lib):
         return False
     try:
-        return json.loads(st).get("digest") == source_digest()
+        return json.loads(st).get("digest") == source_digest(variant)
     except ValueError:
         return False
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, dev=False):
+    variant = DEV if dev else PRODUCT
+    OBJ, LIB, STAMP, FLAGS = variant.obj, variant.lib, variant.stamp, variant.flags
     force = force or os.environ.get("CLIPMI_FORCE_BUILD", "") not in ("", "0")
     os.makedirs(OBJ, exist_ok=True)
     headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))
@@ -103,9 +119,9 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(compile_one, jobs))
-    digest = source_digest()
+    digest = source_digest(variant)
     linked = False
-    if force or jobs or not is_current():
+    if force or jobs or not is_current(variant):
         if os.path.exists(STAMP):
             os.remove(STAMP)
         run([HIPCC] + LINK_FLAGS + objs + ["-o", LIB])
@@ -117,6 +133,6 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    rep = build(force="--force" in sys.argv)
+    rep = build(force="--force" in sys.argv, dev="--dev" in sys.argv)
     print(f"{rep['lib']}: compiled {len(rep['compiled'])} of {rep['units']} translation units "
           f"({', '.join(rep['compiled']) or 'none'}), linked={rep['linked']}, digest {rep['digest'][:16]}")

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include "../../include/clipmi.h"
 
 namespace clipmi {
@@ -37,6 +38,17 @@ struct Arena {
         if (e__ != hipSuccess)                                                           \
             return clipmi::set_err(CLIPMI_EHIP, "%s: %s", what, hipGetErrorString(e__)); \
     } while (0)
+
+// Development knobs. The CLIPMI_* environment variables that A/B runs and tools/ use exist only in the -DCLIPMI_DEV build
+// (libclipmi_dev.so: cli-p_amd/build.py --dev); the product library reads no environment variable on any path, and the
+// laboratory kernels (live-threshold scan, gemm2w, the scan ablations) are not compiled into it.
+#ifdef CLIPMI_DEV
+inline long long dev_knob(const char* name, long long dflt) { const char* e = getenv(name); return e && *e ? atoll(e) : dflt; }
+inline bool dev_knob_set(const char* name) { return getenv(name) != nullptr; }
+#else
+constexpr long long dev_knob(const char*, long long dflt) { return dflt; }
+constexpr bool dev_knob_set(const char*) { return false; }
+#endif
 
 constexpr int NUM_CU = 256;           // MI355X
 constexpr int LDS_BYTES = 160 * 1024; // per CU

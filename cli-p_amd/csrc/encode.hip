@@ -144,7 +144,7 @@ int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int 
             g.w_scale = at<float>(blob, s_off);
             return launch_gemm_fp8(g, epi, st);
         };
-        static const bool fuse_off = [] { const char* e = getenv("CLIPMI_FP8_FUSE"); return e && atoi(e) == 0; }();   // A/B aid
+        static const bool fuse_off = dev_knob("CLIPMI_FP8_FUSE", 1) == 0;   // A/B aid (development build)
         const bool fc_mx = !fuse_off && gemm_fp8_emits_mx(M, 4 * W, W);
         unsigned char* const big8 = reinterpret_cast<unsigned char*>(w.big);
         for (int l = 0; l < t->layers; ++l) {

@@ -1,7 +1,9 @@
 // gemm.hip — instantiation and launch of the bf16 NT GEMM (see gemm.hpp).
 #include "gemm256p.hpp"
 #include "gemm_skinny.hpp"
-#include "gemm2w.hpp"
+#ifdef CLIPMI_DEV
+#include "gemm2w.hpp"      // measured slower: development builds only
+#endif
 #include "gemm256f8.hpp"
 #include <hip/hip_ext.h>
 #include <cstdlib>
@@ -58,7 +60,7 @@ static int launch_epi256(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
 // persistent, role-split 256x256 kernel (gemm256p.hpp): pure-store epilogues only
 static int persist_mode() {
     // development switch for A/B runs on one box: CLIPMI_GEMM_PERSIST=0 keeps every GEMM on gemm256
-    static const int mode = [] { const char* e = getenv("CLIPMI_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
+    static const int mode = (int)dev_knob("CLIPMI_GEMM_PERSIST", 1);
     return mode;
 }
 
@@ -101,13 +103,13 @@ static int launch_epi256p(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
 // LayerNorm-sized pass. Both give the same bits (same adds in the same order, canonical statistics: gemm.hpp).
 
 static int split_pct() {        // CLIPMI_GEMM_SPLIT=<pct>: split off the last round when it is less than pct % full (0: never)
-    static const int pct = [] { const char* e = getenv("CLIPMI_GEMM_SPLIT"); return e ? atoi(e) : 40; }();
+    static const int pct = (int)dev_knob("CLIPMI_GEMM_SPLIT", 40);
     return pct;
 }
 
 // skinny kernel (gemm_skinny.hpp): M <= 128 rows, one wave per 16 columns x 16 rows
 static bool skinny_ok(const GemmArgs& g) {
-    static const bool off = [] { const char* e = getenv("CLIPMI_GEMM_SKINNY"); return e && atoi(e) == 0; }();   // A/B aid
+    static const bool off = dev_knob("CLIPMI_GEMM_SKINNY", 1) == 0;   // A/B aid
     return !off && g.M >= 1 && g.M <= SKINNY_MAX_M && g.N % 16 == 0 && g.K % 32 == 0 && g.K >= 32;
 }
 
@@ -136,6 +138,7 @@ static int launch_skinny(const GemmArgs& g, int epi, hipStream_t st) {
     return set_err(CLIPMI_EINVAL, "gemm_skinny: epilogue %d", epi);
 }
 
+#ifdef CLIPMI_DEV
 // the residual producer as two co-resident workgroups per CU (gemm2w.hpp)
 static bool g2w_ok(const GemmArgs& g) { return g.N % 256 == 0 && g.N <= 1024 && g.K % 32 == 0 && g.K >= 64 && g.M >= 1; }
 static int launch_g2w(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
@@ -150,6 +153,7 @@ static int launch_g2w(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
     CLIPMI_CHECK_LAUNCH("gemm2w_resid_ln_kernel");
     return 0;
 }
+#endif
 
 // algo: 0 = choose by shape, 1 = force the 128x128 kernel, 2 = force the 256x256 kernel,
 //       3 = force the persistent 256x256 kernel
@@ -160,14 +164,18 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmP
         (!g.xhi || !g.xlo || !g.ln_part || !g.tmp_f32 || g.N % 256 != 0 || g.N > 1024 ||
          (const char*)g.xlo < (const char*)g.xhi || (const char*)g.xlo - (const char*)g.xhi >= (1ll << 31) - (long long)256 * g.N * 2))
         return set_err(CLIPMI_EINVAL, "gemm: EPI_BIAS_RESID_LN_F32 needs xhi <= xlo < xhi + 2 GiB, ln_part, tmp_f32 and N %% 256 == 0, N <= 1024");
+#ifndef CLIPMI_DEV
+    if (algo == 4) return set_err(CLIPMI_EUNSUPPORTED, "gemm2w exists in the development build only (libclipmi_dev.so)");
+#else
     if (algo == 4) {
         if (epi != EPI_BIAS_RESID_LN_F32 || !g2w_ok(g) || !g.A || !g.W)
             return set_err(CLIPMI_EINVAL, "gemm2w: the residual producer only (N %% 256 == 0, N <= 1024, K %% 32 == 0, K >= 64)");
         return launch_g2w(g, st, probe);
     }
     // development A/B: CLIPMI_GEMM_G2W=<max K> sends the residual producer with K <= that to gemm2w (measured slower: DESIGN 4.4g)
-    static const int g2w_maxk = [] { const char* e = getenv("CLIPMI_GEMM_G2W"); return e ? atoi(e) : 0; }();
+    static const int g2w_maxk = (int)dev_knob("CLIPMI_GEMM_G2W", 0);
     if (algo == 0 && epi == EPI_BIAS_RESID_LN_F32 && g.K <= g2w_maxk && g.M >= 1024 && g2w_ok(g)) return launch_g2w(g, st, probe);
+#endif
     const bool ok256 = g.N % 256 == 0 && g.K % 64 == 0 && g.K >= 128;
     if (algo == 2 && !ok256) return set_err(CLIPMI_EINVAL, "gemm256: N=%d K=%d (need N %% 256 == 0, K %% 64 == 0, K >= 128)", g.N, g.K);
     const bool store_only = epi == EPI_BIAS_BF16 || epi == EPI_BIAS_QGELU_BF16 || epi == EPI_BIAS_RESID_F32 || epi_is_ln(epi) ||
@@ -365,7 +373,8 @@ extern "C" int clipmi_dbg_gemm_bf16(const void* a_dev, const void* w_dev, const 
     g.bias = bias_dev;
     g.out = out_dev;
     g.M = M; g.N = N; g.K = K;
-    if (const char* e = getenv("CLIPMI_GEMM_DBG")) g.dbg = atoi(e);
+    static const int dbg_env = (int)dev_knob("CLIPMI_GEMM_DBG", 0);
+    g.dbg = dbg_env;
     if (g.dbg & 12) { g.pos = bias_dev; g.bias = nullptr; }     // stamps land in the caller's "bias" buffer (>= 4 KiB)
     return launch_gemm_algo(g, epi, algo, as_stream(stream));
 }
@@ -399,7 +408,8 @@ extern "C" int clipmi_dbg_gemm_resid_ln(const void* a_dev, const void* w_dev, co
     g.xhi = static_cast<unsigned short*>(xhi_dev); g.xlo = static_cast<unsigned short*>(xlo_dev);
     g.ln_part = part_dev; g.tmp_f32 = tmp_dev;
     g.M = M; g.N = N; g.K = K;
-    if (const char* e = getenv("CLIPMI_GEMM_DBG")) g.dbg = atoi(e);
+    static const int dbg_env = (int)dev_knob("CLIPMI_GEMM_DBG", 0);
+    g.dbg = dbg_env;
     return launch_gemm_algo(g, EPI_BIAS_RESID_LN_F32, algo & 7, as_stream(stream));
 }
 

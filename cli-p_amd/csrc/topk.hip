@@ -1188,6 +1188,7 @@ struct LiveArgs {
     unsigned* stats;             // [12] pushed | push spins | popped | stale | re-scored | inserted | batches | ladder rises
 };
 
+#ifdef CLIPMI_DEV      // experimental: compiled into the development library only
 template <int QG, int NSCAN = 4>
 __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1639,6 +1640,8 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
     }
 }
 
+#endif  // CLIPMI_DEV
+
 // =================================================================================================
 // Wide coarse pass (int8 copy only): ONE stream of the copy for up to WIDE_MAX_Q = 1024 queries of one search call
 // (reference: query-index.py:111 is one index.search call; SURVEY.md §8d "DB streamed once per batch").
@@ -1791,12 +1794,15 @@ __global__ void __launch_bounds__(WAVES * 64) scan_coarse_wide_kernel(WideArgs a
             // s the block's scale). Integer pre-test, one per lane (= query): no row of the block can pass unless
             // D >= (T_q - amax_block Y_q) / s, rounded down with slack for the f32 roundings on both sides (|D| < 2^23 is exact
             // in f32; each side rounds a few times at ~1e-7 relative) - so the lane's largest D decides, and the per-row test
-            // runs only where it can succeed. +inf thresholds (padding queries) saturate to "never", -inf (no threshold yet)
-            // and NaN to "always".
+            // runs only where it can succeed. +inf thresholds (padding queries: any Q that is not a multiple of 32) are "never" by
+            // an explicit test - inf - inf below would be NaN = "always", and every block would then run the 16-ballot append
+            // path for its padding lanes; an all-zero block (s = 0: inv_s = inf) clamps to +-1e9 by its sign;
+            // -inf (no threshold yet) and NaN stay "always".
             auto pretest = [&](const i32x16& acc, float tq, float yq) -> bool {
+                if (tq == INFINITY) return false;
                 float xq = fmaf(-bm.y, yq, tq) * inv_s;
+                xq = fminf(fmaxf(xq, -1.0e9f), 1.0e9f);                   // before the slack: no inf - inf; fmaxf(NaN, c) = c: NaN -> always
                 xq = xq - 2.0f - fabsf(xq) * 2e-6f;
-                xq = fminf(fmaxf(xq, -1.0e9f), 1.0e9f);                   // fmaxf(NaN, c) = c: NaN -> always
                 const int dmin = (int)floorf(xq);
                 auto max3 = [](int a_, int b_, int c_) { const int m_ = a_ > b_ ? a_ : b_; return m_ > c_ ? m_ : c_; };
                 const int m0 = max3(acc[0], acc[1], acc[2]), m1 = max3(acc[3], acc[4], acc[5]), m2 = max3(acc[6], acc[7], acc[8]);
@@ -2160,8 +2166,12 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
     // launch, half the re-scored pairs, but 2.3 ms per 10 M-row scan against 0.9 ms for the three segmented scans (r03): its
     // 138 KB of LDS leave one workgroup = FOUR scanner waves per CU with one 16 KB step in flight each, a quarter of the bytes
     // in flight the segmented kernel's 16 waves per CU keep, and the scan is HBM-latency bound.
-    static const bool live_on = [] { const char* e = getenv("CLIPMI_LIVE"); return e && atoi(e) == 1; }();
+#ifdef CLIPMI_DEV
+    static const bool live_on = dev_knob("CLIPMI_LIVE", 0) == 1;
     const bool live = i8 && live_on && N < (1ll << LIVE_ROW_BITS);
+#else
+    constexpr bool live = false;
+#endif
 
     for (int q0 = 0; q0 < Q; q0 += COARSE_Q) {
         const int qa = (Q - q0) < COARSE_Q ? (Q - q0) : COARSE_Q;
@@ -2258,6 +2268,7 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
         float* os_final = out_score_dev + (size_t)q0 * K;
         long long* oi_final = (long long*)out_id_dev + (size_t)q0 * K;
         long long r_done = 0;
+#ifdef CLIPMI_DEV
         if (live) {
             // ONE launch over all rows: scanners + re-scoring waves, thresholds rising through the ladder (scan_coarse_live_kernel)
             LiveArgs la;
@@ -2265,11 +2276,11 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             la.q = qg; la.qmeta = w.qmeta; la.qimage = w.qimage; la.nrows = N; la.QA = qa; la.K = K;
             la.tau_key = w.live_keys; la.tex_key = w.live_keys + COARSE_Q; la.edge0 = w.live_edges; la.delta = w.live_edges + COARSE_Q;
             la.hist = w.hist; la.cand = w.cand_c; la.gcnt = w.gcnt_c; la.cap = COARSE_CAP; la.overflow = w.flag; la.chunk_ctr = w.flag + 1;
-            static const int live_wb = [] { const char* e = getenv("CLIPMI_LIVE_WB"); const int v = e ? atoi(e) : LIVE_WB; return v < 8 ? 8 : v; }();
+            static const int live_wb = [] { const int v = (int)dev_knob("CLIPMI_LIVE_WB", LIVE_WB); return v < 8 ? 8 : v; }();
             la.wb = live_wb;
-            static const bool live_stats = getenv("CLIPMI_LIVE_STATS") != nullptr;
+            static const bool live_stats = dev_knob_set("CLIPMI_LIVE_STATS");
             la.stats = live_stats ? w.flag + 4 : nullptr;
-            static const int live_abl = [] { const char* e = getenv("CLIPMI_LIVE_ABL"); return e ? atoi(e) : 0; }();
+            static const int live_abl = (int)dev_knob("CLIPMI_LIVE_ABL", 0);
             la.abl = live_abl;
             const int QGl = qa <= 16 ? 1 : qa <= 32 ? 2 : 4;
             size_t lds = (size_t)QGl * 8 * 1024 + (size_t)LIVE_QN * 8 + 64 + 512 + 1024 + 64;
@@ -2279,7 +2290,7 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             if (int rc = opt_in_lds(fn, lds)) return rc;
             long long g_ = ((N + 31) / 32 + 3) / 4;
             const int grid = (int)(g_ < NUM_CU ? g_ : NUM_CU);
-            static const int live_nscan = [] { const char* e = getenv("CLIPMI_LIVE_NSCAN"); return e ? atoi(e) : 6; }();
+            static const int live_nscan = (int)dev_knob("CLIPMI_LIVE_NSCAN", 6);
             if (scan_ev) (void)hipEventRecord(scan_ev[0], st);
             if (QGl == 4 && live_nscan == 5) {
                 if (int rc = opt_in_lds((const void*)scan_coarse_live_kernel<4, 5>, lds)) return rc;
@@ -2299,8 +2310,9 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
                                (const unsigned*)nullptr, w.last_m, 0, scap, (float*)nullptr);
             CLIPMI_CHECK_LAUNCH("select_topk_kernel(live)");
         }
+#endif
         // development knob: CLIPMI_COARSE_SEGS=n (>= 4): n geometric segments from 64 k rows, as the wide pass plans them
-        static const int nseg_env = [] { const char* e = getenv("CLIPMI_COARSE_SEGS"); return e ? atoi(e) : 0; }();
+        static const int nseg_env = (int)dev_knob("CLIPMI_COARSE_SEGS", 0);
         if (live) {
         } else if (two_level && nseg_env >= 4 && N >= (1 << 20)) {
             long long b = 65536;
@@ -2367,15 +2379,12 @@ size_t carve_wide(const Plan& p, int Qc, void* base, size_t cap, WideWs* w) {
 }
 
 bool wide_disabled() {          // CLIPMI_WIDE=0: searches of more than 64 queries as 64-query passes (A/B aid)
-    static const bool off = [] { const char* e = getenv("CLIPMI_WIDE"); return e && atoi(e) == 0; }();
+    static const bool off = dev_knob("CLIPMI_WIDE", 1) == 0;
     return off;
 }
 
 int wide_waves() {
-    static const int w = [] {
-        const char* e = getenv("CLIPMI_WIDE_WAVES");
-        return e && atoi(e) == 4 ? 4 : 8;
-    }();
+    static const int w = dev_knob("CLIPMI_WIDE_WAVES", 8) == 4 ? 4 : 8;
     return w;
 }
 
@@ -2399,8 +2408,8 @@ int launch_wide_t(const WideArgs& a, hipStream_t st, hipEvent_t* ev) {
 // (measured at 10 M rows, Q = 1024, same box: ratio 4 158 k q/s, 5 150 k, 6 152 k, 8 149 k, 3 146 k).
 constexpr int WIDE_MAX_SEGS = 8;
 int wide_segments(long long N, int K, long long S1, long long* b) {
-    static const long long first = [] { const char* e = getenv("CLIPMI_WIDE_SEG0"); return e ? atoll(e) : 0ll; }();
-    static const int ratio = [] { const char* e = getenv("CLIPMI_WIDE_SEG_RATIO"); return e && atoi(e) >= 2 ? atoi(e) : 4; }();
+    static const long long first = dev_knob("CLIPMI_WIDE_SEG0", 0);
+    static const int ratio = [] { const int r = (int)dev_knob("CLIPMI_WIDE_SEG_RATIO", 4); return r >= 2 ? r : 4; }();
     long long s = first > 0 ? first : 65536;
     if (s < S1) s = S1;
     s = (s + 31) & ~31ll;
@@ -2453,7 +2462,7 @@ int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta,
             long long gs = ((S1 + 15) / 16 + 3) / 4;
             if (gs > NUM_CU) gs = NUM_CU;
             const int ngroups = (qc + 15) / 16;
-            static const int sdiv = [] { const char* e = getenv("CLIPMI_WIDE_SAMPLE_DIV"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
+            static const int sdiv = [] { const int d = (int)dev_knob("CLIPMI_WIDE_SAMPLE_DIV", 8); return d > 0 ? d : 8; }();
             if (ngroups >= 8 && gs > sdiv) gs = (gs + sdiv - 1) / sdiv;
             hipLaunchKernelGGL(sample_scores_kernel<512>, dim3((unsigned)gs, (unsigned)ngroups), dim3(256), lds1, st,
                                static_cast<const float*>(db_dev), S1, qg, qc, w.cand_c, (long long)WIDE_CAP, w.gcnt_c);
@@ -2470,7 +2479,10 @@ int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta,
         c.nqt = (nsets + WIDE_TILE_SETS - 1) / WIDE_TILE_SETS;
         c.spt = (nsets + c.nqt - 1) / c.nqt;
         c.cand = w.cand_c; c.gcnt = w.gcnt_c; c.cap = WIDE_CAP; c.overflow = w.flag;
-        { const char* e = getenv("CLIPMI_WIDE_MAP"); c.map_mode = e ? atoi(e) : 0; e = getenv("CLIPMI_WIDE_PF"); c.pf_mode = e ? atoi(e) : 0; }
+        {
+            static const int map_env = (int)dev_knob("CLIPMI_WIDE_MAP", 0), pf_env = (int)dev_knob("CLIPMI_WIDE_PF", 0);
+            c.map_mode = map_env; c.pf_mode = pf_env;
+        }
         long long bnd[WIDE_MAX_SEGS];
         const int nseg = wide_segments(N, K, S1, bnd);
         float* os_final = out_score_dev + (size_t)q0 * K;
@@ -2482,10 +2494,14 @@ int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta,
             c.row0 = r0;
             c.nrows = bnd[sgi] - r0;
             hipEvent_t* ev = (scan_ev && ev_used + 2 <= max_ev) ? scan_ev + ev_used : nullptr;
-            static const int abl = [] { const char* e = getenv("CLIPMI_WIDE_ABL"); return e ? atoi(e) : 0; }();
+#ifdef CLIPMI_DEV
+            static const int abl = (int)dev_knob("CLIPMI_WIDE_ABL", 0);        // ablations + the 4-wave form: development build only
             if (int rc = abl == 1 ? launch_wide_t<8, 1>(c, st, ev) : abl == 2 ? launch_wide_t<8, 2>(c, st, ev)
                        : abl == 3 ? launch_wide_t<8, 3>(c, st, ev)
                        : wide_waves() == 4 ? launch_wide_t<4>(c, st, ev) : launch_wide_t<8>(c, st, ev)) return rc;
+#else
+            if (int rc = launch_wide_t<8>(c, st, ev)) return rc;
+#endif
             if (ev) ev_used += 2;
             hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(12, qc), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
                                static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, WIDE_CAP);
@@ -2581,10 +2597,12 @@ __global__ void __launch_bounds__(256) rows_stats_kernel(const float* __restrict
         const double nd = sqrt(acc);
         float nf = (float)nd;
         if ((double)nf < nd) nf = nextafterf(nf, INFINITY);
-        best = nf > best ? nf : best;
+        // a NaN row (or NaN error norm) must surface as a non-finite maximum: the index then keeps the search on the exact
+        // path (index.py: isfinite(rmax)); `nf > best` alone would silently drop it
+        best = !(nf == nf) ? INFINITY : (nf > best ? nf : best);
         if (meta && lane == 0) {
             const float a_ = meta[r].y;
-            abest = a_ > abest ? a_ : abest;
+            abest = !(a_ == a_) ? INFINITY : (a_ > abest ? a_ : abest);
         }
     }
     if (lane == 0) {
@@ -2680,7 +2698,7 @@ static int dbg_coarse_scan_ms(const void* db_dev, const void* db_bf16_dev, bool 
     }
     for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ev[i]);
     if (rc == 0) *scan_ms = (float)(total / reps);
-    if (rc == 0 && getenv("CLIPMI_LIVE_STATS")) {
+    if (rc == 0 && dev_knob_set("CLIPMI_LIVE_STATS")) {
         Plan p; CoarseWs w; coarse_plan(N, E, Q, K, p); carve_coarse(p, ws_dev, ws_bytes, &w);
         unsigned h[28];
         if (hipMemcpy(h, w.flag + 4, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {

@@ -55,7 +55,7 @@ int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int 
     const int nt = (L + 15) / 16;
     // development switch for A/B runs on one box: CLIPMI_ATTN52=0 keeps ViT-B/32 on attention_kernel<4>
     // (CLIPMI_ATTN52: 0 = attention_kernel<4>, 1 = attention52_kernel, default 2 = attention52x4_kernel)
-    static const int use52 = [] { const char* e = getenv("CLIPMI_ATTN52"); return e ? atoi(e) : 2; }();
+    static const int use52 = (int)dev_knob("CLIPMI_ATTN52", 2);
     if (L >= 49 && L <= 52 && !causal && tr == 1 && use52 == 2) {
         // one workgroup per (image, head), one query tile per wave
         const long long items = (long long)B * heads;

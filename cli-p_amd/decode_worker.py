@@ -199,6 +199,8 @@ def _close_all(segments):
 
 
 if __name__ == "__main__":
+    import signal
+    signal.signal(signal.SIGINT, signal.SIG_IGN)      # Ctrl-C is the parent's business; a worker leaves at EOF on stdin
     try:
         serve(sys.stdin.buffer, sys.stdout.buffer)
     except (BrokenPipeError, KeyboardInterrupt):

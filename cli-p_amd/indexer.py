@@ -113,6 +113,13 @@ def ingest_shards(db, store_path):
     return n
 
 
+def _undecodable(bad, pool):
+    """The failed files that may go to skip_db: those a decoder REJECTED. A file whose decode worker died under it (killed,
+    out of memory) failed for this run only and is retried by the next one."""
+    lost = getattr(pool, "lost", None)
+    return [b for b in bad if b not in lost] if lost else bad
+
+
 def encode_directories(dirs, model, db, batch, workers, ranks=None, pool=None, stop=None, store_path="vectors.lmdb"):
     """ranks=None or world 1: the single-GPU loop. Otherwise `db` is only used on rank 0 (others pass None), every rank
     writes `shard_path(store_path, rank)` and rank 0 ingests the shards at the end; returns True when the ranks agreed to
@@ -125,7 +132,7 @@ def encode_directories(dirs, model, db, batch, workers, ranks=None, pool=None, s
             for ok, feats, bad in pipeline.encode_files(model, todo, batch=batch, workers=workers, pool=pool):
                 if ok:
                     db.put_vectors(ok, feats)
-                db.mark_skipped(bad)
+                db.mark_skipped(_undecodable(bad, pool))
                 print("." * len(ok) + "#" * len(bad), end="", flush=True)
             print(flush=True)
         return False
@@ -155,9 +162,14 @@ def encode_directories(dirs, model, db, batch, workers, ranks=None, pool=None, s
                         if stop is not None:
                             stop.set = True
                         ok, feats, bad = [], None, []
+                    if stop is not None and stop.set:
+                        # the signal arrived while this round was being decoded / encoded: nothing of it is committed
+                        # (a terminal's Ctrl-C goes to the whole process group - a decode worker it killed would report
+                        # its current file as failed); the files stay candidates for the next run
+                        ok, feats, bad = [], None, []
                 if ok:
                     shard.put_vectors(ok, feats)       # this rank's own shard: one commit per batch
-                shard.mark_skipped(bad)
+                shard.mark_skipped(_undecodable(bad, pool))
                 flags = ranks.all_gather_ints([len(ok), len(bad), 1 if (stop is not None and stop.set) else 0])
                 if ranks.leader:
                     print("".join("." * f[0] + "#" * f[1] for f in flags), end="", flush=True)   # rank order = list order

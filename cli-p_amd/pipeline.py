@@ -30,8 +30,22 @@ class DecodePool:
         import sys
         self.n = max(1, int(workers))
         script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "decode_worker.py")
-        self.procs = [subprocess.Popen([sys.executable, script], stdin=subprocess.PIPE, stdout=subprocess.PIPE)
-                      for _ in range(self.n)]
+        # own session: a Ctrl-C at the terminal reaches the ranks (which finish their round: indexer.StopFlag), not the
+        # workers - a worker that exited on SIGINT used to turn its current file into a "failed" file that was then
+        # written to skip_db and never retried. The workers also ignore SIGINT themselves and leave at EOF on stdin.
+        import signal
+        import threading
+        restore = None
+        if threading.current_thread() is threading.main_thread():
+            restore = signal.signal(signal.SIGINT, signal.SIG_IGN)      # inherited across exec: ignored from the first instruction
+        try:
+            self.procs = [subprocess.Popen([sys.executable, script], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                           start_new_session=True)
+                          for _ in range(self.n)]
+        finally:
+            if restore is not None:
+                signal.signal(signal.SIGINT, restore)
+        self.lost = set()           # files a worker DIED on: failed for this run, but not proven undecodable (never skip_db)
         self._all_procs = list(self.procs)
         self.threads = ThreadPoolExecutor(max_workers=self.n)
         self.segs = [None, None, None, None]      # 0, 1: the n_px x n_px slots of two batches in turn; 2, 3: their full-size regions
@@ -140,6 +154,7 @@ class DecodePool:
                 pass
             if len(ok) < len(jobs):                # the worker died on file len(ok): that one failed, the rest in-process
                 self.procs[w] = None
+                self.lost.add(jobs[len(ok)][1])    # ... for this run only: the caller must not record it as undecodable
                 ok.append((jobs[len(ok)][0], False))
         for slot, path in jobs[len(ok):]:
             try:

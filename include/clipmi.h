@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CLIPMI_ABI_VERSION 3
+#define CLIPMI_ABI_VERSION 4
 
 enum {
     CLIPMI_OK = 0,
@@ -94,7 +94,9 @@ typedef struct clipmi_tower {
     /* ABI 2. weight_format 0: the four linear layers of every block are bf16 (above). weight_format 1
        (BASELINE.json configs[4], FP8 matrix cores): lo_qkv_w / lo_out_w / lo_fc_w / lo_proj_w point at OCP e4m3
        bytes [out_features][in_features] and lo_*_s at f32 [out_features] per-output-channel scales
-       (weight = scale * e4m3 value); activations are quantised per row on the fly. Needs width % 256 == 0. */
+       (weight = scale * e4m3 value). Activations travel as e4m3 with MX block scales (one e8m0 scale 2^(e-7) per 32
+       consecutive values of a row, written by the producing kernel: attention, the QuickGELU GEMM) or, where a producer
+       sees whole rows (LayerNorm), with one f32 scale per row. Needs width % 256 == 0. */
     int32_t weight_format, ln_fold;
     uint64_t lo_qkv_s, lo_out_s, lo_fc_s, lo_proj_s;
 

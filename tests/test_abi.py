@@ -27,6 +27,22 @@ def test_library_exports_every_declared_symbol(clipmi):
     assert L.clipmi_abi_version() == clipmi._lib.ABI_VERSION
 
 
+def test_product_library_reads_no_environment_and_ships_no_lab_kernels(clipmi):
+    """The product library imports no getenv (the CLIPMI_* A/B knobs exist in the -DCLIPMI_DEV build only) and does not
+    contain the laboratory kernels that no product path selects (live-threshold scan, gemm2w); the development library,
+    which tools/ and two child-process tests load with CLIPMI_DEV_LIB=1, has both."""
+    lib = os.path.join(ROOT, "cli-p_amd", "libclipmi.so")
+    dev = os.path.join(ROOT, "cli-p_amd", "libclipmi_dev.so")
+    assert clipmi._lib.LIB_PATH == lib
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", lib], text=True)
+    assert "getenv" not in undefined
+    blob = open(lib, "rb").read()
+    assert b"scan_coarse_live_kernel" not in blob and b"gemm2w_resid_ln_kernel" not in blob
+    assert os.path.exists(dev), "build() also builds libclipmi_dev.so"
+    assert "getenv" in subprocess.check_output(["nm", "-D", "--undefined-only", dev], text=True)
+    assert b"scan_coarse_live_kernel" in open(dev, "rb").read()
+
+
 def test_tower_struct_matches_header(clipmi, tmp_path):
     """sizeof/offsetof of the ctypes mirror equal the C compiler's view of the header."""
     src = tmp_path / "t.c"

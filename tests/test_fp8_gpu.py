@@ -293,7 +293,7 @@ def test_fp8_fused_producers_write_the_standalone_quantizers_bytes(clipmi, gpu, 
     for k, fuse in enumerate(("1", "0")):
         f = str(tmp_path / f"e{k}.pt")
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fp8_fuse_check.py"), "300", f],
-                           env=dict(os.environ, CLIPMI_FP8_FUSE=fuse), capture_output=True, text=True, timeout=600)
+                           env=dict(os.environ, CLIPMI_FP8_FUSE=fuse, CLIPMI_DEV_LIB="1"), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(torch.load(f))
     assert torch.isfinite(outs[0]).all()

@@ -129,6 +129,39 @@ def test_decode_pool_matches_in_process_decode(clipmi, tmp_path):
         assert (g[1] is None and r[1] is None) or np.array_equal(g[1], r[1])
 
 
+def test_ctrl_c_does_not_turn_good_files_into_skipped_files(clipmi, tmp_path, monkeypatch):
+    """a terminal's Ctrl-C goes to the whole process group. The decode workers sit in their own
+    session and ignore SIGINT, so it never reaches them; and a file whose worker DIED under it (here: killed) fails for
+    this run only - it is kept out of skip_db and the next run encodes it."""
+    import signal, time
+    from PIL import Image
+    bi = _load_script("build-index.py")
+    d = tmp_path / "lib"
+    d.mkdir()
+    rng = np.random.default_rng(8)
+    for i in range(6):
+        Image.fromarray(rng.integers(0, 256, (40, 40, 3), dtype=np.uint8)).save(str(d / f"p{i}.png"))
+    (d / "broken.jpg").write_bytes(b"not an image")
+    base = str(d) + "/"
+    monkeypatch.chdir(tmp_path)
+    db = clipmi.store.VectorStore("vectors.lmdb", dim=512, backend="packed")
+    with clipmi.pipeline.DecodePool(2) as pool:
+        assert all(os.getpgid(p.pid) != os.getpgid(0) for p in pool.procs)     # not in the terminal's foreground group
+        os.kill(pool.procs[0].pid, signal.SIGINT)                              # and a stray SIGINT is ignored
+        time.sleep(0.2)
+        assert pool.procs[0].poll() is None
+        pool.procs[1].kill()                                                   # a worker that dies under its first file
+        pool.procs[1].wait()
+        bi.encode_directories([base], _StubModel(), db, batch=4, workers=2, pool=pool)
+        assert len(pool.lost) == 1
+        lost = next(iter(pool.lost))
+    assert db.is_skipped(base + "broken.jpg") and not db.is_skipped(lost) and not db.has_vector(lost)
+    assert bi.candidates(base, db) == [lost]                                   # retried by the next run
+    bi.encode_directories([base], _StubModel(), db, batch=4, workers=2)
+    assert db.count() == 6 and bi.candidates(base, db) == []
+    db.close()
+
+
 class _StubModel:
     """encode_image/encode_text that are deterministic functions of the input (CPU, test only)."""
     embed_dim, context_length = 512, 77

@@ -103,6 +103,28 @@ def test_topk_nan_inf_rows(clipmi, gpu, topk_oracle):
     assert 3 not in I
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("poison", ["nan", "inf"])
+def test_non_finite_rows_keep_a_coarse_size_database_exact(clipmi, gpu, topk_oracle, poison):
+    """a database large enough for the coarse path (N >= 65536) that holds a NaN / inf row must still return
+    the oracle's result: clipmi_rows_stats reports a non-finite maximum (a NaN used to vanish from `nf > best`), so the
+    index keeps such data on the exact scan, for 3 queries (one pass) and for 200 (the wide pass's shape)."""
+    rng = np.random.default_rng(29)
+    db = unit_rows(rng, 70000, 512)
+    db[4321, 17] = np.nan if poison == "nan" else np.inf
+    idx = clipmi.IndexFlatIP(512, device=gpu)
+    idx.add(db)
+    assert idx.uses_coarse()
+    for Q in (3, 200):
+        q = np.abs(unit_rows(rng, Q, 512)) + 0.01
+        D, I = idx.search(q, 20)
+        Ds, Is = topk_oracle.topk(db, q, 20)
+        _assert_exact(D, I, Ds, Is, f"{poison} row, Q = {Q}")
+    assert not np.isfinite(idx.matrix_i8()[3]) or not np.isfinite(idx.matrix_i8()[2])
+    if poison == "nan":
+        assert 4321 not in I
+
+
 def test_sharded_equals_single(clipmi, gpu, topk_oracle):
     """Size-independent property at scale: split N rows into R contiguous shards, search each
     with its id_base, merge with clipmi_merge_topk == single-pass result == oracle merge."""
@@ -659,7 +681,7 @@ def test_live_threshold_scan_is_bit_exact_when_enabled():
     exact f32 scan's bits. The switch is read once per process, so the check runs in a child."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CLIPMI_LIVE="1")
+    env = dict(os.environ, CLIPMI_LIVE="1", CLIPMI_DEV_LIB="1")      # the kernel lives in the development library only
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "live_check.py"), "300000", "1,16,64"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -1,5 +1,6 @@
 """Encode step A/B of env knobs (development aid): ms per step of B = 870, bf16, min of 3 x 8 steps."""
 import sys, os, time
+os.environ.setdefault("CLIPMI_DEV_LIB", "1")   # A/B knobs: development library only
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import clipmi

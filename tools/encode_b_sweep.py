@@ -1,5 +1,6 @@
 """encode images/s over batch sizes (development aid); CLIPMI_GEMM_SPLIT=0/1 A/B of the whole-rounds + remainder split."""
 import sys, os, time
+os.environ.setdefault("CLIPMI_DEV_LIB", "1")   # A/B knobs: development library only
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import clipmi

@@ -1,6 +1,7 @@
 """FP8 tower: embeddings of B random images to a file (development aid / child of test_fp8_fused_producers...).
 usage: [CLIPMI_FP8_FUSE=0] python tools/fp8_fuse_check.py B out.pt"""
 import sys, os, time
+os.environ.setdefault("CLIPMI_DEV_LIB", "1")   # A/B knobs: development library only
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import clipmi

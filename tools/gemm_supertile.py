@@ -1,6 +1,7 @@
 """Supertile shape (GM row panels x GN column panels run together inside one XCD) of the persistent GEMM's tile order:
 time per launch for the ViT-B/32 shapes at B = 870 (development aid; CLIPMI_GEMM_DBG carries GM << 8 | GN << 16)."""
 import sys, os, subprocess
+os.environ.setdefault("CLIPMI_DEV_LIB", "1")   # A/B knobs: development library only
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch

@@ -1,5 +1,6 @@
 """In-kernel wall-clock stamps of the persistent GEMM (development aid; CLIPMI_GEMM_DBG=4[+1/2])."""
 import sys, os
+os.environ.setdefault("CLIPMI_DEV_LIB", "1")   # A/B knobs: development library only
 os.environ["CLIPMI_GEMM_DBG"] = os.environ.get("CLIPMI_GEMM_DBG", "4")
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

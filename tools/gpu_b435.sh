@@ -1,4 +1,5 @@
 #!/bin/bash
+export CLIPMI_DEV_LIB=1   # the CLIPMI_* A/B knobs are read by the development library only (build.py --dev)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$ROOT"; mkdir -p gpurun_out
 for rep in 1 2; do
 for v in 2 1; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export CLIPMI_DEV_LIB=1   # the CLIPMI_* A/B knobs are read by the development library only (build.py --dev)
 # final-build evidence: the FP8 encode step and the live-threshold search, kernel by kernel. usage: bash tools/gpu_timelines_r03d.sh <tag>
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 tag=${1:-r03d}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export CLIPMI_DEV_LIB=1   # the CLIPMI_* A/B knobs are read by the development library only (build.py --dev)
 # GPU-box helper: wide pass check + timing + kernel timeline
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$ROOT"; mkdir -p gpurun_out
 export TMPDIR=/tmp

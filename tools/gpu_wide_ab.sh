@@ -1,4 +1,5 @@
 #!/bin/bash
+export CLIPMI_DEV_LIB=1   # the CLIPMI_* A/B knobs are read by the development library only (build.py --dev)
 # ablations of the wide kernel (development): duration of the last segment's scan under each
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 for abl in 0 1 2 3; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export CLIPMI_DEV_LIB=1   # the CLIPMI_* A/B knobs are read by the development library only (build.py --dev)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 for cfg in "65536 3" "32768 4" "32768 3" "16384 4" "16384 3" "65536 2"; do
 set -- $cfg

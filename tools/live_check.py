@@ -1,5 +1,6 @@
 """Live-threshold scan (development aid): bit-exactness vs the exact f32 scan + timing at several N / Q."""
 import sys, os, time
+os.environ.setdefault("CLIPMI_DEV_LIB", "1")   # A/B knobs: development library only
 os.environ.setdefault("CLIPMI_LIVE", "1")      # the live scan is off by default (topk.hip)
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

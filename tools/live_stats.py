@@ -1,5 +1,6 @@
 """Statistics of the live-threshold scan (development aid): CLIPMI_LIVE_STATS=1 python tools/live_stats.py [N] [Q]"""
 import sys, os, ctypes as C
+os.environ.setdefault("CLIPMI_DEV_LIB", "1")   # A/B knobs: development library only
 os.environ["CLIPMI_LIVE_STATS"] = "1"
 os.environ.setdefault("CLIPMI_LIVE", "1")      # the live scan is off by default (topk.hip)
 import torch

@@ -1,6 +1,7 @@
 """A/B of the search leg only (development aid): prints one-in-flight / two-in-flight ms at Q = 1, 16, 32, 64 over N rows.
 usage: [CLIPMI_LIVE=1 CLIPMI_LIVE_NSCAN=6] python tools/search_ab.py [N]"""
 import sys, os, time
+os.environ.setdefault("CLIPMI_DEV_LIB", "1")   # A/B knobs: development library only
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import clipmi
