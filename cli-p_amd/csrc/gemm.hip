@@ -57,6 +57,23 @@ static int launch_epi256(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
     return 0;
 }
 
+#ifdef CLIPMI_DEV
+// development: the W-direct form of gemm256 (gemm256.hpp WD = true), algo 5 of the test hooks
+template <int EPI, int WD = 1>
+static int launch_epi256wd(const GemmArgs& g, hipStream_t st) {
+    const int grid = (g.N / 256) * ((g.M + 255) / 256);
+    static thread_local int opted[64];
+    if (!lds_opted(opted)) {
+        if (hipFuncSetAttribute((const void*)gemm256_bf16_nt_kernel<EPI, WD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G256_LDS) != hipSuccess)
+            return set_err(CLIPMI_EHIP, "hipFuncSetAttribute(gemm256 WD, %d B LDS)", G256_LDS);
+    }
+    hipLaunchKernelGGL((gemm256_bf16_nt_kernel<EPI, WD>), dim3(grid), dim3(512), G256_LDS, st, g);
+    CLIPMI_CHECK_LAUNCH("gemm256_bf16_nt_kernel<WD>");
+    return 0;
+}
+#endif
+
 // persistent, role-split 256x256 kernel (gemm256p.hpp): pure-store epilogues only
 static int persist_mode() {
     // development switch for A/B runs on one box: CLIPMI_GEMM_PERSIST=0 keeps every GEMM on gemm256
@@ -165,8 +182,16 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmP
          (const char*)g.xlo < (const char*)g.xhi || (const char*)g.xlo - (const char*)g.xhi >= (1ll << 31) - (long long)256 * g.N * 2))
         return set_err(CLIPMI_EINVAL, "gemm: EPI_BIAS_RESID_LN_F32 needs xhi <= xlo < xhi + 2 GiB, ln_part, tmp_f32 and N %% 256 == 0, N <= 1024");
 #ifndef CLIPMI_DEV
-    if (algo == 4) return set_err(CLIPMI_EUNSUPPORTED, "gemm2w exists in the development build only (libclipmi_dev.so)");
+    if (algo == 4 || algo == 5) return set_err(CLIPMI_EUNSUPPORTED, "algo %d exists in the development build only (libclipmi_dev.so)", algo);
 #else
+    if (algo == 5) {
+        if (g.N % 256 != 0 || g.K % 64 != 0 || g.K < 128 || g.M < 1 || !g.A || !g.W || !g.out)
+            return set_err(CLIPMI_EINVAL, "gemm256 WD: N %% 256 == 0, K %% 64 == 0, K >= 128");
+        if (epi == EPI_BIAS_BF16) return launch_epi256wd<EPI_BIAS_BF16>(g, st);
+        if (epi == EPI_BIAS_QGELU_BF16) return launch_epi256wd<EPI_BIAS_QGELU_BF16>(g, st);
+        if (epi == EPI_F32) return launch_epi256wd<EPI_F32>(g, st);
+        return set_err(CLIPMI_EINVAL, "gemm256 WD: epilogue %d", epi);
+    }
     if (algo == 4) {
         if (epi != EPI_BIAS_RESID_LN_F32 || !g2w_ok(g) || !g.A || !g.W)
             return set_err(CLIPMI_EINVAL, "gemm2w: the residual producer only (N %% 256 == 0, N <= 1024, K %% 32 == 0, K >= 64)");
@@ -364,7 +389,7 @@ using namespace clipmi;
 
 extern "C" int clipmi_dbg_gemm_bf16(const void* a_dev, const void* w_dev, const float* bias_dev, void* out_dev, int M,
                                     int N, int K, int epi, void* stream) {
-    const int algo = (epi >> 8) & 3;      // test hook: bits 8-9 force a kernel (see launch_gemm_algo)
+    const int algo = (epi >> 8) & 7;      // test hook: bits 8-10 force a kernel (see launch_gemm_algo)
     epi &= 0xff;
     if (epi < 0 || epi > 3) return set_err(CLIPMI_EINVAL, "dbg_gemm: epi %d", epi);
     GemmArgs g{};

@@ -40,7 +40,23 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int EPI>
+// WD = true (development build, DESIGN 4.4h "W fragments straight from L2"): the W operand never enters LDS. Every wave
+// loads its own B fragments (16 rows x 64 B per instruction, the fragment shape of v_mfma_f32_16x16x32_bf16) with
+// global_load_dwordx4 straight into the registers the MFMAs read, two phases ahead of their first use and INTO the
+// registers of the fragments they replace - no second register set: the phase order becomes
+//   P0: A-lo x B-lo   P1: A-hi x B-lo   P2: A-hi x B-hi   P3: A-lo x B-hi   (A-lo is read from LDS twice)
+// so that B-lo is dead after P1 (reloaded in P2 for the next K-tile's P0) and B-hi after P3 (reloaded in P0 for P2).
+// Only the A half-tiles go through LDS-DMA: half the LDS-DMA bytes per K-tile. Every accumulator still receives its
+// K-steps in the same order: bit-identical results. vmcnt is counted by hand over BOTH kinds (the loads are inline asm:
+// beside LDS-DMA in flight the compiler would wait vmcnt(0) for an ordinary load); per K-tile and wave, in issue order:
+//   P0: LD B-hi(t) x4 | P1: DMA A-lo(t+1) x2 | P2: LD B-lo(t+1) x4, DMA A-hi(t+1) x2
+//   waits: P0 vmcnt(4) retires A-hi(t) [read in P1]; P2 vmcnt(8) retires B-hi(t) [used in P2]; P3 vmcnt(2) retires
+//   B-lo(t+1), A-lo(t+1) [used / read in P0 of t+1].
+// WAR on LDS: A-lo(t+1) lands in the buffer whose A-lo region group 1 finishes reading (P3 of t-1) one slot into P0(t);
+// its DMA is issued in P1(t), two slots later - the margin of the original schedule.
+// (A second register set for the fragments - the whole next K-tile requested four to six phases ahead - was measured too:
+//  256 VGPRs with 13 spills, slower still: 538-572 TF against 682-743 for this form and 1000-1260 for the LDS-DMA form.)
+template <int EPI, int WD = 0>
 __global__ void __launch_bounds__(512, 2) gemm256_bf16_nt_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -97,8 +113,9 @@ __global__ void __launch_bounds__(512, 2) gemm256_bf16_nt_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    typedef int b128v __attribute__((ext_vector_type(4)));      // 16 bytes of fragment as a plain register quad (asm "=v")
     bf16x8 af[4][2];           // current A half: [mt][ks]
-    bf16x8 bl[2][2], bh[2][2]; // B-lo / B-hi: [nt][ks]
+    b128v bl[2][2], bh[2][2];  // B-lo / B-hi: [nt][ks]
 
 #define G256_READ_A(base, half)                                                                      \
     _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                               \
@@ -107,8 +124,8 @@ __global__ void __launch_bounds__(512, 2) gemm256_bf16_nt_kernel(GemmArgs g) {
     }
 #define G256_READ_B(dst, base, half)                                                                 \
     _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {                                               \
-        dst[t_][0] = *reinterpret_cast<const bf16x8*>((base) + (half) * G256_HALF + offB + t_ * 2048 + c0); \
-        dst[t_][1] = *reinterpret_cast<const bf16x8*>((base) + (half) * G256_HALF + offB + t_ * 2048 + c1); \
+        dst[t_][0] = *reinterpret_cast<const b128v*>((base) + (half) * G256_HALF + offB + t_ * 2048 + c0); \
+        dst[t_][1] = *reinterpret_cast<const b128v*>((base) + (half) * G256_HALF + offB + t_ * 2048 + c1); \
     }
     // MFMA slot: 16 MFMAs of quadrant (A half a, B half b); D = Wfrag x Afrag (C^T tile, see gemm.hpp)
 #define G256_MFMA(a, bfr, b)                                                                         \
@@ -119,13 +136,71 @@ __global__ void __launch_bounds__(512, 2) gemm256_bf16_nt_kernel(GemmArgs g) {
         _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                          \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
                 _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                     \
-                    acc[a][i_][b][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j_][ks_], af[i_][ks_], acc[a][i_][b][j_], 0, 0, 0); \
+                    acc[a][i_][b][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j_][ks_]), af[i_][ks_], acc[a][i_][b][j_], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                           \
         __builtin_amdgcn_s_barrier();                                                                \
     } while (0)
 
     const int nk = K >> 6;
+    if constexpr (WD) {
+        // per-lane byte offsets of the wave's four B fragment rows [half][nt] (+ fg * 16 B: k-chunk fg; ks = 1 is +64 B)
+        unsigned wvo[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) wvo[h][nt] = (unsigned)((h * 128 + wn * 32 + nt * 16 + fr) * K + fg * 8) * 2u;
+        const unsigned short* wb = g.W + (size_t)n0 * K;          // wave-uniform base, + 64 elements per K-tile
+#define WD_LD(dst, vo, base, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(dst) : "v"(vo), "s"(base) : "memory")
+#define WD_LOAD_B(dst, half, kt)                                                                     \
+    do {                                                                                             \
+        const unsigned short* b_ = wb + (size_t)(kt) * 64;                                           \
+        WD_LD(dst[0][0], wvo[half][0], b_, 0);                                                       \
+        WD_LD(dst[0][1], wvo[half][0], b_, 64);                                                      \
+        WD_LD(dst[1][0], wvo[half][1], b_, 0);                                                       \
+        WD_LD(dst[1][1], wvo[half][1], b_, 64);                                                      \
+    } while (0)
+        // prologue: A-lo(0), B-lo(0), A-hi(0) in the K-loop's own order
+        G256_ISSUE(0, 0, 0);
+        WD_LOAD_B(bl, 0, 0);
+        G256_ISSUE(1, 0, 0);
+        wait_vmcnt<2>();
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nk; ++t) {
+            const char* cur = smem + (t & 1) * G256_BUF;
+            const int nb = (t + 1) & 1;
+            const bool more = t + 1 < nk;             // wave-uniform
+            // P0: A-lo x B-lo
+            G256_READ_A(cur, 0);
+            WD_LOAD_B(bh, 1, t);
+            wait_vmcnt<4>();                          // retires A-hi(t)
+            __builtin_amdgcn_s_barrier();
+            G256_MFMA(0, bl, 0);
+            // P1: A-hi x B-lo
+            G256_READ_A(cur, 1);
+            if (more) G256_ISSUE(0, t + 1, nb);
+            __builtin_amdgcn_s_barrier();
+            G256_MFMA(1, bl, 0);
+            // P2: A-hi x B-hi (A-hi fragments still in registers); B-lo's registers take the next K-tile's fragments
+            if (more) {
+                WD_LOAD_B(bl, 0, t + 1);
+                G256_ISSUE(1, t + 1, nb);
+                wait_vmcnt<8>();                      // retires B-hi(t)
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            G256_MFMA(1, bh, 1);
+            // P3: A-lo x B-hi (A-lo read from LDS a second time)
+            G256_READ_A(cur, 0);
+            if (more) wait_vmcnt<2>();                // retires B-lo(t+1), A-lo(t+1)
+            __builtin_amdgcn_s_barrier();
+            G256_MFMA(0, bh, 1);
+        }
+#undef WD_LOAD_B
+#undef WD_LD
+    } else {
     // ---- prologue: K-tile 0 into buffer 0, in the order of first use
     G256_ISSUE(0, 0, 0);
     G256_ISSUE(2, 0, 0);
@@ -180,6 +255,7 @@ __global__ void __launch_bounds__(512, 2) gemm256_bf16_nt_kernel(GemmArgs g) {
         G256_MFMA(1, bh, 1);
         __builtin_amdgcn_s_barrier();
         G256_MFMA(1, bl, 0);
+    }
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();     // balance the stagger: every wave has the same barrier count
 #undef G256_ISSUE

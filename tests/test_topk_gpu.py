@@ -112,7 +112,7 @@ def test_non_finite_rows_keep_a_coarse_size_database_exact(clipmi, gpu, topk_ora
     rng = np.random.default_rng(29)
     db = unit_rows(rng, 70000, 512)
     db[4321, 17] = np.nan if poison == "nan" else np.inf
-    idx = clipmi.IndexFlatIP(512, device=gpu)
+    idx = clipmi.IndexFlatIP(512, device=gpu, coarse="int8")
     idx.add(db)
     assert idx.uses_coarse()
     for Q in (3, 200):
