@@ -58,6 +58,7 @@ class act_round:
 
 
 _FP8_LINEAR = False   # test knob: the four linear layers of every block on e4m3 operands (BASELINE.json configs[4])
+_FP8_ACT = "product"  # which activation quantiser the emulation uses (linear_fp8)
 FP8_MAX = 448.0
 
 
@@ -69,22 +70,52 @@ def _fp8_rows(t):
     return (t * (1.0 / scale)).to(torch.float8_e4m3fn).to(t.dtype) * scale
 
 
+def _fp8_mx_rows(t):
+    """MX block quantise/dequantise - the rule of the product's fp8mx_scale_byte / fp8mx_inv / fp8_pack8 (csrc/gemm.hpp;
+    attention52x4's output stage, the persistent QuickGELU GEMM's store pass, quantize_rows_fp8mx_kernel): one e8m0 scale
+    2^(e - 7) per 32 consecutive values of a row, e = floor(log2 max|block|) read off the float's exponent field (scaled
+    values lie in [128, 256): e4m3 holds 448), scale 1 for an all-zero block, exponent clamped at the bottom of the e8m0
+    range; values RNE to e4m3."""
+    shape = t.shape
+    b = t.reshape(-1, shape[-1] // 32, 32)
+    amax = b.abs().amax(dim=-1, keepdim=True)
+    e = (amax.contiguous().view(torch.int32) >> 23) & 0xff                      # biased exponent of the block maximum
+    sb = torch.where(amax == 0, torch.full_like(e, 127), torch.clamp(e - 7, min=0))
+    inv = ((254 - sb) << 23).view(torch.float32)                                 # 2^(127 - sb), exact
+    scale = torch.where(sb > 0, (sb << 23).view(torch.float32), torch.full_like(amax, 2.0 ** -127))
+    return ((b * inv).to(torch.float8_e4m3fn).to(t.dtype) * scale).reshape(shape)
+
+
 class linear_fp8:
     """Context manager: emulate the FP8 linear layers (products of e4m3 values are exact in f32, so an f32 matmul of
-    the dequantised operands is what the FP8 matrix cores compute, up to summation order)."""
+    the dequantised operands is what the FP8 matrix cores compute, up to summation order).
+    act="row": every activation with one scale per row (round 2's quantiser; kept as the looser yardstick);
+    act="product" (default): the quantisers that run since round 3 - LayerNorm's rows (the operands of in_proj and c_fc) keep
+    a row scale, the rows a GEMM takes straight from a producing kernel (attention's output -> out_proj, the QuickGELU rows ->
+    c_proj) travel with MX block scales (_fp8_mx_rows)."""
+
+    def __init__(self, act="product"):
+        assert act in ("row", "product")
+        self.act = act
 
     def __enter__(self):
-        global _FP8_LINEAR
-        self.prev, _FP8_LINEAR = _FP8_LINEAR, True
+        global _FP8_LINEAR, _FP8_ACT
+        self.prev, _FP8_LINEAR = (_FP8_LINEAR, _FP8_ACT), True
+        _FP8_ACT = self.act
+        return self
 
     def __exit__(self, *a):
-        global _FP8_LINEAR
-        _FP8_LINEAR = self.prev
+        global _FP8_LINEAR, _FP8_ACT
+        _FP8_LINEAR, _FP8_ACT = self.prev
 
 
-def _linear(x, w, b):
+
+
+def _linear(x, w, b, mx=False):
+    """mx: this operand comes straight from a producing kernel (attention, QuickGELU) - MX block scales in the FP8 tower."""
     if _FP8_LINEAR:
-        return _fp8_rows(_r(x)) @ _fp8_rows(w).t() + b
+        xq = _fp8_mx_rows(_r(x)) if (mx and _FP8_ACT == "product") else _fp8_rows(_r(x))
+        return xq @ _fp8_rows(w).t() + b
     return _r(x) @ w.t() + b
 
 
@@ -104,14 +135,14 @@ def _attention(x, sd, p, heads, mask):
         s = s + mask
     a = _r(torch.softmax(s, dim=-1)) @ v
     a = _r(a.transpose(1, 2).reshape(B, L, W))
-    return _linear(a, sd[p + ".attn.out_proj.weight"], sd[p + ".attn.out_proj.bias"])
+    return _linear(a, sd[p + ".attn.out_proj.weight"], sd[p + ".attn.out_proj.bias"], mx=True)
 
 
 def _resblock(x, sd, p, heads, mask):
     # upstream ResidualAttentionBlock.forward: x + attention(ln_1(x)); x + mlp(ln_2(x))
     x = x + _attention(_ln(x, sd, p + ".ln_1"), sd, p, heads, mask)
     h = _linear(_ln(x, sd, p + ".ln_2"), sd[p + ".mlp.c_fc.weight"], sd[p + ".mlp.c_fc.bias"])
-    h = _linear(quick_gelu(h), sd[p + ".mlp.c_proj.weight"], sd[p + ".mlp.c_proj.bias"])
+    h = _linear(quick_gelu(h), sd[p + ".mlp.c_proj.weight"], sd[p + ".mlp.c_proj.bias"], mx=True)
     return x + h
 
 

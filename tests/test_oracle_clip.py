@@ -120,3 +120,27 @@ def test_torchscript_archive_and_pickle_loaders(tmp_path):
     torch.save({"visual.conv1.weight": sd["visual.conv1.weight"], "x": Evil()}, bad)
     with pytest.raises(Exception):
         clipmi.weights.load_state_dict(bad)
+
+
+def test_mx_block_emulation_follows_the_stated_rule():
+    """oracle/clip_oracle._fp8_mx_rows (the yardstick of the FP8 tower's parity tests) restates the product's MX quantiser
+    (csrc/gemm.hpp fp8mx_*): per 32 values scale 2^(e - 7) with e = floor(log2 max|block|), all-zero block -> scale 1,
+    RNE to e4m3; checked against an independent ldexp / frexp formulation and on hand-made blocks."""
+    from oracle import clip_oracle
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(64, 256, generator=g) * torch.rand(64, 1, generator=g) * 50).to(torch.bfloat16).float()
+    x[3] = 0
+    x[4, 32:64] = 0
+    x[5, 7] = 3.0e38
+    x[6, :32] = torch.tensor([448.0] + [1.0] * 31)
+    got = clip_oracle._fp8_mx_rows(x)
+    b = x.reshape(64, 8, 32)
+    amax = b.abs().amax(-1, keepdim=True)
+    _, ex = torch.frexp(amax)                               # amax = m 2^ex, m in [0.5, 1): floor(log2 amax) = ex - 1
+    sc = torch.where(amax == 0, torch.ones_like(amax), torch.ldexp(torch.ones_like(amax), (ex - 1 - 7).clamp(min=-127)))
+    want = ((b / sc).to(torch.float8_e4m3fn).float() * sc).reshape(64, 256)
+    assert torch.equal(got, want)
+    assert (got[3] == 0).all() and (got[4, 32:64] == 0).all()
+    assert got[6, 0] == 448.0 and got[6, 1] == 1.0          # 448 = 1.75 * 2^8 -> scale 2, 224 and 0.5 are e4m3 values
+    blk = (got - x).reshape(64, 8, 32).abs().amax(-1)
+    assert (blk <= amax.squeeze(-1) * 2.0 ** -4).all()      # half an ulp of 3 mantissa bits at the top of the block's range
