@@ -33,7 +33,9 @@ class Variant:
         self.obj = os.path.join(CSRC, "_obj_dev" if dev else "_obj")
         self.lib = os.path.join(HERE, "libclipmi_dev.so" if dev else "libclipmi.so")
         self.stamp = self.lib + ".stamp"
-        self.flags = BASE_FLAGS + (["-DCLIPMI_DEV"] if dev else [])
+        # CLIPMI_EXTRA_CXXFLAGS (development library only): e.g. -DCLIPMI_GEMM_STAMPS=1 for tools/gp_stamps.py; the flags
+        # are part of the content stamp, so the same variable must be set when that build is loaded
+        self.flags = BASE_FLAGS + (["-DCLIPMI_DEV"] + os.environ.get("CLIPMI_EXTRA_CXXFLAGS", "").split() if dev else [])
 
 
 PRODUCT, DEV = Variant(False), Variant(True)

@@ -93,7 +93,8 @@ constexpr int g256p_lds(int epi, bool fp8, int N, int K, int dbg) {
 template <int EPI, bool FP8 = false>
 static int launch_epi256p(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
     const int tiles = (g.N / 256) * ((g.M + 255) / 256);
-    const int grid = tiles < NUM_CU ? tiles : NUM_CU;
+    static const int grid_max = (int)dev_knob("CLIPMI_GEMM_GRID", NUM_CU);      // development: fewer workgroups than CUs
+    const int grid = tiles < grid_max ? tiles : grid_max;
     const int lds = g256p_lds(EPI, FP8, g.N, g.K, g.dbg);
     if (lds > LDS_BYTES) return set_err(CLIPMI_EUNSUPPORTED, "gemm256p: %d B of LDS for N=%d", lds, g.N);
     static thread_local int opted[64];

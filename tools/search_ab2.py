@@ -1,5 +1,6 @@
 """Search leg, one and two calls in flight at Q = 64 (development A/B of env knobs). usage: python tools/search_ab2.py [N]"""
 import sys, os, time
+os.environ.setdefault("CLIPMI_DEV_LIB", "1")   # A/B knobs: development library only
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import clipmi
