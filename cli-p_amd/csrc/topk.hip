@@ -273,12 +273,16 @@ __global__ void __launch_bounds__(256) scan_topk_f32_kernel(ScanArgs a) {
 // (from L2 after the first), and in exchange a workgroup fits on a CU - LDS and registers - beside a coarse scan
 // workgroup of another batch in flight; with the 128-KiB image of all 64 queries this launch waited for that whole scan
 // to drain, and its row tile + 16 accumulators spilled 252 B. A NaN score is stored as -inf.
-template <int E>
+// QG = 2 (the wide pass: up to 1024 queries): 32 queries per workgroup. With 16, every (row tile, query group) unit loaded its
+// 32 KiB of rows for 128 MFMAs - 8 B per cycle and SIMD, the CU's whole L2 -> register rate - and the launch took 287 us for
+// 83 us of f32 MFMA work at Q = 1024; 32 queries per row tile halve the loads per MFMA and give each
+// wave two independent accumulator chains.
+template <int E, int QG = 1>
 __global__ void __launch_bounds__(256) sample_scores_kernel(const float* __restrict__ db, long long nrows,
                                                             const float* __restrict__ q, int QA, uint2* __restrict__ cand,
                                                             long long cap, unsigned* __restrict__ gcnt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = E / 16, QG = 1;
+    constexpr int NT = E / 16;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, g = lane >> 4;
@@ -309,6 +313,10 @@ __global__ void __launch_bounds__(256) sample_scores_kernel(const float* __restr
         f32x4 T[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) T[t] = *reinterpret_cast<const f32x4*>(p + 16 * t);
+        // all 32 loads of the row tile are in flight before the first MFMA: left to itself the scheduler sank them into the
+        // MFMA chain two at a time (vmcnt(1) after every load: 32 dependent L2 round trips per tile, ~16 us per tile against
+        // 1.7 us of MFMA - round 4, hipcc -S)
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[QG];
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) acc[qg] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -2461,9 +2469,15 @@ int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta,
             // 32-KiB query image - so few, fat blocks per group (each wave 4+ row tiles) once the groups alone fill the chip
             long long gs = ((S1 + 15) / 16 + 3) / 4;
             if (gs > NUM_CU) gs = NUM_CU;
-            const int ngroups = (qc + 15) / 16;
             static const int sdiv = [] { const int d = (int)dev_knob("CLIPMI_WIDE_SAMPLE_DIV", 8); return d > 0 ? d : 8; }();
-            if (ngroups >= 8 && gs > sdiv) gs = (gs + sdiv - 1) / sdiv;
+            static const int sqg = (int)dev_knob("CLIPMI_WIDE_SAMPLE_QG", 2);
+            const int ngroups = (qc + 16 * sqg - 1) / (16 * sqg);
+            if (ngroups >= 8 / sqg && gs > sdiv) gs = (gs + sdiv - 1) / sdiv;
+            if (sqg == 2) {
+                if (int rc = opt_in_lds((const void*)sample_scores_kernel<512, 2>, 2 * lds1)) return rc;
+                hipLaunchKernelGGL((sample_scores_kernel<512, 2>), dim3((unsigned)gs, (unsigned)ngroups), dim3(256), 2 * lds1, st,
+                                   static_cast<const float*>(db_dev), S1, qg, qc, w.cand_c, (long long)WIDE_CAP, w.gcnt_c);
+            } else
             hipLaunchKernelGGL(sample_scores_kernel<512>, dim3((unsigned)gs, (unsigned)ngroups), dim3(256), lds1, st,
                                static_cast<const float*>(db_dev), S1, qg, qc, w.cand_c, (long long)WIDE_CAP, w.gcnt_c);
             CLIPMI_CHECK_LAUNCH("sample_scores_kernel(wide)");
