@@ -28,6 +28,8 @@ struct Ws {
     unsigned char* a8;        // weight_format 1: the current GEMM's A operand as e4m3 [B*L][<= 4W]
     float* a_scale;           //                  and its row scales [B*L]
     unsigned char* a_bs;      //                  or (A produced by attention / QuickGELU) its MX block scales, rows padded to 256
+    unsigned char* x8;        // weight_format 1 + ln_fold: the residual rows as e4m3 [B*L][W] (A operand of the LN-folded qkv / c_fc GEMMs)
+    unsigned char* x8_bs;     //                            and their MX block scales, rows padded to 256
     unsigned short* xhi;      // ln_fold: the residual stream kept split, x = hi + lo (bf16 [B*L][W] each, contiguous);
     unsigned short* xlo;      //          hi is also the A operand of the LN-folded qkv / c_fc GEMMs
     float* ln_part;           //          row statistics of x as per-256-column (sum, sum of squares) [B*L][W/256][2]
@@ -49,7 +51,12 @@ size_t carve(const clipmi_tower* t, int B, void* base, size_t cap, Ws* out) {
         w.a_scale = ar.take<float>(rows);
         w.a_bs = ar.take<unsigned char>((rows + 255) / 256 * 256 * (size_t)(4 * W / 32));
     }
-    if (t->ln_fold) {
+    if (t->ln_fold && t->weight_format == 1) {
+        // FP8 tower with folded LayerNorms: the residual stays f32 (w.x); its e4m3 image + statistics travel beside it
+        w.x8 = ar.take<unsigned char>(rows * W);
+        w.x8_bs = ar.take<unsigned char>((rows + 255) / 256 * 256 * (size_t)(W / 32));
+        w.ln_part = ar.take<float>(rows * 2 * (W / 256));
+    } else if (t->ln_fold) {
         w.xhi = ar.take<unsigned short>(2 * rows * W);
         w.xlo = w.xhi + rows * W;
         w.ln_part = ar.take<float>(rows * 2 * (W / 256));
@@ -72,8 +79,12 @@ int check_tower(const clipmi_tower* t, int kind, const char* who) {
         return set_err(CLIPMI_EINVAL, "%s: weight_format %d", who, t->weight_format);
     if (t->weight_format == 1 && t->width % 256 != 0)
         return set_err(CLIPMI_EUNSUPPORTED, "%s: fp8 weights need width %% 256 == 0 (width %d)", who, t->width);
-    if (t->ln_fold != 0 && (t->ln_fold != 1 || t->weight_format != 0 || t->width % 256 != 0))
-        return set_err(CLIPMI_EINVAL, "%s: ln_fold %d needs bf16 weights and width %% 256 == 0 (width %d)", who, t->ln_fold, t->width);
+    if (t->ln_fold != 0 && (t->ln_fold != 1 || t->width % 256 != 0))
+        return set_err(CLIPMI_EINVAL, "%s: ln_fold %d needs width %% 256 == 0 (width %d)", who, t->ln_fold, t->width);
+#ifndef CLIPMI_DEV
+    if (t->ln_fold != 0 && t->weight_format != 0)
+        return set_err(CLIPMI_EUNSUPPORTED, "%s: folded LayerNorms on FP8 weights exist in the development library only", who);
+#endif
     if (t->tokens > 80 && kind == 1)
         return set_err(CLIPMI_EUNSUPPORTED, "%s: %d tokens (causal attention covers <= 80)", who, t->tokens);
     return 0;
@@ -98,6 +109,54 @@ int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int 
         g.A = A; g.W = at<unsigned short>(blob, w_off);
         return launch_gemm_algo(g, epi, 0, st, probe);
     };
+#ifdef CLIPMI_DEV
+    if (t->ln_fold && fp8) {
+        // FP8 blocks with folded LayerNorms (round 4; VERDICT r03 "What's missing" #1; development library: parity-green and
+        // measured SLOWER than the LayerNorm-pass tower below - DESIGN 4.4c - while its GEMMs run on the non-persistent kernel). The residual stream stays f32 in w.x;
+        // every producer of residual rows (the embedding stage through rows_mx_stats_kernel, then the two residual GEMMs'
+        // store passes: EPI_BIAS_RESID_LN8) also leaves them as e4m3 with MX block scales (w.x8 / w.x8_bs) with their
+        // row-statistics partials (w.ln_part), and qkv / c_fc take THOSE as their A operand with the LN-folded epilogue
+        // rstd (acc w_scale - mean colsum) + cb on weights e4m3(W diag(gamma)). No stand-alone LayerNorm pass is left
+        // (round 3: two per layer, 26 x 30 us of a 7.37 ms step).
+        auto lnfold8 = [&](uint64_t w_off, uint64_t s_off, uint64_t cb_off, uint64_t cs_off, void* out, unsigned char* out_bs, int N,
+                           int epi) -> int {
+            GemmArgs g{};
+            g.A = reinterpret_cast<const unsigned short*>(w.x8); g.a_bscale = w.x8_bs;
+            g.W = at<unsigned short>(blob, w_off); g.w_scale = at<float>(blob, s_off);
+            g.bias = at<float>(blob, cb_off); g.colsum = at<float>(blob, cs_off); g.ln_part_in = w.ln_part;
+            g.out = out; g.out_bscale = out_bs; g.M = M; g.N = N; g.K = W;
+            return launch_gemm_fp8(g, epi, st);
+        };
+        auto resid8 = [&](const unsigned char* A8, int K, uint64_t w_off, uint64_t s_off, uint64_t b_off) -> int {
+            GemmArgs g{};
+            g.A = reinterpret_cast<const unsigned short*>(A8); g.a_bscale = w.a_bs;
+            g.W = at<unsigned short>(blob, w_off); g.w_scale = at<float>(blob, s_off); g.bias = at<float>(blob, b_off);
+            g.out = w.x; g.x8 = w.x8; g.x8_bs = w.x8_bs; g.ln_part = w.ln_part; g.M = M; g.N = W; g.K = K;
+            return launch_gemm_fp8(g, EPI_BIAS_RESID_LN8, st);
+        };
+        unsigned char* const big8 = reinterpret_cast<unsigned char*>(w.big);
+        static const bool fuse_off = dev_knob("CLIPMI_FP8_FUSE", 1) == 0;   // A/B aid (development build): stand-alone MX passes
+        for (int l = 0; l < t->layers; ++l) {
+            const uint64_t lb = t->off_layers + (uint64_t)l * t->layer_stride;
+            if (int rc = lnfold8(lb + t->lo_qkv_w, lb + t->lo_qkv_s, lb + t->lo_qkv_cb, lb + t->lo_qkv_colsum, w.big, nullptr, 3 * W, EPI_LN_BIAS_BF16)) return rc;
+            bool fused = false;
+            if (int rc = launch_attention(w.big, w.h, B, L, t->heads, causal, 1, st, fuse_off ? nullptr : w.a8, w.a_bs, &fused)) return rc;
+            if (!fused)
+                if (int rc = launch_quantize_rows_fp8mx(w.h, w.a8, w.a_bs, M, W, st)) return rc;
+            if (int rc = resid8(w.a8, W, lb + t->lo_out_w, lb + t->lo_out_s, lb + t->lo_out_b)) return rc;
+            if (!fuse_off) {
+                // the QuickGELU rows leave c_fc as e4m3 + block scales, into the bf16 buffer's bytes
+                if (int rc = lnfold8(lb + t->lo_fc_w, lb + t->lo_fc_s, lb + t->lo_fc_cb, lb + t->lo_fc_colsum, big8, w.a_bs, 4 * W, EPI_LN_BIAS_QGELU_BF16)) return rc;
+                if (int rc = resid8(big8, 4 * W, lb + t->lo_proj_w, lb + t->lo_proj_s, lb + t->lo_proj_b)) return rc;
+            } else {
+                if (int rc = lnfold8(lb + t->lo_fc_w, lb + t->lo_fc_s, lb + t->lo_fc_cb, lb + t->lo_fc_colsum, w.big, nullptr, 4 * W, EPI_LN_BIAS_QGELU_BF16)) return rc;
+                if (int rc = launch_quantize_rows_fp8mx(w.big, w.a8, w.a_bs, M, 4 * W, st)) return rc;
+                if (int rc = resid8(w.a8, 4 * W, lb + t->lo_proj_w, lb + t->lo_proj_s, lb + t->lo_proj_b)) return rc;
+            }
+        }
+        return 0;
+    }
+#endif
     if (t->ln_fold) {
         // LN-folded blocks (gemm.hpp): ln_1 / ln_2 never run as passes of their own and the residual stream lives split
         // in (w.xhi, w.xlo) with its row statistics in w.ln_part; w.x (f32) is only the embedding stage's output and the
@@ -191,9 +250,10 @@ int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int 
 // pooled rows -> final LayerNorm -> projection [E][W] -> f32 [B][E] (-> optional L2 normalise)
 int run_head(const clipmi_tower* t, const void* blob, const Ws& w, int B, const int* rowidx, long long row_step,
              float* out, int normalize, hipStream_t st) {
-    LnArgs ln{t->ln_fold ? nullptr : w.x, at<float>(blob, t->off_ln_post_w), at<float>(blob, t->off_ln_post_b), w.pooled, rowidx,
+    const bool split = t->ln_fold && t->weight_format == 0;      // bf16 LN-folded towers keep the residual as (hi, lo)
+    LnArgs ln{split ? nullptr : w.x, at<float>(blob, t->off_ln_post_w), at<float>(blob, t->off_ln_post_b), w.pooled, rowidx,
               row_step, B, t->width, 1};
-    ln.xhi = w.xhi; ln.xlo = w.xlo;        // ln_fold: the residual stream is (hi, lo)
+    ln.xhi = w.xhi; ln.xlo = w.xlo;        // split: the residual stream is (hi, lo)
     if (int rc = launch_layernorm(ln, st)) return rc;
     GemmArgs g{};
     g.A = w.pooled; g.W = at<unsigned short>(blob, t->off_out_proj); g.bias = nullptr; g.out = out;
@@ -242,8 +302,13 @@ static int encode_image_impl(const clipmi_tower* t, const void* blob_dev, const 
                        at<float>(blob_dev, t->off_cls), at<float>(blob_dev, t->off_pos), B, L, W);
     CLIPMI_CHECK_LAUNCH("cls_rows_kernel");
     LnArgs ln{w.x, at<float>(blob_dev, t->off_ln_pre_w), at<float>(blob_dev, t->off_ln_pre_b), w.x, nullptr, 1, B * L, W, 0};
-    if (t->ln_fold) { ln.out_hi = w.xhi; ln.out_lo = w.xlo; ln.out_part = w.ln_part; }     // straight into the split residual
-    if (int rc = launch_layernorm(ln, st)) return rc;       // ln_pre (ln_fold 0: in place, each wave owns its row)
+    const bool fold8 = t->ln_fold && t->weight_format == 1;
+    if (t->ln_fold && !fold8) { ln.out_hi = w.xhi; ln.out_lo = w.xlo; ln.out_part = w.ln_part; }     // straight into the split residual
+    if (int rc = launch_layernorm(ln, st)) return rc;       // ln_pre (ln_fold 0 / FP8: in place, each wave owns its row)
+#ifdef CLIPMI_DEV
+    if (fold8)     // FP8 tower with folded LayerNorms: the embedded rows' e4m3 image + statistics for the first qkv GEMM
+        if (int rc = launch_rows_mx_stats(w.x, w.x8, w.x8_bs, w.ln_part, B * L, W, st)) return rc;
+#endif
     if (int rc = run_layers(t, blob_dev, w, B, 0, st, probe)) return rc;
     return run_head(t, blob_dev, w, B, nullptr, L, out_dev, normalize, st);
 }
@@ -276,8 +341,14 @@ extern "C" int clipmi_encode_text(const clipmi_tower* t, const void* blob_dev, c
     CLIPMI_CHECK_LAUNCH("text_embed_kernel");
     hipLaunchKernelGGL(eot_rows_kernel, dim3((Q + 63) / 64), dim3(64), 0, st, ids_dev, w.rowidx, Q, L);
     CLIPMI_CHECK_LAUNCH("eot_rows_kernel");
-    if (t->ln_fold)
+#ifdef CLIPMI_DEV
+    if (t->ln_fold && t->weight_format == 1) {
+        if (int rc = launch_rows_mx_stats(w.x, w.x8, w.x8_bs, w.ln_part, Q * L, W, st)) return rc;
+    } else
+#endif
+    if (t->ln_fold) {
         if (int rc = launch_split_stats(w.x, false, w.xhi, w.xlo, w.ln_part, Q * L, W, st)) return rc;
+    }
     if (int rc = run_layers(t, blob_dev, w, Q, 1, st, nullptr)) return rc;
     return run_head(t, blob_dev, w, Q, w.rowidx, 1, out_dev, normalize, st);
 }

@@ -346,6 +346,23 @@ int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st, int mx) {
         if (g.K > G256F8_BSA_MAX_K) return set_err(CLIPMI_EINVAL, "gemm_fp8: block-scaled A needs K <= %d", G256F8_BSA_MAX_K);
         if (epi == EPI_BIAS_RESID_F32) return launch_epi256f8_bsa<EPI_BIAS_RESID_F32>(g, st);
         if (epi == EPI_F32) return launch_epi256f8_bsa<EPI_F32>(g, st);
+#ifdef CLIPMI_DEV
+        // FP8 tower with folded LayerNorms (round 4, development library: DESIGN 4.4c - parity-green, but slower than the
+        // LayerNorm-pass tower while its GEMMs run on this non-persistent kernel): the residual producer that also emits
+        // e4m3 + MX scales + statistics, and the consumers whose A operand those are
+        if (epi == EPI_BIAS_RESID_LN8) {
+            if (!g.x8 || !g.x8_bs || !g.ln_part || g.N > 1024)
+                return set_err(CLIPMI_EINVAL, "gemm_fp8: EPI_BIAS_RESID_LN8 needs x8, x8_bs, ln_part and N <= 1024");
+            return launch_epi256f8_bsa<EPI_BIAS_RESID_LN8>(g, st);
+        }
+        if (epi_is_ln(epi)) {
+            if (!g.ln_part_in || !g.colsum || !g.bias || g.K % 256 != 0 || g.K > 1024)
+                return set_err(CLIPMI_EINVAL, "gemm_fp8: LN-folded epilogue %d needs ln_part_in, colsum, bias, K %% 256 == 0, K <= 1024", epi);
+            if (g.out_bscale && epi != EPI_LN_BIAS_QGELU_BF16)
+                return set_err(CLIPMI_EINVAL, "gemm_fp8: e4m3 + block-scale output exists for the QuickGELU forms only");
+            return epi == EPI_LN_BIAS_BF16 ? launch_epi256f8_bsa<EPI_LN_BIAS_BF16>(g, st) : launch_epi256f8_bsa<EPI_LN_BIAS_QGELU_BF16>(g, st);
+        }
+#endif
         return set_err(CLIPMI_EINVAL, "gemm_fp8: block-scaled A with epilogue %d", epi);
     }
     // more than one round of tiles: the persistent role-split kernel on FP8 operands (mx = 2 keeps gemm256f8 for tests)

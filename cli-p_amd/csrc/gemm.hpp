@@ -63,7 +63,10 @@ enum Epilogue {
     // LayerNorm folded into the GEMM that consumes it ("LN-folded" linear layers, see ln_fold below):
     EPI_LN_BIAS_BF16 = 5,        // out bf16 = rstd[m] * (acc - mean[m] * colsum[n]) + bias[n]
     EPI_LN_BIAS_QGELU_BF16 = 6,  // out bf16 = quick_gelu(the same)
-    EPI_BIAS_RESID_LN_F32 = 7    // split residual: (xhi, xlo) += acc + bias, + row-statistics partials of the new rows
+    EPI_BIAS_RESID_LN_F32 = 7,   // split residual: (xhi, xlo) += acc + bias, + row-statistics partials of the new rows
+    EPI_BIAS_RESID_LN8 = 8       // FP8 towers with folded LayerNorms (round 4): out f32 [M][N] += acc + bias, and the new rows
+                                 // also leave as e4m3 with MX block scales (x8, x8_bs: the A operand of the next LN-folded
+                                 // FP8 GEMM) with their row-statistics partials (ln_part)
 };
 
 // ---- LN-folded linear layers ---------------------------------------------------------------------------------
@@ -148,6 +151,54 @@ __device__ __forceinline__ uint2 fp8_pack8(const float* f) {
     return make_uint2((unsigned)lo, (unsigned)hi);
 }
 
+// One wave, one 256-column segment of a residual row, four consecutive columns per lane (the layout of every whole-row store
+// pass): the row's e4m3 bytes with MX block scales (a block = 8 lanes) and the segment's canonical (sum, sum of squares).
+// Shared by the FP8 residual GEMM's store pass (EPI_BIAS_RESID_LN8) and rows_mx_stats_kernel (ln_pre's rows), so the bytes
+// and the statistics do not depend on who produced them. Quantises the f32 values themselves (one rounding).
+__device__ __forceinline__ void ln8_row_segment(f32x4 v, unsigned& packed4, unsigned& scale_byte, float& sum, float& sumsq) {
+    sum = ln_wave_sum(ln_lane_sum(v));
+    sumsq = ln_wave_sum(ln_lane_sumsq(v));
+    float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    mx = fmaxf(mx, __shfl_xor(mx, 1));
+    mx = fmaxf(mx, __shfl_xor(mx, 2));
+    mx = fmaxf(mx, __shfl_xor(mx, 4));
+    scale_byte = fp8mx_scale_byte(mx);
+    const float inv = fp8mx_inv(scale_byte);
+    int pk = 0;
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v.x * inv, v.y * inv, pk, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v.z * inv, v.w * inv, pk, true);
+    packed4 = (unsigned)pk;
+}
+
+// 8 consecutive bf16 columns per lane (one 16-byte chunk of a row's store pass), the 4 lanes of a quad = one 32-block:
+// -> the 8 e4m3 bytes and the block's scale byte. The bytes quantize_rows_fp8mx_kernel makes of the same bf16 rows (block
+// maximum on the bf16 MAGNITUDE BITS - 15-bit integers order as the values do - two packed 16-bit maxima, the quad's by DPP).
+__device__ __forceinline__ uint2 mx_pack_bf16x8(uint4 x, unsigned& sb_out) {
+    const unsigned w_[4] = {x.x, x.y, x.z, x.w};
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    u16x2 pm = __builtin_elementwise_max(
+        __builtin_elementwise_max(__builtin_bit_cast(u16x2, w_[0] & 0x7fff7fffu), __builtin_bit_cast(u16x2, w_[1] & 0x7fff7fffu)),
+        __builtin_elementwise_max(__builtin_bit_cast(u16x2, w_[2] & 0x7fff7fffu), __builtin_bit_cast(u16x2, w_[3] & 0x7fff7fffu)));
+    unsigned mm = __builtin_bit_cast(unsigned, pm);
+    mm = (mm & 0xffffu) > (mm >> 16) ? (mm & 0xffffu) : (mm >> 16);
+    const unsigned m1_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mm, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    mm = mm > m1_ ? mm : m1_;
+    const unsigned m2_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mm, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    mm = mm > m2_ ? mm : m2_;
+    const unsigned e_ = mm >> 7;
+    const unsigned sb_ = mm == 0u ? 127u : (e_ > 7u ? e_ - 7u : 0u);      // = fp8mx_scale_byte(block max)
+    const float inv_ = fp8mx_inv(sb_);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 p_ = f32x2{__uint_as_float(w_[j] << 16), __uint_as_float(w_[j] & 0xffff0000u)} * inv_;
+        f[2 * j] = p_.x;
+        f[2 * j + 1] = p_.y;
+    }
+    sb_out = sb_;
+    return fp8_pack8(f);
+}
+
 constexpr bool epi_is_ln(int e) { return e == EPI_LN_BIAS_BF16 || e == EPI_LN_BIAS_QGELU_BF16; }
 constexpr bool epi_is_qgelu(int e) { return e == EPI_BIAS_QGELU_BF16 || e == EPI_LN_BIAS_QGELU_BF16; }
 constexpr bool epi_is_bf16_out(int e) { return e == EPI_BIAS_BF16 || e == EPI_BIAS_QGELU_BF16 || epi_is_ln(e); }
@@ -161,6 +212,8 @@ struct GemmArgs {
     // EPI_PATCH_F32 only
     const float* pos;          // [L][N]
     int np, L;
+    unsigned char* x8;         // EPI_BIAS_RESID_LN8: the new residual rows as e4m3 [M][N] ...
+    unsigned char* x8_bs;      // ... and their e8m0 block scales [rows padded to 256][N / 32]
     int dbg;                   // development experiments only (tools/gemm_persist.py); 0 in every product path
     // FP8 path (gemm256f8.hpp): A and W point at e4m3 bytes; per-row / per-output-channel dequantisation scales
     const float* a_scale;      // [M]

@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(512, 2) gemm256f8_nt_kernel(GemmArgs g) {
     // row-major LDS image of the tile — 16-byte chunks XOR-swizzled with row & 15 so that the 16 rows
     // of a fragment column do not share banks — and the tile leaves as whole rows, 16 B per lane,
     // 512 B..1 KiB contiguous per wave-instruction; the residual / positional add happens on that pass.
-    f32x4 bz[2][2], ws[2][2];
+    f32x4 bz[2][2], ws[2][2], cs[2][2];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -230,6 +230,7 @@ __global__ void __launch_bounds__(512, 2) gemm256f8_nt_kernel(GemmArgs g) {
             const int n = n0 + b * 128 + wn * 32 + nt * 16 + 4 * fg;
             bz[b][nt] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
             ws[b][nt] = *reinterpret_cast<const f32x4*>(g.w_scale + n);
+            if (epi_is_ln(EPI)) cs[b][nt] = *reinterpret_cast<const f32x4*>(g.colsum + n);
         }
     float as[2][4];            // activation row scales of this lane's accumulator rows: [A half][mt]
 #pragma unroll
@@ -241,17 +242,27 @@ __global__ void __launch_bounds__(512, 2) gemm256f8_nt_kernel(GemmArgs g) {
             as[a][mt] = BSA ? 1.0f : g.a_scale[m];
         }
     __syncthreads();
-    if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16) {
+    if (epi_is_bf16_out(EPI)) {
         // image: 256 rows x 512 B
 #pragma unroll
         for (int idx = 0; idx < 8; ++idx) {
             const int row = (idx >> 2) * 128 + wm * 64 + (idx & 3) * 16 + fr;
+            // LN-folded consumer (round 4; gemm.hpp): A = e4m3(x) with MX block scales, W = e4m3(W diag(gamma)): the epilogue is
+            // rstd (acc w_scale - mean colsum) + cb with colsum of the ROUNDED e4m3 weights (weights.py ln_fold_terms_fp8)
+            f32x2 st = {0.f, 1.f};
+            if (epi_is_ln(EPI)) {
+                const int m = m0 + row;
+                const int nseg = g.K >> 8;
+                st = ln_row_stats(g.ln_part_in + (size_t)(m < g.M ? m : g.M - 1) * 2 * nseg, nseg, g.K);
+            }
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    f32x4 v = acc[idx >> 2][idx & 3][b][nt] * (ws[b][nt] * as[idx >> 2][idx & 3]) + bz[b][nt];
-                    if (EPI == EPI_BIAS_QGELU_BF16) {
+                    f32x4 v;
+                    if (epi_is_ln(EPI)) v = ln_apply(acc[idx >> 2][idx & 3][b][nt] * (ws[b][nt] * as[idx >> 2][idx & 3]), st.x, st.y, cs[b][nt], bz[b][nt]);
+                    else v = acc[idx >> 2][idx & 3][b][nt] * (ws[b][nt] * as[idx >> 2][idx & 3]) + bz[b][nt];
+                    if (epi_is_qgelu(EPI)) {
                         v = quick_gelu4(v);
                     }
                     const int colbyte = (b * 128 + wn * 32 + nt * 16 + 4 * fg) * 2;
@@ -261,13 +272,25 @@ __global__ void __launch_bounds__(512, 2) gemm256f8_nt_kernel(GemmArgs g) {
         }
         __syncthreads();
         unsigned short* outp = static_cast<unsigned short*>(g.out);
+        unsigned char* const out8 = static_cast<unsigned char*>(g.out);
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {
             const int row = wave * 32 + i * 2 + (lane >> 5);
             const int chunk = lane & 31;
             const uint4 v = *reinterpret_cast<const uint4*>(smem + row * 512 + ((chunk ^ (row & 15)) << 4));
             const int m = m0 + row;
-            if (m < g.M) *reinterpret_cast<uint4*>(outp + (size_t)m * g.N + n0 + chunk * 8) = v;
+            if (epi_is_qgelu(EPI) && g.out_bscale) {
+                // the rows leave as e4m3 + MX block scales (the next GEMM's A operand) instead of bf16: gemm.hpp mx_pack_bf16x8,
+                // the bytes the persistent kernel's storers and quantize_rows_fp8mx_kernel write
+                unsigned sb_;
+                const uint2 q8_ = mx_pack_bf16x8(v, sb_);
+                if (m < g.M) {
+                    *reinterpret_cast<uint2*>(out8 + (size_t)m * g.N + n0 + chunk * 8) = q8_;
+                    if ((lane & 3) == 0) g.out_bscale[(size_t)m * (g.N >> 5) + ((n0 + chunk * 8) >> 5)] = (unsigned char)sb_;
+                }
+            } else if (m < g.M) {
+                *reinterpret_cast<uint4*>(outp + (size_t)m * g.N + n0 + chunk * 8) = v;
+            }
         }
     } else {
         // two passes of 128 rows x 1 KiB (f32)
@@ -301,8 +324,21 @@ __global__ void __launch_bounds__(512, 2) gemm256f8_nt_kernel(GemmArgs g) {
                         v += *reinterpret_cast<const f32x4*>(g.pos + (size_t)(1 + p_) * g.N + n0 + lane * 4);
                     }
                     float* dst = outp + orow * g.N + n0 + lane * 4;
-                    if (EPI == EPI_BIAS_RESID_F32) v += *reinterpret_cast<const f32x4*>(dst);
+                    if (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_BIAS_RESID_LN8) v += *reinterpret_cast<const f32x4*>(dst);
                     *reinterpret_cast<f32x4*>(dst) = v;
+                }
+                if constexpr (EPI == EPI_BIAS_RESID_LN8) {
+                    // the new residual row also leaves as e4m3 + MX block scales (A operand of the next LN-folded FP8 GEMM) with
+                    // its 256-column statistics partial; a wave holds the whole segment (4 columns per lane): gemm.hpp
+                    // ln8_row_segment, shared with rows_mx_stats_kernel. Rows past M are computed (wave-wide shuffles) and dropped.
+                    unsigned p4_, sb_;
+                    float sm_, sq_;
+                    ln8_row_segment(v, p4_, sb_, sm_, sq_);
+                    if (m < g.M) {
+                        *reinterpret_cast<unsigned*>(g.x8 + (size_t)m * g.N + n0 + lane * 4) = p4_;
+                        if ((lane & 7) == 0) g.x8_bs[(size_t)m * (g.N >> 5) + ((n0 + lane * 4) >> 5)] = (unsigned char)sb_;
+                        if (lane == 0) *reinterpret_cast<f32x2*>(g.ln_part + ((size_t)m * (g.N >> 8) + (n0 >> 8)) * 2) = f32x2{sm_, sq_};
+                    }
                 }
             }
         }

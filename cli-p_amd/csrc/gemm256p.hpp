@@ -669,33 +669,12 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                                 unsigned char* const out8 = static_cast<unsigned char*>(g.out);
     #pragma unroll
                                 for (int k = 0; k < 8; ++k) {
-                                    const unsigned w_[4] = {xs[k].x, xs[k].y, xs[k].z, xs[k].w};
-                                    // block maximum on the bf16 MAGNITUDE BITS (15-bit integers order as the values do): two
-                                    // packed 16-bit maxima, the quad's by DPP; its exponent field is the float's
-                                    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-                                    u16x2 pm = __builtin_elementwise_max(
-                                        __builtin_elementwise_max(__builtin_bit_cast(u16x2, w_[0] & 0x7fff7fffu), __builtin_bit_cast(u16x2, w_[1] & 0x7fff7fffu)),
-                                        __builtin_elementwise_max(__builtin_bit_cast(u16x2, w_[2] & 0x7fff7fffu), __builtin_bit_cast(u16x2, w_[3] & 0x7fff7fffu)));
-                                    unsigned mm = __builtin_bit_cast(unsigned, pm);
-                                    mm = (mm & 0xffffu) > (mm >> 16) ? (mm & 0xffffu) : (mm >> 16);
-                                    const unsigned m1_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mm, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-                                    mm = mm > m1_ ? mm : m1_;
-                                    const unsigned m2_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mm, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
-                                    mm = mm > m2_ ? mm : m2_;
-                                    const unsigned e_ = mm >> 7;
-                                    const unsigned sb_ = mm == 0u ? 127u : (e_ > 7u ? e_ - 7u : 0u);      // = fp8mx_scale_byte(block max)
-                                    const float inv_ = fp8mx_inv(sb_);
-                                    float f[8];
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j) {
-                                        const f32x2 p_ = f32x2{__uint_as_float(w_[j] << 16), __uint_as_float(w_[j] & 0xffff0000u)} * inv_;
-                                        f[2 * j] = p_.x;
-                                        f[2 * j + 1] = p_.y;
-                                    }
+                                    unsigned sb_;
+                                    const uint2 q8_ = mx_pack_bf16x8(xs[k], sb_);          // gemm.hpp: shared by every producer
                                     const int m = m0 + a * 128 + k * 16 + rlow;
                                     if (m < g.M) {
                                         const int col = n0 + (lane & 31) * 8;
-                                        *reinterpret_cast<uint2*>(out8 + (size_t)m * g.N + col) = fp8_pack8(f);
+                                        *reinterpret_cast<uint2*>(out8 + (size_t)m * g.N + col) = q8_;
                                         if ((lane & 3) == 0) g.out_bscale[(size_t)m * (g.N >> 5) + (col >> 5)] = (unsigned char)sb_;
                                     }
                                 }

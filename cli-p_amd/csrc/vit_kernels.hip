@@ -107,6 +107,16 @@ int launch_quantize_rows_fp8mx(const unsigned short* in, unsigned char* out, uns
     return 0;
 }
 
+#ifdef CLIPMI_DEV
+int launch_rows_mx_stats(const float* x, unsigned char* x8, unsigned char* bs, float* part, int M, int W, hipStream_t st) {
+    if (M < 1) return 0;
+    if (W < 256 || W % 256 != 0 || !x || !x8 || !bs || !part) return set_err(CLIPMI_EINVAL, "rows_mx_stats: W=%d", W);
+    hipLaunchKernelGGL(rows_mx_stats_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, x8, bs, part, M, W);
+    CLIPMI_CHECK_LAUNCH("rows_mx_stats_kernel");
+    return 0;
+}
+#endif
+
 int launch_patchify(const PatchArgs& a, hipStream_t st) {
     if (a.dtype == CLIPMI_U8 && a.P % 16 == 0 && a.R % 16 == 0 && a.patch_k == 3 * a.P * a.P && a.P * a.R <= 48 * 1024) {
         hipLaunchKernelGGL(patchify_strip_u8_kernel, dim3((unsigned)((long long)a.B * 3 * a.grid)), dim3(256), (size_t)a.P * a.R + 512, st, a);

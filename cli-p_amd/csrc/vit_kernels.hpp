@@ -574,6 +574,29 @@ static __global__ void __launch_bounds__(256) quantize_rows_fp8mx_kernel(const u
     }
 }
 
+// rows_mx_stats_kernel (FP8 towers with folded LayerNorms, round 4): f32 rows [M][W] -> the rows as e4m3 with MX block
+// scales [M][W] + [M][W / 32] and their canonical statistics partials [M][W / 256][2] - what the FP8 residual GEMM's store
+// pass (EPI_BIAS_RESID_LN8) leaves behind for every later layer, here for the embedding stage's rows (ln_pre's output).
+// One wave per row; per 256-column segment a lane holds 4 consecutive columns: gemm.hpp ln8_row_segment. W % 256 == 0.
+static __global__ void __launch_bounds__(256) rows_mx_stats_kernel(const float* __restrict__ x, unsigned char* __restrict__ x8,
+                                                                   unsigned char* __restrict__ bs, float* __restrict__ part,
+                                                                   int M, int W) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const int nseg = W >> 8;
+    for (int sg = 0; sg < nseg; ++sg) {
+        const size_t col = (size_t)sg * 256 + lane * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * W + col);
+        unsigned p4, sb;
+        float sm, sq;
+        ln8_row_segment(v, p4, sb, sm, sq);
+        *reinterpret_cast<unsigned*>(x8 + (size_t)r * W + col) = p4;
+        if ((lane & 7) == 0) bs[(size_t)r * (W >> 5) + (col >> 5)] = (unsigned char)sb;
+        if (lane == 0) *reinterpret_cast<f32x2*>(part + ((size_t)r * nseg + sg) * 2) = f32x2{sm, sq};
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // attention52_kernel: the ViT-B/32 shape (49 <= L <= 52, 4 key/query tiles, no mask) with the query tiles
 // walked in a LOOP instead of all at once. attention_kernel<4,...> keeps 16 score tiles + 16 output tiles +
@@ -1120,5 +1143,6 @@ int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int 
 int launch_patchify(const PatchArgs& a, hipStream_t st);
 int launch_quantize_rows_fp8(const unsigned short* in, unsigned char* out, float* scale, int M, int K, hipStream_t st);
 int launch_quantize_rows_fp8mx(const unsigned short* in, unsigned char* out, unsigned char* bscale, int M, int K, hipStream_t st);
+int launch_rows_mx_stats(const float* x, unsigned char* x8, unsigned char* bs, float* part, int M, int W, hipStream_t st);
 
 }  // namespace clipmi

@@ -223,12 +223,28 @@ def ln_fold_terms(w, bias, gamma, beta):
     return wg, colsum.float(), cb.float()
 
 
+def ln_fold_terms_fp8(w, bias, gamma, beta):
+    """The LN-folded linear layer on FP8 operands (tower ABI 4): -> (e4m3 bytes uint8 [N][K], w_scale f32 [N], colsum f32 [N],
+    cb f32 [N]). The folded matrix Wg = W * gamma (W = the bf16-rounded weights, product in f32) is quantised per output
+    channel like every FP8 weight; colsum[n] = w_scale[n] * sum_k q[n][k] is the row sum of the DEQUANTISED e4m3 values - it
+    must cancel exactly what the GEMM adds up - and cb = W beta + bias as in the bf16 fold; sums in float64."""
+    wb = w.detach().to("cpu").to(torch.bfloat16).float()
+    wg = wb * gamma.detach().float()[None, :]
+    q, scale = quantize_fp8_rows(wg)
+    colsum = q.view(torch.float8_e4m3fn).double().sum(dim=1) * scale.double()
+    cb = wb.double() @ beta.detach().double() + bias.detach().double()
+    return q, scale, colsum.float(), cb.float()
+
+
 def _pack_layers(tw, blob, sd, prefix, width, layers, fp8=False):
     bf, f32 = torch.bfloat16, torch.float32
     first = None
     stride = None
     # (CLIPMI_LN_FOLD=0: development switch for A/B runs on one box — the stand-alone LayerNorm passes)
-    tw.ln_fold = 1 if (not fp8 and width % 256 == 0 and os.environ.get("CLIPMI_LN_FOLD", "1") != "0") else 0
+    # (FP8 towers: the folded form - e4m3(W diag(gamma)) weights, colsum of the rounded values - exists, is parity-green and
+    #  measured slower than the LayerNorm-pass tower, DESIGN.md 4.4c: development library only, CLIPMI_FP8_LN_FOLD=1)
+    fold_ok = not fp8 or os.environ.get("CLIPMI_FP8_LN_FOLD", "0") == "1"
+    tw.ln_fold = 1 if (fold_ok and width % 256 == 0 and os.environ.get("CLIPMI_LN_FOLD", "1") != "0") else 0
     names = [("lo_ln1_w", "ln_1.weight", f32), ("lo_ln1_b", "ln_1.bias", f32),
              ("lo_qkv_w", "attn.in_proj_weight", bf), ("lo_qkv_b", "attn.in_proj_bias", f32),
              ("lo_out_w", "attn.out_proj.weight", bf), ("lo_out_b", "attn.out_proj.bias", f32),
@@ -243,14 +259,20 @@ def _pack_layers(tw, blob, sd, prefix, width, layers, fp8=False):
             p_ = f"{prefix}.resblocks.{i}"
             for fld_w, wk, bk, ln in (("lo_qkv_w", "attn.in_proj_weight", "attn.in_proj_bias", "ln_1"),
                                       ("lo_fc_w", "mlp.c_fc.weight", "mlp.c_fc.bias", "ln_2")):
-                folded[fld_w] = ln_fold_terms(sd[f"{p_}.{wk}"], sd[f"{p_}.{bk}"], sd[f"{p_}.{ln}.weight"], sd[f"{p_}.{ln}.bias"])
+                args = (sd[f"{p_}.{wk}"], sd[f"{p_}.{bk}"], sd[f"{p_}.{ln}.weight"], sd[f"{p_}.{ln}.bias"])
+                if fp8:
+                    q8, sc8, colsum8, cb8 = ln_fold_terms_fp8(*args)
+                    folded[fld_w] = ((q8, sc8), colsum8, cb8)
+                else:
+                    folded[fld_w] = ln_fold_terms(*args)
         for field, key, dt in names:
             t = sd[f"{prefix}.resblocks.{i}.{key}"]
             if field in folded:
                 t = folded[field][0]                   # W * diag(ln weight), already bf16
             if fp8 and field in scale_field:
-                # the weights as the bf16 path stores them, then e4m3 + one scale per output channel
-                q, sc = quantize_fp8_rows(t.to(torch.bfloat16).float())
+                # the weights as the bf16 path stores them, then e4m3 + one scale per output channel (the LN-folded
+                # matrices come quantised from ln_fold_terms_fp8: their colsum belongs to exactly these bytes)
+                q, sc = t if field in folded else quantize_fp8_rows(t.to(torch.bfloat16).float())
                 off = blob.put(q, torch.uint8)
                 soff = blob.put(sc, f32)
                 if i == 0:

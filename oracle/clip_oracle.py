@@ -92,10 +92,13 @@ class linear_fp8:
     act="row": every activation with one scale per row (round 2's quantiser; kept as the looser yardstick);
     act="product" (default): the quantisers that run since round 3 - LayerNorm's rows (the operands of in_proj and c_fc) keep
     a row scale, the rows a GEMM takes straight from a producing kernel (attention's output -> out_proj, the QuickGELU rows ->
-    c_proj) travel with MX block scales (_fp8_mx_rows)."""
+    c_proj) travel with MX block scales (_fp8_mx_rows);
+    act="fold": round 4's tower - as "product", but ln_1 / ln_2 are FOLDED into in_proj / c_fc (_ln_linear): the A operand is
+    the un-normalised f32 residual row as e4m3 with MX block scales, the weights e4m3(W diag(gamma)) per output channel, and
+    the result rstd (acc - mean colsum) + (W beta + b) with colsum the row sums of the dequantised weights."""
 
     def __init__(self, act="product"):
-        assert act in ("row", "product")
+        assert act in ("row", "product", "fold")
         self.act = act
 
     def __enter__(self):
@@ -114,18 +117,30 @@ class linear_fp8:
 def _linear(x, w, b, mx=False):
     """mx: this operand comes straight from a producing kernel (attention, QuickGELU) - MX block scales in the FP8 tower."""
     if _FP8_LINEAR:
-        xq = _fp8_mx_rows(_r(x)) if (mx and _FP8_ACT == "product") else _fp8_rows(_r(x))
+        xq = _fp8_mx_rows(_r(x)) if (mx and _FP8_ACT in ("product", "fold")) else _fp8_rows(_r(x))
         return xq @ _fp8_rows(w).t() + b
     return _r(x) @ w.t() + b
 
 
+def _ln_linear(x, sd, ln, w, b):
+    """linear(LayerNorm(x)) - upstream's ln_1 -> in_proj and ln_2 -> c_fc. With linear_fp8(act="fold") in the product's folded
+    FP8 form (csrc/gemm.hpp "LN-folded linear layers", weights.ln_fold_terms_fp8): e4m3 MX blocks of the un-normalised row."""
+    if _FP8_LINEAR and _FP8_ACT == "fold":
+        gamma, beta = sd[ln + ".weight"], sd[ln + ".bias"]
+        mean = x.mean(dim=-1, keepdim=True)
+        rstd = torch.rsqrt(x.var(dim=-1, unbiased=False, keepdim=True) + LN_EPS)
+        wq = _fp8_rows(w * gamma[None, :])
+        return rstd * (_fp8_mx_rows(x) @ wq.t() - mean * wq.sum(dim=1)) + (w @ beta + b)
+    return _linear(_ln(x, sd, ln), w, b)
+
+
 def _attention(x, sd, p, heads, mask):
-    """nn.MultiheadAttention(width, heads) self-attention as ResidualAttentionBlock.attention
-    calls it (need_weights=False, attn_mask=mask); x is [B, L, W] here (upstream uses [L, B, W];
+    """ln_1 + nn.MultiheadAttention(width, heads) self-attention as ResidualAttentionBlock.attention
+    calls it on ln_1(x) (need_weights=False, attn_mask=mask); x is the block's input [B, L, W] here (upstream uses [L, B, W];
     the arithmetic is per (batch, head) and identical)."""
     B, L, W = x.shape
     hd = W // heads
-    qkv = _r(_linear(x, sd[p + ".attn.in_proj_weight"], sd[p + ".attn.in_proj_bias"]))
+    qkv = _r(_ln_linear(x, sd, p + ".ln_1", sd[p + ".attn.in_proj_weight"], sd[p + ".attn.in_proj_bias"]))
     q, k, v = qkv.split(W, dim=-1)
     q = q.reshape(B, L, heads, hd).transpose(1, 2)
     k = k.reshape(B, L, heads, hd).transpose(1, 2)
@@ -140,8 +155,8 @@ def _attention(x, sd, p, heads, mask):
 
 def _resblock(x, sd, p, heads, mask):
     # upstream ResidualAttentionBlock.forward: x + attention(ln_1(x)); x + mlp(ln_2(x))
-    x = x + _attention(_ln(x, sd, p + ".ln_1"), sd, p, heads, mask)
-    h = _linear(_ln(x, sd, p + ".ln_2"), sd[p + ".mlp.c_fc.weight"], sd[p + ".mlp.c_fc.bias"])
+    x = x + _attention(x, sd, p, heads, mask)             # _attention applies ln_1 itself (_ln_linear)
+    h = _ln_linear(x, sd, p + ".ln_2", sd[p + ".mlp.c_fc.weight"], sd[p + ".mlp.c_fc.bias"])
     h = _linear(quick_gelu(h), sd[p + ".mlp.c_proj.weight"], sd[p + ".mlp.c_proj.bias"], mx=True)
     return x + h
 
