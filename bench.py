@@ -582,9 +582,14 @@ def main():
     ms_fc, nl_fc, sym_fc = probe(1)
     fc_ms = ms_fc[2] if ms_fc[2] > 0 else ms_fc[1] if ms_fc[1] > 0 else ms_fc[0]
     fc_tflops = 2.0 * M * N * Kd / (fc_ms * 1e-3) / 1e12
-    ms_rs, nl_rs, sym_rs = probe(2)
-    rs_ms = ms_rs[1] if ms_rs[1] > 0 else ms_rs[0]                       # average over the (out_proj, c_proj) launches
     rs_flop = (2.0 * M * 768 * 768 + 2.0 * M * 768 * 3072) / 2.0           # per launch, averaged over the pair
+    try:
+        ms_rs, nl_rs, sym_rs = probe(2)
+        rs_ms = ms_rs[1] if ms_rs[1] > 0 else ms_rs[0]                   # average over the (out_proj, c_proj) launches
+    except clipmi.ClipmiError:
+        # small batches (fewer tiles than CUs): the residual producer runs as GEMM-into-scratch + split_stats, which this
+        # probe does not bracket - report the c_fc GEMM in its place (not the headline configuration)
+        ms_rs, nl_rs, sym_rs, rs_ms, rs_flop = ms_fc, nl_fc, sym_fc + " [residual producer not on the persistent kernel at this batch: c_fc reported]", fc_ms, 2.0 * M * N * Kd
     rs_tflops = rs_flop / (rs_ms * 1e-3) / 1e12
     del ews, eout, model, images
     torch.cuda.empty_cache()

@@ -5,7 +5,7 @@ import os, sys
 os.environ.setdefault("CLIPMI_DEV_LIB", "1")
 os.environ.setdefault("CLIPMI_FP8_LN_FOLD", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))     # a test helper: lives under tests/ (it imports the oracle)
 import torch
 import clipmi
 import clip_case

@@ -311,9 +311,9 @@ def test_fp8_tower_with_folded_layernorms_in_the_development_library(clipmi, gpu
     residual GEMMs' store passes emit the residual rows as e4m3 + MX block scales + statistics partials, qkv / c_fc take those
     with the LN-folded epilogue. Parity-green against the emulation of exactly that arithmetic (clip_oracle.linear_fp8(act=
     "fold")) but slower than the default tower while its GEMMs run on the non-persistent kernel, so it lives
-    in the development library: a child process with CLIPMI_DEV_LIB=1 CLIPMI_FP8_LN_FOLD=1 runs tools/fp8_fold_check.py."""
+    in the development library: a child process with CLIPMI_DEV_LIB=1 CLIPMI_FP8_LN_FOLD=1 runs tests/fp8_fold_check.py."""
     import subprocess
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fp8_fold_check.py")],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fp8_fold_check.py")],
                        env=dict(os.environ, CLIPMI_DEV_LIB="1", CLIPMI_FP8_LN_FOLD="1"), capture_output=True, text=True, timeout=900)
     print(r.stdout)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
