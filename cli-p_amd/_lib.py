@@ -102,7 +102,7 @@ def lib():
     L.clipmi_i8_meta_bytes.restype = sz
     L.clipmi_i8_meta_bytes.argtypes = [i64]
     L.clipmi_quantize_rows_i8.restype = i32
-    L.clipmi_quantize_rows_i8.argtypes = [vp, i64, i32, vp, vp, vp]
+    L.clipmi_quantize_rows_i8.argtypes = [vp, i64, i32, vp, sz, vp, sz, vp]
     L.clipmi_topk_ip_coarse_i8.restype = i32
     L.clipmi_topk_ip_coarse_i8.argtypes = [vp, vp, vp, C.c_float, i64, i32, C.c_float, vp, i32, i32, i64, vp, vp, vp, sz, vp]
     L.clipmi_dbg_topk_coarse_i8_scan_ms.restype = i32

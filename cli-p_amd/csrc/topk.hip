@@ -2579,9 +2579,13 @@ extern "C" size_t clipmi_i8_meta_bytes(int64_t N) {
     return N < 0 ? 0 : (i8_row_meta_entries(N) + (size_t)((N + 31) / 32 + 1)) * sizeof(float2);
 }
 
-extern "C" int clipmi_quantize_rows_i8(const float* db_dev, int64_t N, int E, void* out_i8_dev, float* meta_dev, void* stream) {
+extern "C" int clipmi_quantize_rows_i8(const float* db_dev, int64_t N, int E, void* out_i8_dev, size_t out_i8_bytes, float* meta_dev,
+                                       size_t meta_bytes, void* stream) {
     if (!db_dev || !out_i8_dev || !meta_dev || N < 1 || E < 32 || E % 32 != 0)
         return set_err(CLIPMI_EINVAL, "quantize_rows_i8: bad arguments (N=%lld E=%d; E must be a multiple of 32)", (long long)N, E);
+    if (out_i8_bytes < clipmi_i8_copy_bytes(N, E) || meta_bytes < clipmi_i8_meta_bytes(N))
+        return set_err(CLIPMI_EINVAL, "quantize_rows_i8: copy %zu B / meta %zu B, need %zu / %zu (clipmi_i8_copy_bytes, clipmi_i8_meta_bytes)",
+                       out_i8_bytes, meta_bytes, clipmi_i8_copy_bytes(N, E), clipmi_i8_meta_bytes(N));
     float2* meta = reinterpret_cast<float2*>(meta_dev);
     hipLaunchKernelGGL(quantize_rows_i8_kernel, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, as_stream(stream), db_dev,
                        (long long)N, E, static_cast<signed char*>(out_i8_dev), meta, meta + i8_row_meta_entries(N));

@@ -155,8 +155,8 @@ class IndexFlatIP:
             N = db.shape[0]
             q8 = torch.empty(L.clipmi_i8_copy_bytes(N, self.d), dtype=torch.int8, device=db.device)
             meta = torch.zeros(L.clipmi_i8_meta_bytes(N) // 4, dtype=torch.float32, device=db.device)
-            _lib.check(L.clipmi_quantize_rows_i8(db.data_ptr(), N, self.d, q8.data_ptr(), meta.data_ptr(),
-                                                 _lib.stream_ptr(self.device)), "clipmi_quantize_rows_i8")
+            _lib.check(L.clipmi_quantize_rows_i8(db.data_ptr(), N, self.d, q8.data_ptr(), q8.numel(), meta.data_ptr(),
+                                                 meta.numel() * 4, _lib.stream_ptr(self.device)), "clipmi_quantize_rows_i8")
             self._rmax, amax = self._stats(meta)
             self._db8 = (q8, meta, amax)
         return self._db8 + (self._row_norm_max(),)

@@ -185,7 +185,10 @@ int clipmi_rows_stats(const float* db_dev, int64_t N, int E, const float* meta_d
 int clipmi_rows_to_bf16(const float* db_dev, int64_t N, int E, void* out_bf16_dev, void* stream);
 size_t clipmi_i8_copy_bytes(int64_t N, int E);
 size_t clipmi_i8_meta_bytes(int64_t N);
-int clipmi_quantize_rows_i8(const float* db_dev, int64_t N, int E, void* out_i8_dev, float* meta_dev, void* stream);
+/* (ABI 4: the two buffer sizes are arguments - a copy or meta buffer smaller than clipmi_i8_copy_bytes / clipmi_i8_meta_bytes
+ *  is refused with CLIPMI_EINVAL instead of written past.) */
+int clipmi_quantize_rows_i8(const float* db_dev, int64_t N, int E, void* out_i8_dev, size_t out_i8_bytes, float* meta_dev,
+                            size_t meta_bytes, void* stream);
 int clipmi_topk_ip_coarse_i8(const void* db_dev, const void* db_i8_dev, const float* meta_dev, float amax,
                              int64_t N, int E, float rmax, const float* q_dev, int Q, int K, int64_t id_base,
                              float* out_score_dev, int64_t* out_id_dev,

@@ -68,6 +68,14 @@ def test_topk_argument_validation_without_gpu(clipmi):
     assert rc == 4 and "db_dtype" in clipmi._lib.last_error()
     rc = L.clipmi_merge_topk(None, None, 2, 1, 5, None, None, None, 0, None)
     assert rc == 1
+    # the int8 copy's buffers are sized by the library and CHECKED (no launch happens: argument validation only) -
+    # a caller that sizes them as the first version-3 header described ((N32 + 32) x 2 floats, an [N][E] copy) is refused
+    N = 1000
+    N32 = (N + 31) // 32 * 32
+    assert L.clipmi_i8_copy_bytes(N, 512) == N32 * 512 and L.clipmi_i8_meta_bytes(N) == ((N32 + 32) + (N32 // 32 + 1)) * 8
+    fake = C.c_void_p(256)
+    rc = L.clipmi_quantize_rows_i8(fake, N, 512, fake, N * 512, fake, (N32 + 32) * 8, None)
+    assert rc == 1 and "clipmi_i8_meta_bytes" in clipmi._lib.last_error()
 
 
 def test_missing_library_fails_loudly(clipmi, monkeypatch):
