@@ -583,9 +583,24 @@ def main():
     fc_ms = ms_fc[2] if ms_fc[2] > 0 else ms_fc[1] if ms_fc[1] > 0 else ms_fc[0]
     fc_tflops = 2.0 * M * N * Kd / (fc_ms * 1e-3) / 1e12
     rs_flop = (2.0 * M * 768 * 768 + 2.0 * M * 768 * 3072) / 2.0           # per launch, averaged over the pair
+    rs_parts = None
     try:
-        ms_rs, nl_rs, sym_rs = probe(2)
-        rs_ms = ms_rs[1] if ms_rs[1] > 0 else ms_rs[0]                   # average over the (out_proj, c_proj) launches
+        # completion of the kernel directly in front -> completion of this one (ms3[2], the estimator that agrees with
+        # rocprofv3): c_proj (K = 3072) follows c_fc, out_proj (K = 768) follows attention, whose launch carries its own end
+        # stamp in this mode. Average of the pair = the family.
+        ms_cp, nl_cp, sym_rs = probe(2 | (3072 << 8))
+        ms_op, nl_op, _ = probe(2 | (768 << 8))
+        cp_ms = ms_cp[2] if ms_cp[2] > 0 else ms_cp[1]
+        op_ms = ms_op[2] if ms_op[2] > 0 else ms_op[1]
+        rs_ms, nl_rs = (cp_ms + op_ms) / 2.0, nl_cp + nl_op
+        ms_rs = [(ms_cp[0] + ms_op[0]) / 2.0, (ms_cp[1] + ms_op[1]) / 2.0, 0.0]
+        rs_parts = {"c_proj_K3072": {"kernel_ms": cp_ms, "tflops": 2.0 * M * 768 * 3072 / (cp_ms * 1e-3) / 1e12,
+                                     "estimator": "completion_to_completion", "completion_to_completion": ms_cp[2],
+                                     "event_in_front_to_end": ms_cp[1], "launch_begin_to_end_events": ms_cp[0]},
+                    "out_proj_K768": {"kernel_ms": op_ms, "tflops": 2.0 * M * 768 * 768 / (op_ms * 1e-3) / 1e12,
+                                      "estimator": "completion_to_completion" if ms_op[2] > 0 else "event_in_front_to_end",
+                                      "completion_to_completion": ms_op[2], "event_in_front_to_end": ms_op[1],
+                                      "launch_begin_to_end_events": ms_op[0]}}
     except clipmi.ClipmiError:
         # small batches (fewer tiles than CUs): the residual producer runs as GEMM-into-scratch + split_stats, which this
         # probe does not bracket - report the c_fc GEMM in its place (not the headline configuration)
@@ -661,7 +676,8 @@ def main():
                      "kernel_ms": rs_ms, "launches_timed": nl_rs,
                      "algorithmic_flop_per_launch": rs_flop,
                      "kernel_ms_estimators": {"event_in_front_to_end": ms_rs[1], "launch_begin_to_end_events": ms_rs[0],
-                                              "used": "event_in_front_to_end (average over the out_proj / c_proj pair)"},
+                                              "used": "mean of c_proj and out_proj, each completion of the kernel in front -> own completion"},
+                     "per_shape": rs_parts,
                      "c_fc": {"kernel": sym_fc + f" (MLP c_fc + LayerNorm fold + bias + QuickGELU, M={M} N={N} K={Kd}; 12 launches per step)",
                               "achieved": fc_tflops, "frac": fc_tflops / PEAK_BF16_TFLOPS, "kernel_ms": fc_ms,
                               "launches_timed": nl_fc, "traffic": traffic_fc, "traffic_source": tsrc_fc,

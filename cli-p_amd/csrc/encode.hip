@@ -181,7 +181,13 @@ int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int 
         for (int l = 0; l < t->layers; ++l) {
             const uint64_t lb = lb_of(l);
             if (int rc = ln_linear(lb + t->lo_qkv_w, lb + t->lo_qkv_cb, lb + t->lo_qkv_colsum, 3 * W, EPI_LN_BIAS_BF16)) return rc;
-            if (int rc = launch_attention(w.big, w.h, B, L, t->heads, causal, 1, st)) return rc;
+            // (bench probe, mode 2: attention's own end stamp, so that out_proj gets a completion-to-completion time too)
+            hipEvent_t* aev = nullptr;
+            if (probe && probe->mode == 2 && probe->n < GemmProbe::MAX) {
+                const int pi = probe->begin(GemmProbe::EPI_ATTENTION, 2, st, 0);
+                aev = &probe->ev[2 * pi];
+            }
+            if (int rc = launch_attention(w.big, w.h, B, L, t->heads, causal, 1, st, nullptr, nullptr, nullptr, aev)) return rc;
             if (int rc = resid_linear(w.h, W, lb + t->lo_out_w, lb + t->lo_out_b)) return rc;
             if (int rc = ln_linear(lb + t->lo_fc_w, lb + t->lo_fc_cb, lb + t->lo_fc_colsum, 4 * W, EPI_LN_BIAS_QGELU_BF16)) return rc;
             if (int rc = resid_linear(w.big, 4 * W, lb + t->lo_proj_w, lb + t->lo_proj_b)) return rc;
@@ -369,6 +375,9 @@ static int encode_probe(const clipmi_tower* t, const void* blob_dev, const void*
                         void* ws_dev, size_t ws_bytes, void* stream, int probe_epi, int reps, int nmodes, float* ms, int* launches,
                         int* kernel_kind, int* epi_ran) {
     if (!ms || reps < 1) return set_err(CLIPMI_EINVAL, "dbg_encode_image_probe_ms: bad arguments");
+    // probe_epi bits 8..: only launches with this K (out_proj and c_proj share the residual epilogue and differ in K); 0 = any
+    const int k_filter = probe_epi >> 8;
+    probe_epi &= 0xff;
     GemmProbe p;             // lives on this call's stack: the library keeps no mutable state (clipmi.h)
     for (int i = 0; i < 2 * GemmProbe::MAX; ++i)
         if (hipEventCreate(&p.ev[i]) != hipSuccess) return set_err(CLIPMI_EHIP, "hipEventCreate");
@@ -384,13 +393,16 @@ static int encode_probe(const clipmi_tower* t, const void* blob_dev, const void*
             if (rc) break;
             if (hipStreamSynchronize(as_stream(stream)) != hipSuccess) { rc = set_err(CLIPMI_EHIP, "hipStreamSynchronize"); break; }
             for (int i = 0; i < p.n; ++i) {
-                if (GemmProbe::base_of(p.epi_of[i]) != probe_epi) continue;
+                if (GemmProbe::base_of(p.epi_of[i]) != probe_epi || (k_filter && p.k_of[i] != k_filter)) continue;
                 float v = 0.f;
                 if (mode == 0) (void)hipEventElapsedTime(&v, p.ev[2 * i], p.ev[2 * i + 1]);
                 else if (mode == 1) (void)hipEventElapsedTime(&v, p.pre[i], p.ev[2 * i + 1]);
                 else {
-                    // the launch in front must be the residual producer of the same block (no kernel between them)
-                    if (i == 0 || p.epi_of[i - 1] != EPI_BIAS_RESID_LN_F32 || p.kernel_of[i - 1] != 2) continue;
+                    // the launch in front must carry its own end stamp with NO kernel between them: the residual producer in front
+                    // of qkv / c_fc, c_fc in front of c_proj, attention (probed in this mode) in front of out_proj
+                    if (i == 0 || p.kernel_of[i - 1] != 2 ||
+                        (p.epi_of[i - 1] != EPI_BIAS_RESID_LN_F32 && p.epi_of[i - 1] != EPI_LN_BIAS_QGELU_BF16 &&
+                         p.epi_of[i - 1] != GemmProbe::EPI_ATTENTION)) continue;
                     (void)hipEventElapsedTime(&v, p.ev[2 * (i - 1) + 1], p.ev[2 * i + 1]);
                 }
                 total += v;

@@ -26,7 +26,7 @@ static int launch_epi(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
     if (probe && probe->wants(EPI)) {
         GemmProbe& p = *probe;
         // measurement probe: the events take the dispatch's own begin/end timestamps
-        const int i = p.begin(EPI, 0, st);
+        const int i = p.begin(EPI, 0, st, g.K);
         hipExtLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(grid), dim3(256), GEMM_LDS_BYTES, st, p.ev[2 * i],
                               p.ev[2 * i + 1], 0, g);
     } else {
@@ -47,7 +47,7 @@ static int launch_epi256(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
     }
     if (probe && probe->wants(EPI)) {
         GemmProbe& p = *probe;
-        const int i = p.begin(EPI, 1, st);
+        const int i = p.begin(EPI, 1, st, g.K);
         hipExtLaunchKernelGGL(gemm256_bf16_nt_kernel<EPI>, dim3(grid), dim3(512), G256_LDS, st, p.ev[2 * i],
                               p.ev[2 * i + 1], 0, g);
     } else {
@@ -105,7 +105,7 @@ static int launch_epi256p(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
     }
     if (probe && probe->wants(EPI)) {
         GemmProbe& p = *probe;
-        const int i = p.begin(EPI, 2, st);
+        const int i = p.begin(EPI, 2, st, g.K);
         hipExtLaunchKernelGGL((gemm256p_bf16_nt_kernel<EPI, FP8>), dim3(grid), dim3(512), lds, st, p.ev[2 * i],
                               p.ev[2 * i + 1], 0, g);
     } else {

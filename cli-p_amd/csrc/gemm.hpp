@@ -415,7 +415,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(GemmArgs g) {
 // library keeps no mutable state of its own): every launch whose epilogue is `epi` (or its LN-folded twin) is
 // bracketed by a pair of HIP events on its own stream.
 struct GemmProbe {
-    static constexpr int MAX = 64;
+    static constexpr int MAX = 96;
+    static constexpr int EPI_ATTENTION = 100;     // pseudo-epilogue of a probed attention launch (mode 2: the kernel in front of out_proj)
     int epi = -1, n = 0;
     // mode 0: events from hipExtLaunchKernel (the dispatch's own begin / end) around the launches whose epilogue matches
     //         `epi`; mode 1: the same plus a plain event record in front (`pre`: completion of everything before);
@@ -425,15 +426,17 @@ struct GemmProbe {
     hipEvent_t pre[MAX];
     int epi_of[MAX];          // the epilogue that really ran (EPI_LN_* when the tower folds its LayerNorms)
     int kernel_of[MAX];       // 0 gemm_bf16_nt_kernel (128^2), 1 gemm256_bf16_nt_kernel, 2 gemm256p_bf16_nt_kernel
+    int k_of[MAX];            // the launch's K (out_proj and c_proj share an epilogue and differ in K)
     static int base_of(int e) {
         return e == EPI_LN_BIAS_BF16 ? EPI_BIAS_BF16 : e == EPI_LN_BIAS_QGELU_BF16 ? EPI_BIAS_QGELU_BF16 :
                e == EPI_BIAS_RESID_LN_F32 ? EPI_BIAS_RESID_F32 : e;
     }
     bool wants(int e) const { return n < MAX && (mode == 2 || base_of(e) == epi); }
     // called by the launchers right before a probed launch; returns the slot
-    int begin(int e, int kernel, hipStream_t st) {
+    int begin(int e, int kernel, hipStream_t st, int K = 0) {
         epi_of[n] = e;
         kernel_of[n] = kernel;
+        k_of[n] = K;
         if (mode == 1) (void)hipEventRecord(pre[n], st);
         return n++;
     }

@@ -1,5 +1,6 @@
 // vit_kernels.hip — launchers for the non-GEMM tower kernels and their debug entry points.
 #include "vit_kernels.hpp"
+#include <hip/hip_ext.h>
 #include <cstdlib>
 
 namespace clipmi {
@@ -36,7 +37,7 @@ static int launch_attn_t(const unsigned short* qkv, unsigned short* out, int B, 
 }
 
 int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int L, int heads, int causal, int tr,
-                     hipStream_t st, unsigned char* out8, unsigned char* out_bs, bool* fused) {
+                     hipStream_t st, unsigned char* out8, unsigned char* out_bs, bool* fused, hipEvent_t* probe_ev) {
     if (fused) *fused = false;
     if (B < 1) return 0;
     if (L < 1) return set_err(CLIPMI_EINVAL, "attention: L=%d", L);
@@ -64,6 +65,10 @@ int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int 
             hipLaunchKernelGGL(attention52x4_kernel<true>, dim3((unsigned)(items < resident ? items : resident)), dim3(256),
                                64 * 128 + 52 * 128, st, qkv, out, B, L, heads, out8, out_bs);
             *fused = true;
+        } else if (probe_ev) {
+            hipExtLaunchKernelGGL(attention52x4_kernel<false>, dim3((unsigned)(items < resident ? items : resident)), dim3(256),
+                                  64 * 128 + 52 * 128, st, probe_ev[0], probe_ev[1], 0, qkv, out, B, L, heads, (unsigned char*)nullptr,
+                                  (unsigned char*)nullptr);
         } else {
             hipLaunchKernelGGL(attention52x4_kernel<false>, dim3((unsigned)(items < resident ? items : resident)), dim3(256),
                                64 * 128 + 52 * 128, st, qkv, out, B, L, heads, (unsigned char*)nullptr, (unsigned char*)nullptr);

@@ -1139,7 +1139,8 @@ int launch_layernorm(const LnArgs& a, hipStream_t st);
 // out8 / out_bs / fused (FP8 towers): when the shape's kernel has the fused form, the rows are written as e4m3 + MX block
 // scales into out8 / out_bs INSTEAD of bf16 into out and *fused is set; otherwise bf16 into out as always
 int launch_attention(const unsigned short* qkv, unsigned short* out, int B, int L, int heads, int causal, int tr,
-                     hipStream_t st, unsigned char* out8 = nullptr, unsigned char* out_bs = nullptr, bool* fused = nullptr);
+                     hipStream_t st, unsigned char* out8 = nullptr, unsigned char* out_bs = nullptr, bool* fused = nullptr,
+                     hipEvent_t* probe_ev = nullptr);     // probe_ev[0..1]: the dispatch's own begin / end (bench probe)
 int launch_patchify(const PatchArgs& a, hipStream_t st);
 int launch_quantize_rows_fp8(const unsigned short* in, unsigned char* out, float* scale, int M, int K, hipStream_t st);
 int launch_quantize_rows_fp8mx(const unsigned short* in, unsigned char* out, unsigned char* bscale, int M, int K, hipStream_t st);

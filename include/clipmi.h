@@ -309,7 +309,9 @@ int clipmi_dbg_encode_image_probe_ms(const clipmi_tower* t, const void* blob_dev
 /* The same with three estimators of the kernel's in-situ duration, ms3[0..2] (csrc/encode.hip encode_probe): begin -> end
  * events of the launch itself (reads long in a back-to-back stream), plain event in front -> end event, and end event of the
  * GEMM directly in front -> end event of this one (completion to completion; 0 when not applicable). *kernel_kind: 0 / 1 / 2 =
- * gemm_bf16_nt_kernel / gemm256_bf16_nt_kernel / gemm256p_bf16_nt_kernel; *epi_ran: its EPI template argument. */
+ * gemm_bf16_nt_kernel / gemm256_bf16_nt_kernel / gemm256p_bf16_nt_kernel; *epi_ran: its EPI template argument.
+ * probe_epi bits 8 and up, when non-zero, restrict the probe to launches with that K (attn.out_proj and mlp.c_proj share the
+ * residual epilogue: 2 | (3072 << 8) times c_proj alone). */
 int clipmi_dbg_encode_image_probe3_ms(const clipmi_tower* t, const void* blob_dev, const void* pixels_dev,
                                       int pix_dtype, int B, float* out_dev, void* ws_dev, size_t ws_bytes,
                                       void* stream, int probe_epi, int reps, float* ms3, int* launches,
