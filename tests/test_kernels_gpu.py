@@ -405,7 +405,8 @@ def test_gemm_ln_folded_consumer(clipmi, gpu, M, W, N, epi):
         assert torch.equal(out, outs[0]), f"algo {algo} differs from the default kernel's bits"
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 768, 768), (300, 512, 2048), (6400, 768, 768), (6401, 768, 3072), (70000, 768, 768),
+@pytest.mark.parametrize("M,N,K", [(1, 768, 768), (77, 512, 2048), (10, 512, 512), (128, 768, 768), (100, 1024, 1024), (17, 768, 3072),
+                                   (300, 512, 2048), (6400, 768, 768), (6401, 768, 3072), (70000, 768, 768),
                                    (43500, 768, 3072), (1000, 1024, 1024), (25600, 768, 768), (25601, 768, 3072)])
 def test_gemm_resid_ln_producer(clipmi, gpu, M, N, K):
     """(hi, lo) += a W^T + bias with the statistics partials of the new rows: the persistent kernel's fused store pass
