@@ -667,15 +667,23 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // their scale (s = the block's max |x| / 127): a wave's compare then has one scale per step and becomes an integer
 // test (scan_coarse_wide_kernel). meta[r] = (s_block, a_r); bmeta[block] = (s_block, max a_r of the block), stored
 // behind the row meta. Rows past N in the last block are zero.
+// Round 4: the copy is a PERMUTATION of the rows. Slot t of the copy holds row perm[t] (perm = null: the identity); callers
+// order the rows by their largest |component| (IndexFlatIP.matrix_i8), so that the 32 rows of a block have nearly the same
+// maximum and the block's scale is (almost) each row's own: the error norms a_r - and with them the coarse bound's margin -
+// drop back to the per-row-scale values of round 2 (x 1.265 -> x 1.000 on unit rows; re-scored rows per query 5.8 k -> 5.1 k
+// at 10 M rows). The scans work on slots; slot_rows[t] = the row a slot holds (0xffffffff for the padding slots N .. N32 - 1),
+// stored behind the block meta, is read only for survivors (rescore_pairs_kernel), which leave the lists as row ids.
 __global__ void __launch_bounds__(256) quantize_rows_i8_kernel(const float* __restrict__ db, long long N, int E,
+                                                               const unsigned* __restrict__ perm,
                                                                signed char* __restrict__ out, float2* __restrict__ meta,
-                                                               float2* __restrict__ bmeta) {
+                                                               float2* __restrict__ bmeta, unsigned* __restrict__ slot_rows) {
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long blk = blockIdx.x, r0 = blk * 32;
     float mx = 0.f;
     for (int i = 0; i < 8; ++i) {
-        const long long r = r0 + wave * 8 + i;
+        const long long t = r0 + wave * 8 + i;                     // slot
+        const long long r = t < N ? (perm ? (long long)perm[t] : t) : N;
         if (r < N)
             for (int k = lane * 4; k < E; k += 256) {
                 const float4 v = *reinterpret_cast<const float4*>(db + (size_t)r * E + k);
@@ -693,7 +701,8 @@ __global__ void __launch_bounds__(256) quantize_rows_i8_kernel(const float* __re
     float amax_w = 0.f;
     for (int i = 0; i < 8; ++i) {
         const int rloc = wave * 8 + i;
-        const long long r = r0 + rloc;
+        const long long t = r0 + rloc;                             // slot
+        const long long r = t < N ? (perm ? (long long)perm[t] : t) : N;
         float ee = 0.f;
         for (int k = lane * 4; k < E; k += 256) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -714,7 +723,10 @@ __global__ void __launch_bounds__(256) quantize_rows_i8_kernel(const float* __re
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) ee += __shfl_xor(ee, o);
         const float a_r = r < N ? sqrtf(ee) * 1.001f : 0.f;
-        if (lane == 0) meta[r] = make_float2(s, a_r);
+        if (lane == 0) {
+            meta[t] = make_float2(s, a_r);
+            slot_rows[t] = r < N ? (unsigned)r : 0xffffffffu;
+        }
         amax_w = fmaxf(amax_w, a_r);
     }
     if (lane == 0) red[4 + wave] = amax_w;
@@ -821,6 +833,11 @@ __global__ void __launch_bounds__(256) coarse_prep_kernel(const float* __restric
     }
 }
 
+// A coarse scan appends (CAND_SLOT, slot of the copy); the re-scoring pass turns such an entry into (exact score bits, row id).
+// No score has these bits (a NaN score is stored as -inf), so an entry that was re-scored before - the K best a select keeps at
+// the head of the list - is recognised and keeps its row id.
+constexpr unsigned CAND_SLOT = 0xffffffffu;
+
 struct CoarseArgs {
     const void* dbc;             // coarse copy of the matrix: bf16 [nrows][E] or int8 [nrows][E]
     const float2* rmeta;         // int8 only: per row (scale s_r, error norm a_r >= ||x_r - s_r q_r||), padded to 32 rows
@@ -855,7 +872,7 @@ __device__ __noinline__ void coarse_flush(uint2* list, int* lcnt, unsigned* gcnt
     for (int e = lane; e < n; e += 64) {
         const uint2 c = list[e];
         const unsigned pos = atomicAdd(&gcnt[c.x], 1u);
-        if ((long long)pos < cap) cand[(size_t)c.x * cap + pos] = make_uint2(0u, c.y);
+        if ((long long)pos < cap) cand[(size_t)c.x * cap + pos] = make_uint2(CAND_SLOT, c.y);
         else *overflow = 1u;
     }
     wave_lds_sync();
@@ -1072,7 +1089,7 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
     for (int e = lane; e < n_mine; e += 64) {
         const uint2 c = list[e];
         const unsigned pos = gbase[c.x] + atomicAdd(&hoff[c.x], 1u);
-        if ((long long)pos < a.cap) a.cand[(size_t)c.x * a.cap + pos] = make_uint2(0u, c.y);
+        if ((long long)pos < a.cap) a.cand[(size_t)c.x * a.cap + pos] = make_uint2(CAND_SLOT, c.y);
         else *a.overflow = 1u;
     }
 }
@@ -1085,7 +1102,8 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
 // one thread fetching its own 2-KB row took ~1 ms for 175 k pairs: 4 uncoalesced loads in flight).
 template <int E>
 __global__ void __launch_bounds__(256) rescore_pairs_kernel(const float* __restrict__ db, const float* __restrict__ q,
-                                                            uint2* cand, const unsigned* __restrict__ gcnt, long long cap) {
+                                                            uint2* cand, const unsigned* __restrict__ gcnt, long long cap,
+                                                            const unsigned* __restrict__ slot_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RS = 68;                                  // floats per staged row chunk (64 + 4 pad: conflict-free b128 reads)
     float* qs = reinterpret_cast<float*>(smem);
@@ -1100,7 +1118,10 @@ __global__ void __launch_bounds__(256) rescore_pairs_kernel(const float* __restr
     uint2* lst = cand + (size_t)qi * cap;
     for (long long base = ((long long)blockIdx.x * 4 + wave) * 64; base < M; base += (long long)gridDim.x * 4 * 64) {
         const long long my = base + lane;
-        const unsigned id_my = lst[my < M ? my : M - 1].y;
+        const uint2 ent = lst[my < M ? my : M - 1];
+        // a fresh survivor names a SLOT of the (permuted) int8 copy: its row id comes from slot_rows (one more dependent read,
+        // for survivors only); entries kept from earlier segments are row ids already
+        const unsigned id_my = (ent.x == CAND_SLOT && slot_rows) ? slot_rows[ent.y] : ent.y;
         float acc = 0.f;
         // chunk c+1's 16 loads are issued (to registers) before chunk c is consumed from LDS: one
         // HBM round trip per chunk stays, but it overlaps the previous chunk's LDS reads and fmaf chain
@@ -1134,7 +1155,7 @@ __global__ void __launch_bounds__(256) rescore_pairs_kernel(const float* __restr
             }
             wave_lds_sync();
         }
-        if (my < M) lst[my].x = __float_as_uint(acc == acc ? acc : -INFINITY);      // NaN never ranks
+        if (my < M) lst[my] = make_uint2(__float_as_uint(acc == acc ? acc : -INFINITY), id_my);      // NaN never ranks
     }
 }
 
@@ -1175,6 +1196,7 @@ __device__ __forceinline__ float fkey_inv(unsigned k) {
 struct LiveArgs {
     const signed char* dbc;      // int8 copy (32-row blocks)
     const float2* rmeta;         // per row (block scale, error norm)
+    const unsigned* slot_rows;   // the row each slot of the copy holds (quantize_rows_i8_kernel)
     const float* db;             // f32 [N][512]
     const float* q;              // f32 [QA][512]
     const float* qmeta;          // [4][64]: 1/t | Y/t | (unused here) | margin
@@ -1510,7 +1532,8 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
             // ---- the lanes that hold a pair
             if (got) { *sl = make_uint2(0u, LIVE_EMPTY); pend = false; ++st_pop; }
             const unsigned qi = got ? (e.y >> LIVE_ROW_BITS) : 0u;
-            const unsigned row = e.y & ((1u << LIVE_ROW_BITS) - 1u);
+            const unsigned slot_ = e.y & ((1u << LIVE_ROW_BITS) - 1u);
+            const unsigned row = (got && a.slot_rows) ? a.slot_rows[slot_] : slot_;       // the copy is a permutation of the rows
             bool live_ = got && a.abl != 2;
             bool scored = false;
             float myscore = 0.f;
@@ -1668,6 +1691,11 @@ __global__ void __launch_bounds__(512) scan_coarse_live_kernel(LiveArgs a) {
 // =================================================================================================
 // meta of the int8 copy: row entries for N rounded up to 32 rows (+32), then one (scale, largest error norm) pair per block (+1)
 inline size_t i8_row_meta_entries(int64_t N) { return (size_t)((N + 31) / 32 * 32 + 32); }
+inline size_t i8_block_meta_entries(int64_t N) { return (size_t)((N + 31) / 32 + 1); }
+// ... and behind the block meta one u32 per slot: the row it holds (quantize_rows_i8_kernel)
+inline const unsigned* i8_slot_rows(const float2* rmeta, int64_t N) {
+    return reinterpret_cast<const unsigned*>(rmeta + i8_row_meta_entries(N) + i8_block_meta_entries(N));
+}
 
 constexpr int WIDE_MAX_Q = 1024;                 // queries of one wide launch (4 tiles of 256)
 constexpr int WIDE_TILE_SETS = 4;                // 64-query sets per tile: 4 x 32 KiB of image
@@ -1702,7 +1730,7 @@ __device__ __noinline__ void wide_flush(const uint2* list, int n, int qbase, uns
         const uint2 c = list[e];
         const unsigned q = (unsigned)qbase + c.x;
         const unsigned pos = atomicAdd(&gcnt[q], 1u);
-        if ((long long)pos < cap) cand[(size_t)q * cap + pos] = make_uint2(0u, c.y);
+        if ((long long)pos < cap) cand[(size_t)q * cap + pos] = make_uint2(CAND_SLOT, c.y);
         else *overflow = 1u;
     }
     wave_lds_sync();
@@ -1907,7 +1935,7 @@ __global__ void __launch_bounds__(WAVES * 64) scan_coarse_wide_kernel(WideArgs a
     for (int e = lane; e < npend; e += 64) {
         const uint2 c = list[e];
         const unsigned pos = gbase[c.x] + atomicAdd(&hoff[c.x], 1u);
-        if ((long long)pos < a.cap) a.cand[(size_t)(qbase + c.x) * a.cap + pos] = make_uint2(0u, c.y);
+        if ((long long)pos < a.cap) a.cand[(size_t)(qbase + c.x) * a.cap + pos] = make_uint2(CAND_SLOT, c.y);
         else *a.overflow = 1u;
     }
 }
@@ -2170,6 +2198,8 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
     hipStream_t st = as_stream(stream);
     if (int rc = opt_in_lds((const void*)select_topk_kernel, p.lds_sel)) return rc;
     if (int rc = opt_in_lds((const void*)rescore_pairs_kernel<512>, 512 * 4 + 4 * 64 * 68 * 4)) return rc;
+    // int8: the rows the copy's slots hold, behind the block meta (quantize_rows_i8_kernel); bf16 copy: rows in order
+    const unsigned* slot_rows = i8 ? i8_slot_rows(rmeta, N) : nullptr;
     // int8 copy, shards below 2^26 rows: the live-threshold scan - EXPERIMENTAL, off unless CLIPMI_LIVE=1. Bit-exact, ONE scan
     // launch, half the re-scored pairs, but 2.3 ms per 10 M-row scan against 0.9 ms for the three segmented scans (r03): its
     // 138 KB of LDS leave one workgroup = FOUR scanner waves per CU with one 16 KB step in flight each, a quarter of the bytes
@@ -2240,7 +2270,7 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             if (rc_) return rc_;
             // ~1-3 k survivors per query = ~11 blocks of 256 pairs; a larger grid only queues idle blocks
             hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(12, qa), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
-                               static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, COARSE_CAP);
+                               static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, COARSE_CAP, slot_rows);
             CLIPMI_CHECK_LAUNCH("rescore_pairs_kernel");
             // 4096 staged entries (32 KiB of LDS) cover these lists; a select block then fits on a CU even beside the
             // last segment's scan of ANOTHER batch in flight (104 KiB), which the 96-KiB staging of the sample select does not
@@ -2281,6 +2311,7 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             // ONE launch over all rows: scanners + re-scoring waves, thresholds rising through the ladder (scan_coarse_live_kernel)
             LiveArgs la;
             la.dbc = static_cast<const signed char*>(dbh_dev); la.rmeta = rmeta; la.db = static_cast<const float*>(db_dev);
+            la.slot_rows = slot_rows;
             la.q = qg; la.qmeta = w.qmeta; la.qimage = w.qimage; la.nrows = N; la.QA = qa; la.K = K;
             la.tau_key = w.live_keys; la.tex_key = w.live_keys + COARSE_Q; la.edge0 = w.live_edges; la.delta = w.live_edges + COARSE_Q;
             la.hist = w.hist; la.cand = w.cand_c; la.gcnt = w.gcnt_c; la.cap = COARSE_CAP; la.overflow = w.flag; la.chunk_ctr = w.flag + 1;
@@ -2449,6 +2480,7 @@ int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta,
     carve_wide(p, qc_max, ws_dev, ws_bytes, &w);
     const int qs = wide_qs(qc_max);
     hipStream_t st = as_stream(stream);
+    const unsigned* slot_rows = i8_slot_rows(rmeta, N);
     if (int rc = opt_in_lds((const void*)select_topk_kernel, p.lds_sel)) return rc;
     if (int rc = opt_in_lds((const void*)rescore_pairs_kernel<512>, 512 * 4 + 4 * 64 * 68 * 4)) return rc;
     const size_t lds1 = (size_t)(512 / 16) * 1024;
@@ -2518,7 +2550,7 @@ int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta,
 #endif
             if (ev) ev_used += 2;
             hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(12, qc), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
-                               static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, WIDE_CAP);
+                               static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, WIDE_CAP, slot_rows);
             CLIPMI_CHECK_LAUNCH("rescore_pairs_kernel(wide)");
             // keep: bit 0 = the K best stay at the head of the list for the next segment; bit 1 = add to the survivor count
             const int keep = (last ? 0 : 1) | (sgi > 0 ? 2 : 0);
@@ -2576,19 +2608,21 @@ extern "C" size_t clipmi_i8_copy_bytes(int64_t N, int E) {
 }
 
 extern "C" size_t clipmi_i8_meta_bytes(int64_t N) {
-    return N < 0 ? 0 : (i8_row_meta_entries(N) + (size_t)((N + 31) / 32 + 1)) * sizeof(float2);
+    return N < 0 ? 0 : (i8_row_meta_entries(N) + i8_block_meta_entries(N)) * sizeof(float2) + (size_t)((N + 31) / 32 * 32 + 32) * sizeof(unsigned);
 }
 
-extern "C" int clipmi_quantize_rows_i8(const float* db_dev, int64_t N, int E, void* out_i8_dev, size_t out_i8_bytes, float* meta_dev,
-                                       size_t meta_bytes, void* stream) {
+extern "C" int clipmi_quantize_rows_i8(const float* db_dev, int64_t N, int E, const uint32_t* perm_dev, void* out_i8_dev,
+                                       size_t out_i8_bytes, float* meta_dev, size_t meta_bytes, void* stream) {
     if (!db_dev || !out_i8_dev || !meta_dev || N < 1 || E < 32 || E % 32 != 0)
         return set_err(CLIPMI_EINVAL, "quantize_rows_i8: bad arguments (N=%lld E=%d; E must be a multiple of 32)", (long long)N, E);
     if (out_i8_bytes < clipmi_i8_copy_bytes(N, E) || meta_bytes < clipmi_i8_meta_bytes(N))
         return set_err(CLIPMI_EINVAL, "quantize_rows_i8: copy %zu B / meta %zu B, need %zu / %zu (clipmi_i8_copy_bytes, clipmi_i8_meta_bytes)",
                        out_i8_bytes, meta_bytes, clipmi_i8_copy_bytes(N, E), clipmi_i8_meta_bytes(N));
+    if (N >= (1ll << 32) - 1) return set_err(CLIPMI_EINVAL, "quantize_rows_i8: N=%lld (slots are 32-bit)", (long long)N);
     float2* meta = reinterpret_cast<float2*>(meta_dev);
     hipLaunchKernelGGL(quantize_rows_i8_kernel, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, as_stream(stream), db_dev,
-                       (long long)N, E, static_cast<signed char*>(out_i8_dev), meta, meta + i8_row_meta_entries(N));
+                       (long long)N, E, perm_dev, static_cast<signed char*>(out_i8_dev), meta, meta + i8_row_meta_entries(N),
+                       const_cast<unsigned*>(i8_slot_rows(meta, N)));
     CLIPMI_CHECK_LAUNCH("quantize_rows_i8_kernel");
     return 0;
 }
@@ -2629,6 +2663,21 @@ __global__ void __launch_bounds__(256) rows_stats_kernel(const float* __restrict
     }
 }
 
+__global__ void __launch_bounds__(256) rows_absmax_kernel(const float* __restrict__ db, long long N, int E, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    for (long long r = wave0; r < N; r += nw) {
+        float mx = 0.f;
+        for (int k = lane * 4; k < E; k += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(db + (size_t)r * E + k);
+            mx = fmaxf(fmaxf(mx, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (lane == 0) out[r] = mx;
+    }
+}
+
 __global__ void __launch_bounds__(256) rows_to_bf16_kernel(const float* __restrict__ db, long long n4, uint2* __restrict__ out) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const f32x4 v = reinterpret_cast<const f32x4*>(db)[i];
@@ -2645,6 +2694,15 @@ extern "C" int clipmi_rows_stats(const float* db_dev, int64_t N, int E, const fl
     hipLaunchKernelGGL(rows_stats_kernel, dim3(grid), dim3(256), 0, as_stream(stream), db_dev, (long long)N, E,
                        reinterpret_cast<const float2*>(meta_dev), reinterpret_cast<unsigned*>(stats2_dev));
     CLIPMI_CHECK_LAUNCH("rows_stats_kernel");
+    return 0;
+}
+
+extern "C" int clipmi_rows_absmax(const float* db_dev, int64_t N, int E, float* out_dev, void* stream) {
+    if (!db_dev || !out_dev || N < 1 || E < 4 || E % 4 != 0) return set_err(CLIPMI_EINVAL, "rows_absmax: bad arguments (N=%lld E=%d)", (long long)N, E);
+    const long long want = (N + 3) / 4;
+    const unsigned grid = (unsigned)(want < 16 * NUM_CU ? want : 16 * NUM_CU);
+    hipLaunchKernelGGL(rows_absmax_kernel, dim3(grid), dim3(256), 0, as_stream(stream), db_dev, (long long)N, E, out_dev);
+    CLIPMI_CHECK_LAUNCH("rows_absmax_kernel");
     return 0;
 }
 

@@ -72,9 +72,9 @@ def test_topk_argument_validation_without_gpu(clipmi):
     # a caller that sizes them as the first version-3 header described ((N32 + 32) x 2 floats, an [N][E] copy) is refused
     N = 1000
     N32 = (N + 31) // 32 * 32
-    assert L.clipmi_i8_copy_bytes(N, 512) == N32 * 512 and L.clipmi_i8_meta_bytes(N) == ((N32 + 32) + (N32 // 32 + 1)) * 8
+    assert L.clipmi_i8_copy_bytes(N, 512) == N32 * 512 and L.clipmi_i8_meta_bytes(N) == ((N32 + 32) + (N32 // 32 + 1)) * 8 + (N32 + 32) * 4
     fake = C.c_void_p(256)
-    rc = L.clipmi_quantize_rows_i8(fake, N, 512, fake, N * 512, fake, (N32 + 32) * 8, None)
+    rc = L.clipmi_quantize_rows_i8(fake, N, 512, None, fake, N * 512, fake, (N32 + 32) * 8, None)
     assert rc == 1 and "clipmi_i8_meta_bytes" in clipmi._lib.last_error()
 
 

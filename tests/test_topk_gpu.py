@@ -520,15 +520,17 @@ def test_wide_pass_useless_threshold_and_anisotropic(clipmi, gpu, topk_oracle):
 
 
 def test_quantize_rows_i8_matches_numpy(clipmi, gpu):
-    """clipmi_quantize_rows_i8 (include/clipmi.h): blocks of 32 rows share scale = max|x| / 127, q = rint(x / scale)
-    (round half to even), stored as [block][k-step of 32 B][lane][16 B] with lane l = row l & 31, bytes 32 s + 16 (l >> 5);
-    error norm >= the true one and within 0.2 % of it; one (scale, largest error norm) pair per block behind the row meta."""
+    """clipmi_quantize_rows_i8 (include/clipmi.h): slot t of the copy holds row perm[t] (IndexFlatIP orders the rows by their
+    largest |component|: a stable sort), blocks of 32 slots share scale = max|x| / 127, q = rint(x / scale) (round half to
+    even), stored as [block][k-step of 32 B][lane][16 B] with lane l = slot l & 31, bytes 32 s + 16 (l >> 5); error norm >= the
+    true one and within 0.2 % of it; one (scale, largest error norm) pair per block behind the slot meta, then the slot -> row
+    table. Sorted blocks give every row (nearly) its own scale: the error norms are those of per-row scales."""
     import torch
     rng = np.random.default_rng(81)
     N = 1000
     x = (unit_rows(rng, N, 512) * rng.uniform(0.1, 3.0, size=(N, 1))).astype(np.float32)
     x[7] = 0.0
-    x[32:64] = 0.0                                     # a whole block of zero rows: scale 1, codes 0
+    x[32:64] = 0.0                                     # 33 zero rows: they sort to the front; a whole block of them: scale 1, codes 0
     idx = clipmi.IndexFlatIP(512, device=gpu, coarse="int8")
     idx.add(x)
     q8, meta, amax, rmax = idx.matrix_i8()
@@ -537,12 +539,15 @@ def test_quantize_rows_i8_matches_numpy(clipmi, gpu):
     N32 = (N + 31) // 32 * 32
     nblk = N32 // 32
     assert q8.numel() == L.clipmi_i8_copy_bytes(N, 512) == N32 * 512
-    assert meta.numel() * 4 == L.clipmi_i8_meta_bytes(N) == ((N32 + 32) + (nblk + 1)) * 8
+    assert meta.numel() * 4 == L.clipmi_i8_meta_bytes(N) == ((N32 + 32) + (nblk + 1)) * 8 + (N32 + 32) * 4
     q8, meta = q8.cpu().numpy(), meta.cpu().numpy()
     rmeta = meta[:2 * (N32 + 32)].reshape(-1, 2)
-    bmeta = meta[2 * (N32 + 32):].reshape(-1, 2)
+    bmeta = meta[2 * (N32 + 32):2 * (N32 + 32) + 2 * (nblk + 1)].reshape(-1, 2)
+    slot_rows = meta[2 * (N32 + 32) + 2 * (nblk + 1):].view(np.uint32)
+    perm = np.argsort(np.abs(x).max(axis=1), kind="stable")
+    assert np.array_equal(slot_rows[:N], perm.astype(np.uint32)) and (slot_rows[N:N32] == 0xffffffff).all()
     xp = np.zeros((N32, 512), np.float32)
-    xp[:N] = x
+    xp[:N] = x[perm]
     s = np.abs(xp).reshape(nblk, -1).max(axis=1) / np.float32(127.0)
     s[s == 0] = 1.0
     s = s.astype(np.float32)
@@ -556,6 +561,10 @@ def test_quantize_rows_i8_matches_numpy(clipmi, gpu):
     assert (rmeta[:N, 1] >= err[:N]).all() and (rmeta[:N, 1] <= err[:N] * 1.002 + 1e-12).all()
     assert (rmeta[N:, 1] == 0).all() and (rmeta[N32:] == 0).all() and (bmeta[nblk:] == 0).all()
     assert np.array_equal(bmeta[:nblk, 1], rmeta[:N32, 1].reshape(nblk, 32).max(axis=1))
+    # the point of the order: a block's scale is within a few per cent of each of its rows' own
+    own = np.abs(xp[:N]).max(axis=1) / np.float32(127.0)
+    nz = own > 0
+    assert np.median(srow[:N][nz] / own[nz]) < 1.05
     assert amax >= rmeta[:, 1].max() and rmax >= np.linalg.norm(x, axis=1).max()
 
 
