@@ -1,3 +1,6 @@
+"""Is the 12.5 M-row search faster with two calls in flight than with one, and does the answer depend on how many calls are
+timed? (in a fresh process it is, at every length; bench.py's old shard leg lost because its streams shared a
+hardware queue.) usage: python tools/shard_steps.py"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, clipmi
