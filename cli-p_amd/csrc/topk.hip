@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
                                                                  const unsigned* run_if, unsigned* m_out = nullptr,
                                                                  int keep = 0, int stage_cap = -1, float* qmeta = nullptr,
                                                                  int qs = 64, unsigned* live_keys = nullptr,
-                                                                 float* live_edges = nullptr) {
+                                                                 float* live_edges = nullptr, int dense = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (run_if && *run_if == 0) return;
     unsigned long long* red = reinterpret_cast<unsigned long long*>(smem);   // [16] min, [16] max
@@ -412,7 +412,26 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
     const int need = (int)(M < K ? M : K);
     // stage_cap: entries of LDS the launch reserved behind the K-entry result buffer (-1: the most K leaves room for)
     const bool staged = M <= (stage_cap < 0 ? sel_stage_entries(K) : stage_cap);
-    if (staged) {
+    // dense (the wide pass's sample lists: entry e IS row e - sample_scores_kernel writes cand[q][row] = (score, row)): only the
+    // 4 score bytes of an entry are staged, the id is the index - 48 KiB instead of 96 for 12 288 rows, so three select blocks
+    // fit on a CU instead of one (1024 of them per call of 1024 queries: 121 -> ~50 us)
+    unsigned* const l32 = reinterpret_cast<unsigned*>(lent);
+    if (staged && dense) {
+        for (long long e0 = tid; e0 < M; e0 += 4 * SEL_THREADS) {
+            unsigned v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long e = e0 + (long long)j * SEL_THREADS;
+                v[j] = src[e < M ? e : M - 1].x;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long e = e0 + (long long)j * SEL_THREADS;
+                if (e < M) l32[e] = v[j];
+            }
+        }
+        __syncthreads();
+    } else if (staged) {
         for (long long e0 = tid; e0 < M; e0 += 4 * SEL_THREADS) {
             uint2 v[4];
 #pragma unroll
@@ -534,7 +553,8 @@ __global__ void __launch_bounds__(SEL_THREADS) select_topk_kernel(const uint2* _
         if (thr_out && need < K && tid == 0) thr_out[q] = -INFINITY;
         if (qmeta && need < K && tid == 0) qmeta[2 * qs + q] = -INFINITY;
     };
-    if (staged) passes([&](long long e) -> uint2 { return lent[e]; });
+    if (staged && dense) passes([&](long long e) -> uint2 { return make_uint2(l32[e], (unsigned)e); });
+    else if (staged) passes([&](long long e) -> uint2 { return lent[e]; });
     else passes([&](long long e) -> uint2 { return src[e]; });
     if (live_keys) {
         // live-threshold scan (scan_coarse_live_kernel): exact threshold = the sample's K-th best, ladder of LIVE_NB edges
@@ -2513,9 +2533,11 @@ int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta,
             hipLaunchKernelGGL(sample_scores_kernel<512>, dim3((unsigned)gs, (unsigned)ngroups), dim3(256), lds1, st,
                                static_cast<const float*>(db_dev), S1, qg, qc, w.cand_c, (long long)WIDE_CAP, w.gcnt_c);
             CLIPMI_CHECK_LAUNCH("sample_scores_kernel(wide)");
-            hipLaunchKernelGGL(select_topk_kernel, dim3(qc), dim3(SEL_THREADS), p.lds_sel, st, w.cand_c, w.gcnt_c, WIDE_CAP, K,
+            // dense staging (4 bytes per row): S1 <= 12 288 rows always fit; LDS sized for them, not for the generic 8-byte stage
+            const size_t lds_dense = SEL_FIXED + (size_t)K * 8 + (size_t)S1 * 4 + 16;
+            hipLaunchKernelGGL(select_topk_kernel, dim3(qc), dim3(SEL_THREADS), lds_dense, st, w.cand_c, w.gcnt_c, WIDE_CAP, K,
                                (long long)0, (float*)nullptr, (long long*)nullptr, w.thr0, (const unsigned*)nullptr,
-                               (unsigned*)nullptr, 0, p.stage, w.qmeta, qs);
+                               (unsigned*)nullptr, 0, (int)S1, w.qmeta, qs, (unsigned*)nullptr, (float*)nullptr, 1);
             CLIPMI_CHECK_LAUNCH("select_topk_kernel(wide sample)");
         }
         WideArgs c;
