@@ -440,6 +440,16 @@ def search_leg(L, a, dev, dist, world, rank, rows_total, n_local, seed, steps, w
                                    "frac": ops / (ms_call * 1e-3) / 1e12 / (2 * PEAK_BF16_TFLOPS),
                                    "note": "whole call (sample, scans, exact re-scoring, selects) over the scan's operations"}},
             **sp_big)
+        if kind == "int8":
+            # 2 x large_q queries in ONE call = two wide chunks, which IndexFlatIP alternates between two streams
+            qL2 = torch.cat([qL, qL.flip(0)])
+
+            def big2_step():
+                res[0] = searcher.search_device(qL2, K)
+            dt2 = timed(big2_step, 3, 1, dist, world)
+            out["one_call_many_queries"]["one_call_2x"] = {
+                "queries": 2 * large_q, "value": 2 * large_q * 3 / dt2, "unit": "queries/s", "ms_per_call": dt2 / 3 * 1e3, "steps": 3,
+                "note": "two wide chunks of one call, alternating between two streams (IndexFlatIP._search_pipelined)"}
     if large_q > 0:
         sweep = {}
         for Qs in (1, 16):

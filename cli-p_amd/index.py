@@ -203,7 +203,12 @@ class IndexFlatIP:
         # more than 64 queries: the int8 path takes the whole search as wide passes inside the library (one stream of the
         # copy per <= 1024 queries, csrc/topk.hip "Wide coarse pass"); the bf16 path pipelines its 64-query passes here
         if coarse and self.coarse != "int8" and Q > self.PASS_Q and self.batches_in_flight > 1 and not _one_pass:
-            return self._search_pipelined(q, K, out)
+            return self._search_pipelined(q, K, out, self.PASS_Q)
+        # int8, more than one wide chunk (1024 queries): the chunks alternate between two streams the same way - one chunk's
+        # re-scoring and selects run beside the other's matrix-bound scan (10 M rows, 2 x 1024 queries: 6.37 -> 6.07 ms per chunk,
+        # 160.9 -> 168.8 k q/s; a single chunk cut in two halves gains nothing: 162.4 k)
+        if coarse and self.coarse == "int8" and Q > self.WIDE_Q and self.batches_in_flight > 1 and not _one_pass:
+            return self._search_pipelined(q, K, out, self.WIDE_Q)
         need = (L.clipmi_topk_ip_coarse_workspace_bytes if coarse else L.clipmi_topk_ip_workspace_bytes)(N, self.d, Q, K)
         if need == 0:
             raise _lib.ClipmiError("topk_ip: " + _lib.last_error())
@@ -237,10 +242,12 @@ class IndexFlatIP:
         return out_s, out_i
 
     PASS_Q = 64                   # queries of one coarse pass (csrc/topk.hip COARSE_Q)
+    WIDE_Q = 1024                 # queries of one wide pass of the int8 copy (csrc/topk.hip WIDE_MAX_Q)
     batches_in_flight = 2         # 64-query passes of ONE large search kept in flight on internal streams (1 = off)
 
-    def _search_pipelined(self, q, K, out):
-        """A search of more than 64 queries on the coarse path: its 64-query passes alternate between the caller's stream and an
+    def _search_pipelined(self, q, K, out, chunk):
+        """A search of more than 64 queries on the bf16 coarse path (`chunk` = 64), or of more than 1024 on the int8 path (`chunk`
+        = 1024 = one wide pass): its passes alternate between the caller's stream and an
         internal HIP stream (each with its own workspace), so one pass's latency-bound side kernels run beside the other's
         HBM-bound scan -
         what bench.py measures as "two batches in flight" (0.97-1.03 vs 1.09-1.10 ms per pass at 10 M rows). Same calls,
@@ -262,8 +269,8 @@ class IndexFlatIP:
         lanes = [cur] + side
         for s_ in side:
             s_.wait_stream(cur)                       # q, the outputs and the index copies are ready
-        for gi, lo in enumerate(range(0, Q, self.PASS_Q)):
-            hi = min(Q, lo + self.PASS_Q)
+        for gi, lo in enumerate(range(0, Q, chunk)):
+            hi = min(Q, lo + chunk)
             with torch.cuda.stream(lanes[gi % len(lanes)]):
                 self.search_device(q[lo:hi], K, out=(out_s[lo:hi], out_i[lo:hi]), _one_pass=True)
         for s_ in side:

@@ -448,7 +448,7 @@ def test_large_query_batch_is_pipelined_and_exact(clipmi, gpu, topk_oracle, kind
 
 
 @pytest.mark.parametrize("N,Q,K", [(70001, 65, 51), (100000, 256, 51), (131072, 300, 11), (90000, 640, 21), (200003, 1024, 51),
-                                   (66000, 1100, 51)])
+                                   (66000, 1100, 51), (66000, 2200, 21)])
 def test_wide_int8_pass_is_bit_exact(clipmi, gpu, topk_oracle, N, Q, K):
     """More than 64 queries in ONE call (query-index.py:111 is one index.search whatever Q): the int8 path takes them as
     wide passes (csrc/topk.hip scan_coarse_wide_kernel: 1, 2, 3 or 4 query tiles, partial sets, a second chunk past 1024).

@@ -1,4 +1,4 @@
-"""Search leg, one and two calls in flight at Q = 64 (development A/B of env knobs). usage: python tools/search_ab2.py [N]"""
+"""Search leg, one and two calls in flight (development A/B of env knobs). usage: python tools/search_ab2.py [N] [Q]"""
 import sys, os, time
 os.environ.setdefault("CLIPMI_DEV_LIB", "1")   # A/B knobs: development library only
 import torch
@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import clipmi
 dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-K, Q = 51, 64
+K = 51
+Q = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 g = torch.Generator(device=dev); g.manual_seed(1)
 idx = clipmi.IndexFlatIP(512, device=dev, coarse="int8")
 for lo in range(0, N, 1 << 20):
@@ -34,4 +35,4 @@ for nfl in (1, 2):
         for i in range(nfl): call(i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / (20 * nfl)
-    print(f"N={N} Q={Q} in flight {nfl}: {dt * 1e3:.3f} ms per call ({5.2e9 * N / 1e7 / dt / 8e12:.3f} of 8 TB/s)", flush=True)
+    print(f"N={N} Q={Q} in flight {nfl}: {dt * 1e3:.3f} ms per call ({5.2e9 * N / 1e7 / dt / 8e12:.3f} of 8 TB/s; {Q / dt / 1e3:.1f} k q/s)", flush=True)
