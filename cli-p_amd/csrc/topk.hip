@@ -692,7 +692,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // maximum and the block's scale is (almost) each row's own: the error norms a_r - and with them the coarse bound's margin -
 // drop back to the per-row-scale values of round 2 (x 1.265 -> x 1.000 on unit rows; re-scored rows per query 5.8 k -> 5.1 k
 // at 10 M rows). The scans work on slots; slot_rows[t] = the row a slot holds (0xffffffff for the padding slots N .. N32 - 1),
-// stored behind the block meta, is read only for survivors (rescore_pairs_kernel), which leave the lists as row ids.
+// stored behind the block meta, is read only for survivors (rescore_pairs_kernel, rescore_pairs16_kernel), which leave the lists as row ids.
 __global__ void __launch_bounds__(256) quantize_rows_i8_kernel(const float* __restrict__ db, long long N, int E,
                                                                const unsigned* __restrict__ perm,
                                                                signed char* __restrict__ out, float2* __restrict__ meta,
@@ -765,10 +765,14 @@ __global__ void __launch_bounds__(256) quantize_rows_i8_kernel(const float* __re
 // and the query image the scan kernels copy into LDS (entry [(qg*KS + s)*64 + lane] = 16 bytes of query 16 qg + (lane & 15):
 // bf16 k = 32 s + 8 g .. + 7, or int8 k = 64 s + 16 g .. + 15, g = lane >> 4; zero for queries >= QA). Block 0 also clears
 // the call's control words (candidate counters, overflow flag): no memset node.
+// q2 (int8, 64-query passes; round 4): the query as TWO int8 digits, y = t p1 + (t / 254) p2 + f' - the second image sits
+// COARSE_IMG2 entries behind the first and the margin is built from ||f'|| (1 / 254 of ||f||): the query's half of the
+// bound's margin is gone, the scan pays a second MFMA per fragment (it is HBM-latency bound with the matrix pipe 16 % busy).
+constexpr int COARSE_IMG2 = 4 * 8 * 64;          // entries of a full 64-query int8 image (32 KiB)
 template <bool I8>
 __global__ void __launch_bounds__(256) coarse_prep_kernel(const float* __restrict__ q, int E, float rmax, float amax, int QA,
                                                           float* qmeta, uint4* qimage, unsigned* ctl, int nctl, int qs,
-                                                          int wide = 0) {
+                                                          int wide = 0, int q2 = 0) {
     constexpr int KS = 512 / (I8 ? 64 : 32);
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -780,7 +784,10 @@ __global__ void __launch_bounds__(256) coarse_prep_kernel(const float* __restric
     const int widx = ((qi >> 5) * 16 + (lane >> 1)) * 64 + (lane & 1) * 32 + (qi & 31);
     if (qi >= QA) {                                            // padding query of a used query group: zero image
         if (wide) { if (lane < 32) qimage[widx] = make_uint4(0u, 0u, 0u, 0u); }
-        else if (lane < KS * 4) qimage[(qg * KS + (lane >> 2)) * 64 + (lane & 3) * 16 + col] = make_uint4(0u, 0u, 0u, 0u);
+        else if (lane < KS * 4) {
+            qimage[(qg * KS + (lane >> 2)) * 64 + (lane & 3) * 16 + col] = make_uint4(0u, 0u, 0u, 0u);
+            if (I8 && q2) qimage[COARSE_IMG2 + (qg * KS + (lane >> 2)) * 64 + (lane & 3) * 16 + col] = make_uint4(0u, 0u, 0u, 0u);
+        }
         return;
     }
     const float* y = q + (size_t)qi * E;
@@ -790,12 +797,20 @@ __global__ void __launch_bounds__(256) coarse_prep_kernel(const float* __restric
     for (int o = 32; o >= 1; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); ss += __shfl_xor(ss, o); }
     const float t = mx > 0.f ? mx / 127.0f : 1.0f;
     const float inv = I8 ? 1.0f / t : 1.0f;
+    const float t2 = t * (1.0f / 254.0f), inv2 = 1.0f / t2;             // second digit's step (q2)
+    // both digits of component v and what they leave; the query images below use the same expressions
+    auto digits = [&](float v, float& p1, float& p2) -> float {
+        p1 = fminf(fmaxf(rintf(v * inv), -127.f), 127.f);
+        const float r1 = fmaf(-t, p1, v);
+        if (!q2) { p2 = 0.f; return r1; }
+        p2 = fminf(fmaxf(rintf(r1 * inv2), -127.f), 127.f);
+        return fmaf(-t2, p2, r1);
+    };
     float ff = 0.f;
     if (I8) {
         for (int k = lane; k < E; k += 64) {
-            const float v = y[k];
-            const float p = fminf(fmaxf(rintf(v * inv), -127.f), 127.f);     // the query image below uses the same expression
-            const float f = v - t * p;
+            float p1, p2;
+            const float f = digits(y[k], p1, p2);
             ff = fmaf(f, f, ff);
         }
 #pragma unroll
@@ -833,18 +848,22 @@ __global__ void __launch_bounds__(256) coarse_prep_kernel(const float* __restric
         uint4 v;
         if (I8) {
             const float* p = y + 64 * s_ + 16 * g_;
-            unsigned w[4];
+            unsigned w[4], w2[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                unsigned pk = 0;
+                unsigned pk = 0, pk2 = 0;
 #pragma unroll
                 for (int b_ = 0; b_ < 4; ++b_) {
-                    const float pq = fminf(fmaxf(rintf(p[4 * j + b_] * inv), -127.f), 127.f);
-                    pk |= ((unsigned)(int)pq & 0xffu) << (8 * b_);
+                    float p1, p2;
+                    (void)digits(p[4 * j + b_], p1, p2);
+                    pk |= ((unsigned)(int)p1 & 0xffu) << (8 * b_);
+                    pk2 |= ((unsigned)(int)p2 & 0xffu) << (8 * b_);
                 }
                 w[j] = pk;
+                w2[j] = pk2;
             }
             v = make_uint4(w[0], w[1], w[2], w[3]);
+            if (q2) qimage[COARSE_IMG2 + (qg * KS + s_) * 64 + g_ * 16 + col] = make_uint4(w2[0], w2[1], w2[2], w2[3]);
         } else {
             const float* p = y + 32 * s_ + 8 * g_;
             v = make_uint4(pack2_bf16(p[0], p[1]), pack2_bf16(p[2], p[3]), pack2_bf16(p[4], p[5]), pack2_bf16(p[6], p[7]));
@@ -857,6 +876,7 @@ __global__ void __launch_bounds__(256) coarse_prep_kernel(const float* __restric
 // No score has these bits (a NaN score is stored as -inf), so an entry that was re-scored before - the K best a select keeps at
 // the head of the list - is recognised and keeps its row id.
 constexpr unsigned CAND_SLOT = 0xffffffffu;
+constexpr size_t RESCORE16_LDS = 512 * 4 + 4 * 16 * 68 * 4;      // rescore_pairs16_kernel: the query + four waves' tiles of 16 row chunks
 
 struct CoarseArgs {
     const void* dbc;             // coarse copy of the matrix: bf16 [nrows][E] or int8 [nrows][E]
@@ -902,14 +922,17 @@ __device__ __noinline__ void coarse_flush(uint2* list, int* lcnt, unsigned* gcnt
 
 // PREPASS only changes the kernel's NAME (the level-2 pre-pass over S2 rows must not dilute the profiler's
 // per-name average of the main scan).
-template <int E, int QG, bool PREPASS, bool I8>
+// Q2 (int8 only): two query digits (coarse_prep_kernel q2) - 2 QG MFMAs per fragment, D = D1 + D2 / 254.
+template <int E, int QG, bool PREPASS, bool I8, bool Q2 = false>
 __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
+    static_assert(!Q2 || I8, "the second query digit belongs to the int8 copy");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = E / (I8 ? 64 : 32);   // MFMA k-steps per 16-row tile (16 bytes per lane and step either way)
     constexpr int ROWB = I8 ? E : 2 * E;     // bytes per row of the coarse copy
     constexpr int SLOTS = 2 * KS;       // one step = two row tiles (32 rows): SLOTS 16-byte fragments per lane
     constexpr int NIMG = QG * KS * 64;                  // 16-byte entries of one query image
-    constexpr int IMG_BYTES = NIMG * 16;
+    constexpr int ND = Q2 ? 2 : 1;                      // query digits
+    constexpr int IMG_BYTES = ND * NIMG * 16;
     static_assert(COARSE_LIST >= COARSE_FLUSH + 4 * 64, "a block's appends must fit behind a pending flush");
 
     const int tid = threadIdx.x;
@@ -930,6 +953,13 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (base + j * 256 < NIMG) qimg[base + j * 256] = v[j];
+            if constexpr (Q2) {                                  // the second digit's image, NIMG entries behind the first in LDS
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = base + j * 256 < NIMG ? a.qimage[COARSE_IMG2 + base + j * 256] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (base + j * 256 < NIMG) qimg[NIMG + base + j * 256] = v[j];
+            }
         }
     }
     uint2* list = reinterpret_cast<uint2*>(smem + IMG_BYTES + (size_t)wave * COARSE_WAVE_BYTES);
@@ -997,21 +1027,23 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
             uint4 MN[4] = {};
             load_meta(has_next ? nxt : step, MN);
 
-            AccT acc[2][QG];
+            AccT acc[2][ND * QG];                       // [rt][digit * QG + qg]
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int qg = 0; qg < QG; ++qg) acc[rt][qg] = AccT{0, 0, 0, 0};
+                for (int qg = 0; qg < ND * QG; ++qg) acc[rt][qg] = AccT{0, 0, 0, 0};
             // One slot at a time: the LDS reads of the NEXT slot's query fragments, this slot's MFMAs, then the refill of
             // this slot's register with the next step's fragment. A load can only be issued once the MFMAs reading its
             // register have been, and its data is needed one step later, so a step lasts (HBM latency + the MFMA time
             // between two refills): refilling after every slot instead of every 8 (the first version) keeps that second
             // term at QG MFMAs - main scan 629-648 -> 619 us at 10 M rows. The sched_group_barriers state the order; no
             // fake dependency on the accumulators is needed.
-            uint4 B[2][QG];
+            uint4 B[2][ND * QG];
             auto load_b = [&](int s_, uint4* b) {
 #pragma unroll
-                for (int qg = 0; qg < QG; ++qg) b[qg] = qimg[(qg * KS + s_) * 64 + lane];
+                for (int d = 0; d < ND; ++d)
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg) b[d * QG + qg] = qimg[d * NIMG + (qg * KS + s_) * 64 + lane];
             };
             __builtin_amdgcn_sched_barrier(0);
             load_b(0, B[0]);
@@ -1024,7 +1056,7 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
                 if (slot + 1 < SLOTS) load_b((slot + 1) % KS, B[(slot + 1) & 1]);
                 const uint4* b = B[slot & 1];
 #pragma unroll
-                for (int qg = 0; qg < QG; ++qg) {
+                for (int qg = 0; qg < ND * QG; ++qg) {
                     if constexpr (I8)
                         acc[rt][qg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, T[slot]),
                                                                             __builtin_bit_cast(i32x4, b[qg]), acc[rt][qg], 0, 0, 0);
@@ -1034,7 +1066,7 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
                 }
                 T[slot] = *reinterpret_cast<const uint4*>(pn[rt] + KSTRIDE * (slot % KS));
             }
-            constexpr int NBQ = QG;
+            constexpr int NBQ = ND * QG;
             __builtin_amdgcn_sched_group_barrier(0x100, NBQ, 0);               // slot 0's fragments
 #pragma unroll
             for (int slot = 0; slot < SLOTS; ++slot) {
@@ -1055,8 +1087,11 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
 #pragma unroll
                 for (int qg = 0; qg < QG; ++qg)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        val[rt][qg][r] = I8 ? fmaf((float)acc[rt][qg][r], sr[r], ar[r] * yt[qg]) : (float)acc[rt][qg][r];
+                    for (int r = 0; r < 4; ++r) {
+                        float d = (float)acc[rt][qg][r];
+                        if constexpr (Q2) d = fmaf((float)acc[rt][QG + qg][r], 1.0f / 254.0f, d);
+                        val[rt][qg][r] = I8 ? fmaf(d, sr[r], ar[r] * yt[qg]) : d;
+                    }
             }
             bool any = false;
 #pragma unroll
@@ -1114,12 +1149,81 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
     }
 }
 
-// Exact f32 re-scoring of the coarse survivors. Each lane owns one (query, candidate) pair and runs the
-// SAME fmaf chain as the MFMA scan (t, c, g order), so the score bits equal the exact kernel's and the
-// oracle's. The rows are fetched COOPERATIVELY: a wave takes 64 candidates and walks their rows in
-// 256-byte chunks, 4 rows x 256 B contiguous per wave-instruction (16 in flight per chunk), through a
-// padded per-wave LDS tile from which every lane then reads its own row's chunk (a first version with
-// one thread fetching its own 2-KB row took ~1 ms for 175 k pairs: 4 uncoalesced loads in flight).
+// Exact f32 re-scoring of the coarse survivors: (exact score bits, row id) for every entry of the candidate lists. A lane that
+// owns a (query, row) pair runs the SAME fmaf chain as the MFMA scan (t, c, g order) - one serial chain over the row's 512
+// components, so the score bits equal the exact kernel's and the oracle's; that chain is why a row cannot be split over lanes and
+// the rows go through a per-wave LDS tile: fetched COOPERATIVELY (4 rows x 256 B contiguous per wave-instruction), read back by
+// the owning lane. (A first version with one thread fetching its own 2-KB row: ~1 ms for 175 k pairs, 4 uncoalesced loads in flight.)
+//
+// Two forms. rescore_pairs16_kernel (round 4, the wide passes' lists: up to 1 024 queries x ~500 pairs): a wave takes SIXTEEN pairs
+// and issues all 32 loads of their whole rows (32 KB in flight per wave) before it touches the first chunk - one HBM round trip
+// per batch, 19 KB of LDS per block, three waves per SIMD; the compute runs on lanes 0-15's rows four times over (lanes l and
+// l + 16 k read the same LDS words: broadcasts), 4 x the issue slots per pair and still far below the gathers' time. One call of
+// 1 024 queries at 10 M rows: 6.26 -> 6.08-6.12 ms (same box). rescore_pairs_kernel (below): 64 pairs per wave in 8 chunks, kept
+// for the 64-query passes, where the two gather at the same rate and this one costs the other call in flight less.
+template <int E>
+__global__ void __launch_bounds__(256) rescore_pairs16_kernel(const float* __restrict__ db, const float* __restrict__ q,
+                                                            uint2* cand, const unsigned* __restrict__ gcnt, long long cap,
+                                                            const unsigned* __restrict__ slot_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RS = 68;                                  // floats per staged row chunk (64 + 4 pad: conflict-free b128 reads)
+    constexpr int NCH = E / 64;                             // 256-byte chunks per row
+    float* qs = reinterpret_cast<float*>(smem);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* st = qs + E + wave * 16 * RS;
+    const int qi = blockIdx.y;
+    for (int k = threadIdx.x; k < E; k += 256) qs[k] = q[(size_t)qi * E + k];
+    __syncthreads();
+    long long M = gcnt[qi];
+    if (M > cap) M = cap;
+    uint2* lst = cand + (size_t)qi * cap;
+    const int r16 = lane & 15, j4 = lane >> 4;
+    for (long long base = ((long long)blockIdx.x * 4 + wave) * 16; base < M; base += (long long)gridDim.x * 4 * 16) {
+        const long long my = base + r16;
+        const uint2 ent = lst[my < M ? my : M - 1];
+        // a fresh survivor names a SLOT of the (permuted) int8 copy: its row id comes from slot_rows (one more dependent read,
+        // for survivors only); entries kept from earlier segments are row ids already
+        const unsigned id_my = (ent.x == CAND_SLOT && slot_rows) ? slot_rows[ent.y] : ent.y;
+        f32x4 nx[4][NCH];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned rid = __shfl(id_my, 4 * i + j4);
+            const float* rowp = db + (size_t)rid * E + r16 * 4;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) nx[i][c] = *reinterpret_cast<const f32x4*>(rowp + c * 64);
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int chunk = 0; chunk < NCH; ++chunk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(st + (4 * i + j4) * RS + r16 * 4) = nx[i][chunk];
+            wave_lds_sync();
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                f32x4 v[4];
+#pragma unroll
+                for (int g_ = 0; g_ < 4; ++g_) v[g_] = *reinterpret_cast<const f32x4*>(st + r16 * RS + 16 * tt + 4 * g_);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g_ = 0; g_ < 4; ++g_)
+                        acc = __builtin_fmaf(v[g_][c], qs[64 * chunk + 16 * tt + 4 * g_ + c], acc);
+                // pin the chain here: with the chunk loop unrolled the compiler sinks all 512 fmaf below the last chunk (acc
+                // is only used at the end) and keeps every chunk's LDS reads alive - 512 registers + 550 spilled to scratch
+                asm volatile("" : "+v"(acc) :: "memory");
+            }
+            wave_lds_sync();
+        }
+        if (j4 == 0 && my < M) lst[my] = make_uint2(__float_as_uint(acc == acc ? acc : -INFINITY), id_my);      // NaN never ranks
+    }
+}
+
+// The 64-query passes' form (rounds 2-3): 64 pairs per wave, 8 chunks of 16 loads with one chunk of prefetch. Same-box A/B
+// (CLIPMI_RESCORE=16 / 64, development library; profiles/r04_search_rescore_ab.txt): its lists (2 500 / 1 500 / 700 pairs per
+// query) are gathered at the same ~5 TB/s by either form - 58.6 / 41.6 / 29.3 us against 58.1 / 47.8 / 27.2 at 10 M rows - and
+// with two calls in flight this one disturbs the other call's streaming scan less (0.976 against 1.005 ms per call).
+constexpr size_t RESCORE_LDS = 512 * 4 + 4 * 64 * 68 * 4;
 template <int E>
 __global__ void __launch_bounds__(256) rescore_pairs_kernel(const float* __restrict__ db, const float* __restrict__ q,
                                                             uint2* cand, const unsigned* __restrict__ gcnt, long long cap,
@@ -2141,12 +2245,12 @@ constexpr int COARSE_Q = 64;                     // queries per coarse pass. (12
                                                  // leaves LDS for only 2 waves per CU = 2 of 4 SIMDs, and the pass turns
                                                  // MFMA-bound: 5.29 ms per 128 queries vs 2 x 2.21 ms)
 
-template <int QG, bool PREPASS, bool I8>
+template <int QG, bool PREPASS, bool I8, bool Q2 = false>
 int launch_coarse(const CoarseArgs& a, long long nsteps, hipStream_t st, hipEvent_t* ev) {
     static_assert(QG <= 4, "64 queries per pass at most");
     constexpr int WAVES = 4;
     // the final publication reuses the head of the query image for 3 * 16 QG counters: keep >= 1 KiB
-    size_t lds = (size_t)QG * (512 / (I8 ? 64 : 32)) * 1024 + WAVES * COARSE_WAVE_BYTES;
+    size_t lds = (size_t)(Q2 ? 2 : 1) * QG * (512 / (I8 ? 64 : 32)) * 1024 + WAVES * COARSE_WAVE_BYTES;
     // The LAST segment's scan (3/4 of the rows) reserves COARSE_MAIN_LDS although it uses 56-88 KiB: with two batches in
     // flight on two streams, two such scans then cannot share a CU. Sharing halves each one's bandwidth, both finish
     // together and both batches run their latency-bound side kernels at the same time with HBM idle (1.06-1.08 ms per 64
@@ -2155,11 +2259,11 @@ int launch_coarse(const CoarseArgs& a, long long nsteps, hipStream_t st, hipEven
     // batch takes 0.97-1.00 ms. (Padding every scan, i.e. the 114 KiB all of them used to need: 1.02-1.04 ms.)
     if (!PREPASS && lds < (size_t)COARSE_MAIN_LDS) lds = COARSE_MAIN_LDS;
     if (lds > (size_t)LDS_LIMIT) return set_err(CLIPMI_EUNSUPPORTED, "scan_coarse: %zu B of LDS", lds);
-    if (int rc = opt_in_lds((const void*)scan_coarse_kernel<512, QG, PREPASS, I8>, lds)) return rc;
+    if (int rc = opt_in_lds((const void*)scan_coarse_kernel<512, QG, PREPASS, I8, Q2>, lds)) return rc;
     long long g_ = (nsteps + WAVES - 1) / WAVES;
     const int grid = (int)(g_ < NUM_CU ? g_ : NUM_CU);
     if (ev) (void)hipEventRecord(ev[0], st);
-    hipLaunchKernelGGL((scan_coarse_kernel<512, QG, PREPASS, I8>), dim3(grid), dim3(WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((scan_coarse_kernel<512, QG, PREPASS, I8, Q2>), dim3(grid), dim3(WAVES * 64), lds, st, a);
     if (ev) (void)hipEventRecord(ev[1], st);
     CLIPMI_CHECK_LAUNCH("scan_coarse_kernel");
     return 0;
@@ -2198,6 +2302,23 @@ size_t carve_coarse(const Plan& p, void* base, size_t cap, CoarseWs* w) {
     return ar.off + 256;
 }
 
+inline int opt_in_rescore() {
+    if (int rc = opt_in_lds((const void*)rescore_pairs_kernel<512>, RESCORE_LDS)) return rc;
+    return opt_in_lds((const void*)rescore_pairs16_kernel<512>, RESCORE16_LDS);
+}
+
+// wide: the lists of a wide pass (up to 1 024 queries x ~500 pairs) go to the 16-pair form, the 64-query passes' to the 64-pair one
+inline void launch_rescore(bool wide, dim3 grid, hipStream_t st, const float* db, const float* q, uint2* cand, const unsigned* gcnt,
+                           long long cap, const unsigned* slot_rows) {
+#ifdef CLIPMI_DEV
+    static const int form = (int)dev_knob("CLIPMI_RESCORE", 0);            // 16 / 64: force one form (A/B)
+    if (form == 16) wide = true;
+    if (form == 64) wide = false;
+#endif
+    if (wide) hipLaunchKernelGGL(rescore_pairs16_kernel<512>, grid, dim3(256), RESCORE16_LDS, st, db, q, cand, gcnt, cap, slot_rows);
+    else hipLaunchKernelGGL(rescore_pairs_kernel<512>, grid, dim3(256), RESCORE_LDS, st, db, q, cand, gcnt, cap, slot_rows);
+}
+
 // i8 = false: dbh_dev is the bf16 copy (rmeta, amax unused); i8 = true: dbh_dev is the int8 copy, rmeta its per-row
 // (scale, error norm) pairs padded to a multiple of 32 rows, amax >= every error norm
 int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const float2* rmeta, float amax, int64_t N, int E,
@@ -2217,7 +2338,7 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
     carve_coarse(p, ws_dev, ws_bytes, &w);
     hipStream_t st = as_stream(stream);
     if (int rc = opt_in_lds((const void*)select_topk_kernel, p.lds_sel)) return rc;
-    if (int rc = opt_in_lds((const void*)rescore_pairs_kernel<512>, 512 * 4 + 4 * 64 * 68 * 4)) return rc;
+    if (int rc = opt_in_rescore()) return rc;
     // int8: the rows the copy's slots hold, behind the block meta (quantize_rows_i8_kernel); bf16 copy: rows in order
     const unsigned* slot_rows = i8 ? i8_slot_rows(rmeta, N) : nullptr;
     // int8 copy, shards below 2^26 rows: the live-threshold scan - EXPERIMENTAL, off unless CLIPMI_LIVE=1. Bit-exact, ONE scan
@@ -2227,8 +2348,13 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
 #ifdef CLIPMI_DEV
     static const bool live_on = dev_knob("CLIPMI_LIVE", 0) == 1;
     const bool live = i8 && live_on && N < (1ll << LIVE_ROW_BITS);
+    // CLIPMI_COARSE_Q2=1: the query as TWO int8 digits (coarse_prep_kernel q2): -42 % coarse survivors, but the scan's second
+    // MFMA per fragment costs more than the re-scoring it saves - measured, development library only
+    static const bool q2_on = dev_knob("CLIPMI_COARSE_Q2", 0) != 0;
+    const bool q2 = i8 && q2_on && !live;
 #else
     constexpr bool live = false;
+    constexpr bool q2 = false;
 #endif
 
     for (int q0 = 0; q0 < Q; q0 += COARSE_Q) {
@@ -2240,7 +2366,7 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             const int nq = (qa + 15) / 16 * 16;
             if (i8)
                 hipLaunchKernelGGL(coarse_prep_kernel<true>, dim3(nq / 4), dim3(256), 0, st, qg, E, rmax, amax, qa, w.qmeta, w.qimage,
-                                   w.gcnt_e, COARSE_CTL, COARSE_QS);
+                                   w.gcnt_e, COARSE_CTL, COARSE_QS, 0, q2 ? 1 : 0);
             else
                 hipLaunchKernelGGL(coarse_prep_kernel<false>, dim3(nq / 4), dim3(256), 0, st, qg, E, rmax, amax, qa, w.qmeta, w.qimage,
                                    w.gcnt_e, COARSE_CTL, COARSE_QS);
@@ -2279,6 +2405,13 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
             c.nrows = r1 - r0;
             const long long nsteps = (c.nrows + 31) / 32;
             int rc_;
+#ifdef CLIPMI_DEV
+            if (i8 && q2)
+                rc_ = qa <= 16 ? (pre ? launch_coarse<1, true, true, true>(c, nsteps, st, ev) : launch_coarse<1, false, true, true>(c, nsteps, st, ev))
+                    : qa <= 32 ? (pre ? launch_coarse<2, true, true, true>(c, nsteps, st, ev) : launch_coarse<2, false, true, true>(c, nsteps, st, ev))
+                               : (pre ? launch_coarse<4, true, true, true>(c, nsteps, st, ev) : launch_coarse<4, false, true, true>(c, nsteps, st, ev));
+            else
+#endif
             if (i8)
                 rc_ = qa <= 16 ? (pre ? launch_coarse<1, true, true>(c, nsteps, st, ev) : launch_coarse<1, false, true>(c, nsteps, st, ev))
                     : qa <= 32 ? (pre ? launch_coarse<2, true, true>(c, nsteps, st, ev) : launch_coarse<2, false, true>(c, nsteps, st, ev))
@@ -2289,8 +2422,7 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
                                : (pre ? launch_coarse<4, true, false>(c, nsteps, st, ev) : launch_coarse<4, false, false>(c, nsteps, st, ev));
             if (rc_) return rc_;
             // ~1-3 k survivors per query = ~11 blocks of 256 pairs; a larger grid only queues idle blocks
-            hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(12, qa), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
-                               static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, COARSE_CAP, slot_rows);
+            launch_rescore(false, dim3(12, qa), st, static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, COARSE_CAP, slot_rows);
             CLIPMI_CHECK_LAUNCH("rescore_pairs_kernel");
             // 4096 staged entries (32 KiB of LDS) cover these lists; a select block then fits on a CU even beside the
             // last segment's scan of ANOTHER batch in flight (104 KiB), which the 96-KiB staging of the sample select does not
@@ -2502,7 +2634,7 @@ int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta,
     hipStream_t st = as_stream(stream);
     const unsigned* slot_rows = i8_slot_rows(rmeta, N);
     if (int rc = opt_in_lds((const void*)select_topk_kernel, p.lds_sel)) return rc;
-    if (int rc = opt_in_lds((const void*)rescore_pairs_kernel<512>, 512 * 4 + 4 * 64 * 68 * 4)) return rc;
+    if (int rc = opt_in_rescore()) return rc;
     const size_t lds1 = (size_t)(512 / 16) * 1024;
     if (int rc = opt_in_lds((const void*)sample_scores_kernel<512>, lds1)) return rc;
     int ev_used = 0;
@@ -2571,9 +2703,8 @@ int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta,
             if (int rc = launch_wide_t<8>(c, st, ev)) return rc;
 #endif
             if (ev) ev_used += 2;
-            hipLaunchKernelGGL(rescore_pairs_kernel<512>, dim3(12, qc), dim3(256), 512 * 4 + 4 * 64 * 68 * 4, st,
-                               static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, WIDE_CAP, slot_rows);
-            CLIPMI_CHECK_LAUNCH("rescore_pairs_kernel(wide)");
+            launch_rescore(true, dim3(12, qc), st, static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, WIDE_CAP, slot_rows);
+            CLIPMI_CHECK_LAUNCH("rescore_pairs16_kernel(wide)");
             // keep: bit 0 = the K best stay at the head of the list for the next segment; bit 1 = add to the survivor count
             const int keep = (last ? 0 : 1) | (sgi > 0 ? 2 : 0);
             hipLaunchKernelGGL(select_topk_kernel, dim3(qc), dim3(SEL_THREADS), SEL_FIXED + (size_t)K * 8 + (size_t)scap * 8, st,

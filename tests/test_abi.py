@@ -38,9 +38,12 @@ def test_product_library_reads_no_environment_and_ships_no_lab_kernels(clipmi):
     assert "getenv" not in undefined
     blob = open(lib, "rb").read()
     assert b"scan_coarse_live_kernel" not in blob and b"gemm2w_resid_ln_kernel" not in blob
+    two_digit_scan = b"scan_coarse_kernelILi512ELi4ELb0ELb1ELb1E"        # <512, 4, false, int8, two query digits>: DESIGN 4.1h
+    assert two_digit_scan not in blob
     assert os.path.exists(dev), "build() also builds libclipmi_dev.so"
     assert "getenv" in subprocess.check_output(["nm", "-D", "--undefined-only", dev], text=True)
-    assert b"scan_coarse_live_kernel" in open(dev, "rb").read()
+    dblob = open(dev, "rb").read()
+    assert b"scan_coarse_live_kernel" in dblob and two_digit_scan in dblob
 
 
 def test_tower_struct_matches_header(clipmi, tmp_path):

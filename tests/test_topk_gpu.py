@@ -695,3 +695,19 @@ def test_live_threshold_scan_is_bit_exact_when_enabled():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.count("exact: True") == 3 and "exact: False" not in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_two_digit_query_scan_and_both_rescoring_forms_are_bit_exact():
+    """Development-library variants that the product does not select for every shape: the 64-query scan with the
+    query as two int8 digits (CLIPMI_COARSE_Q2=1: a tighter margin, the same exact results) and each exact re-scoring form forced
+    onto all lists (CLIPMI_RESCORE=16 / 64). Knobs are read once per process: child processes, tools/live_check.py with the live
+    scan off."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for knobs in ({"CLIPMI_COARSE_Q2": "1"}, {"CLIPMI_RESCORE": "16"}, {"CLIPMI_RESCORE": "64"}):
+        env = dict(os.environ, CLIPMI_LIVE="0", CLIPMI_DEV_LIB="1", **knobs)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "live_check.py"), "300000", "1,33,64,200"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.count("exact: True") == 4 and "exact: False" not in r.stdout, (knobs, r.stdout)
