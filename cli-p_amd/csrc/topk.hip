@@ -1939,7 +1939,10 @@ __global__ void __launch_bounds__(WAVES * 64) scan_coarse_wide_kernel(WideArgs a
         // Returns false after the wave's last block.
         const int ng = 2 * nsets;
         const int pf_g = (qt == 0 || a.pf_mode == 1) ? 0 : a.pf_mode == 2 ? ng - 2 : a.pf_mode == 3 ? qt * ng / a.nqt : ng / 2;
-        constexpr int BR = 4;                                  // ring of query fragments: LDS reads run BR MFMAs ahead
+#ifndef CLIPMI_WIDE_BR
+#define CLIPMI_WIDE_BR 4
+#endif
+        constexpr int BR = CLIPMI_WIDE_BR;                     // ring of query fragments: LDS reads run BR MFMAs ahead
         auto run_block = [&](uint4 (&T)[KS], uint4 (&TN)[KS]) -> bool {
             const int nxt = __builtin_amdgcn_readfirstlane(blk + tw);
             const bool has_next = nxt < nblk;
@@ -2579,6 +2582,210 @@ int wide_waves() {
     return w;
 }
 
+// =================================================================================================
+// Wide pass, second form (more than 512 queries): QUERIES IN REGISTERS, ROWS THROUGH AN LDS RING.
+//
+// scan_coarse_wide_kernel keeps a 256-query tile's image in LDS and the rows in registers: one KiB of LDS per MFMA, the rows'
+// fragments twice over (this block + the next) in 128 registers, 256 registers with spills - no room for a deeper fragment ring,
+// and four workgroups fetch every block. Here a wave owns TWO 32-query groups for the whole launch (their B fragments: 128
+// registers), a workgroup's 8 waves = a tile of 512 queries, and the 32-row blocks arrive by LDS-DMA in a ring of W2_NB 16-KiB
+// slots (the copy's block layout IS the MFMA register image, so the DMA deposits fragments as they are read): every row
+// fragment read from LDS feeds two MFMAs (half a KiB per MFMA), and two workgroups fetch a block instead of four. All waves
+// walk the same blocks; one barrier per block publishes the slot that landed and frees the one that was read.
+// The compare (integer pre-test per lane, per-row test and ballot appends behind it) is scan_coarse_wide_kernel's.
+// =================================================================================================
+constexpr int W2_NB = 4;                          // ring slots
+constexpr int W2_TILE_Q = 512;                    // queries per workgroup: 8 waves x 2 groups x 32
+constexpr int W2_SLOT = 16384 + 256;              // a ring slot: 16 KiB of fragments + the block's meta
+
+template <int N_>
+__device__ __forceinline__ void w2_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+template <int NB>
+__global__ void __launch_bounds__(512) scan_coarse_wide2_kernel(WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, h = lane >> 5;
+    // workgroup -> (query tile, row lane): blocks b, b + 8, ... share an XCD; the tiles of a row lane are such neighbours
+    const int ntile = (a.Q + W2_TILE_Q - 1) / W2_TILE_Q;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, jb = gridDim.x >> 3;
+    const int rlx = jb / ntile;
+    if (j >= rlx * ntile) return;
+    const int qt = j % ntile, nrl = __builtin_amdgcn_readfirstlane(rlx * 8);
+    const int rl = (j / ntile) * 8 + x;
+    const int qbase = qt * W2_TILE_Q;
+    char* ring = smem;                                            // NB slots of 16 KiB of fragments + 256 B of block meta
+    uint2* list = reinterpret_cast<uint2*>(smem + (size_t)NB * W2_SLOT + (size_t)wave * WIDE_WAVE_BYTES);
+
+    // this wave's two query groups: fragments (the wide image of coarse_prep_kernel: entry [(G 16 + s) 64 + lane]) and per-lane
+    // thresholds - constant over the launch
+    uint4 Bq[2][KS];
+    float tq[2], yq[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int G = qt * (W2_TILE_Q / 32) + 2 * wave + g;
+        const bool has_img = G * 32 < a.qs;                         // the image covers qs (a multiple of 64) queries
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_)
+            Bq[g][s_] = has_img ? a.qimage[((size_t)G * KS + s_) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
+        const int qi = G * 32 + n;
+        const bool act = qi < a.Q;
+        tq[g] = act ? a.qmeta[2 * a.qs + qi] : INFINITY;
+        yq[g] = act ? a.qmeta[a.qs + qi] : 0.f;
+    }
+
+    const int blk0 = (int)(a.row0 >> 5);
+    const int nblk = blk0 + (int)((a.nrows + 31) >> 5);
+    const unsigned last_row32 = (unsigned)(a.row0 + a.nrows - 1);
+    const int first = __builtin_amdgcn_readfirstlane(blk0 + rl);
+    const int nk = first < nblk ? (nblk - first + nrl - 1) / nrl : 0;       // blocks of this row lane (the same for all 8 waves)
+    int npend = 0;
+    if (nk > 0) {
+        // block k of the row lane -> ring slot k % NB; this wave moves k-steps 2 wave, 2 wave + 1 of it (2 x 1 KiB). Past the
+        // last block the last one is fetched again (into a slot nobody reads): the counted waits below stay valid to the end.
+        // (buffer loads: scalar resource rebased per block, ONE long-lived lane-offset register - per-lane 64-bit addresses were
+        //  recycled as fragment registers and the compiler then waited vmcnt(0) for the DMA before the first LDS read)
+        const unsigned lane16 = (unsigned)lane * 16u, lane4 = (unsigned)lane * 4u;
+        auto issue = [&](int k) {
+            const int b_ = __builtin_amdgcn_readfirstlane(first + (k < nk ? k : nk - 1) * nrl);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<signed char*>(a.dbc) + (size_t)b_ * (32 * 512), 0, 32 * 512, 0x00020000);
+            char* dst = ring + (size_t)(k & (NB - 1)) * W2_SLOT + (size_t)(2 * wave) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) char*)dst, 16, lane16, (2 * wave) * 1024, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) char*)(dst + 1024), 16, lane16,
+                                                     (2 * wave + 1) * 1024, 0, 0);
+            // the block's (scale, largest error norm) travels with it: 8 bytes through a buffer of 8 (lanes 2.. read past it: zeros),
+            // every wave writes the same words - a third DMA per block and wave keeps the counted waits uniform. (A scalar load
+            // returns out of order on lgkmcnt, a vector load shares vmcnt with the DMA and the compiler waits vmcnt(0) for it.)
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float2*>(a.bmeta) + b_, 0, 8, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (__attribute__((address_space(3))) char*)(ring + (size_t)(k & (NB - 1)) * W2_SLOT + 16384),
+                                                     4, lane4, 0, 0, 0);
+        };
+#pragma unroll
+        for (int k = 0; k < NB - 1; ++k) issue(k);
+        const unsigned ring_a = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring + lane16;
+        const unsigned list_a = (unsigned)(size_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(list);
+        // The compare of scan_coarse_wide_kernel (see there): an integer pre-test per lane (= query), the per-row test and the
+        // ballot appends only behind it. It follows the block's MFMAs; waves 4-7 run HALF A BLOCK behind waves 0-3 (their barrier
+        // sits at the end of a block instead of its middle), so on every SIMD one wave's compare runs under its partner's MFMAs.
+        auto pretest = [&](const i32x16& acc, float tq_, float yq_, float2 bm_) -> bool {
+            float xq = fmaf(-bm_.y, yq_, tq_) * __builtin_amdgcn_rcpf(bm_.x);      // 1 ulp: far inside the slack below
+            xq = fminf(fmaxf(xq, -1.0e9f), 1.0e9f);
+            xq = xq - 2.0f - fabsf(xq) * 2e-6f;
+            const int dmin = (int)floorf(xq);
+            auto max3 = [](int a_, int b_, int c_) { const int m_ = a_ > b_ ? a_ : b_; return m_ > c_ ? m_ : c_; };
+            const int m0 = max3(acc[0], acc[1], acc[2]), m1 = max3(acc[3], acc[4], acc[5]), m2 = max3(acc[6], acc[7], acc[8]);
+            const int m3 = max3(acc[9], acc[10], acc[11]), m4 = max3(acc[12], acc[13], acc[14]);
+            const int ma = max3(m0, m1, m2), mb = max3(m3, m4, acc[15]);
+            return ((ma > mb ? ma : mb) >= dmin) & (tq_ != INFINITY);      // +inf (padding query): never; no branch in the MFMA stream
+        };
+        // (list entries are written by inline asm: a compiler-visible LDS store would wait vmcnt(0) for the DMA in flight)
+        auto append = [&](const i32x16& acc, int g, float tq_, float yq_, int blk_, float2 bm_) {
+            const unsigned rbase = (unsigned)blk_ * 32u + 4u * (unsigned)h;
+            const float ay = bm_.y * yq_;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const unsigned row = rbase + (unsigned)((i & 3) + 8 * (i >> 2));
+                const float val = fmaf((float)acc[i], bm_.x, ay);
+                const bool pass = (val >= tq_) && (row <= last_row32);
+                const unsigned long long m = __ballot(pass);
+                if (m) {
+                    const int pos = npend + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (pass) {
+                        const uint2 ent = make_uint2((unsigned)((2 * wave + g) * 32 + n), row);
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(list_a + (unsigned)pos * 8u), "v"(ent) : "memory");
+                    }
+                    npend += __builtin_popcountll(m);
+                }
+                if ((i & 3) == 3 && npend > WIDE_FLUSH) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    wide_flush(list, npend, qbase, a.gcnt, a.cand, a.cap, a.overflow);
+                    npend = 0;
+                }
+            }
+        };
+        // The fragment ring never drains: the reads behind k-steps 12-15 of block k fetch k-steps 0-3 of block k + 1. Barrier b
+        // publishes block b + 1 (everyone's pieces have landed) and frees block b - 1's slot for block b + NB - 1; waves 0-3 reach
+        // it in the MIDDLE of block b, waves 4-7 at the END of block b - 1 (before block 0 for b = 0): same count, half a block apart.
+        // lgkmcnt by hand: LDS operations complete in order, 4 fragment reads are in flight before every k-step, so lgkmcnt(3)
+        // retires the oldest; anything younger in between (the meta read, an append's list writes) only makes a wait retire more.
+        const bool late = wave >= 4;
+        i32x4 A[4];
+        auto frag = [&](int k, int s_) -> unsigned { return ring_a + (unsigned)(k & (NB - 1)) * (unsigned)W2_SLOT + (unsigned)s_ * 1024u; };
+        auto ring_barrier = [&](int b_) {
+            // my pieces of block b + 1 have landed (NB - 3 younger blocks may be in flight)
+            w2_wait_vmcnt<3 * (NB - 3)>();
+            __builtin_amdgcn_s_barrier();
+            issue(b_ + NB - 1);
+        };
+        // block 0: my pieces landed (NB - 2 younger blocks may be in flight), then everyone's
+        w2_wait_vmcnt<3 * (NB - 2)>();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) asm volatile("ds_read_b128 %0, %1" : "=v"(A[p_]) : "v"(frag(0, p_)));
+        if (late) ring_barrier(0);
+        for (int k = 0; k < nk; ++k) {
+            const int blk = __builtin_amdgcn_readfirstlane(first + k * nrl);
+            i32x16 acc0, acc1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc0[i] = 0; acc1[i] = 0; }
+            uint2 pm = make_uint2(0u, 0u);                    // the block's meta, read from its slot behind k-step 0
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {
+                // (k-step 4's wait also retires the meta read: it is older than the fragment of k-step 5)
+                if (s_ == 4) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(A[s_ & 3]), "+v"(pm));
+                else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(A[s_ & 3]));
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[s_ & 3], __builtin_bit_cast(i32x4, Bq[0][s_]), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[s_ & 3], __builtin_bit_cast(i32x4, Bq[1][s_]), acc1, 0, 0, 0);
+                if (s_ == KS / 2 - 1 && !late) ring_barrier(k);
+                if (s_ == KS - 1 && late && k + 1 < nk) ring_barrier(k + 1);
+                // the refill may not overtake the two MFMAs that read the register: tie it to their results
+                const unsigned fa = s_ + 4 < KS ? frag(k, s_ + 4) : frag(k + 1, s_ + 4 - KS);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(A[s_ & 3]) : "v"(fa), "v"(acc0), "v"(acc1));
+                if (s_ == 0)
+                    asm volatile("ds_read_b64 %0, %1" : "=v"(pm) : "v"(ring_a - lane16 + (unsigned)(k & (NB - 1)) * (unsigned)W2_SLOT + 16384u));
+            }
+            const float2 bm = make_float2(__uint_as_float(pm.x), __uint_as_float(pm.y));
+            if (__ballot(pretest(acc0, tq[0], yq[0], bm))) append(acc0, 0, tq[0], yq[0], blk, bm);
+            if (__ballot(pretest(acc1, tq[1], yq[1], bm))) append(acc1, 1, tq[1], yq[1], blk, bm);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        w2_wait_vmcnt<0>();                                   // the re-fetched tail blocks: nothing may land after the ring is reused
+    }
+    // final publication, aggregated per workgroup (one returning global atomic per (workgroup, query))
+    __syncthreads();
+    unsigned* hist = reinterpret_cast<unsigned*>(smem);              // the ring is dead now
+    unsigned* gbase = hist + W2_TILE_Q;
+    unsigned* hoff = hist + 2 * W2_TILE_Q;
+    for (int i = tid; i < W2_TILE_Q; i += 512) { hist[i] = 0; hoff[i] = 0; }
+    __syncthreads();
+    for (int e = lane; e < npend; e += 64) atomicAdd(&hist[list[e].x], 1u);
+    __syncthreads();
+    for (int i = tid; i < W2_TILE_Q; i += 512) gbase[i] = hist[i] ? atomicAdd(&a.gcnt[qbase + i], hist[i]) : 0u;
+    __syncthreads();
+    for (int e = lane; e < npend; e += 64) {
+        const uint2 c = list[e];
+        const unsigned pos = gbase[c.x] + atomicAdd(&hoff[c.x], 1u);
+        if ((long long)pos < a.cap) a.cand[(size_t)(qbase + c.x) * a.cap + pos] = make_uint2(CAND_SLOT, c.y);
+        else *a.overflow = 1u;
+    }
+}
+
+template <int NB>
+int launch_wide2(const WideArgs& a, hipStream_t st, hipEvent_t* ev) {
+    const size_t lds = (size_t)NB * W2_SLOT + 8 * WIDE_WAVE_BYTES;
+    if (lds > (size_t)LDS_LIMIT) return set_err(CLIPMI_EUNSUPPORTED, "scan_coarse_wide2: %zu B of LDS", lds);
+    if (int rc = opt_in_lds((const void*)scan_coarse_wide2_kernel<NB>, lds)) return rc;
+    if (ev) (void)hipEventRecord(ev[0], st);
+    hipLaunchKernelGGL(scan_coarse_wide2_kernel<NB>, dim3(NUM_CU), dim3(512), lds, st, a);
+    if (ev) (void)hipEventRecord(ev[1], st);
+    CLIPMI_CHECK_LAUNCH("scan_coarse_wide2_kernel");
+    return 0;
+}
+
 template <int WAVES, int ABL = 0>
 int launch_wide_t(const WideArgs& a, hipStream_t st, hipEvent_t* ev) {
     const size_t lds = (size_t)a.spt * 32768 + 2048 + WAVES * WIDE_WAVE_BYTES;
@@ -2696,11 +2903,18 @@ int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta,
             hipEvent_t* ev = (scan_ev && ev_used + 2 <= max_ev) ? scan_ev + ev_used : nullptr;
 #ifdef CLIPMI_DEV
             static const int abl = (int)dev_knob("CLIPMI_WIDE_ABL", 0);        // ablations + the 4-wave form: development build only
+            // CLIPMI_WIDE2: 0 = never the second form, 4 / 8 = every segment (ring slots), 1 (default) = as the product build: the
+            // last segment only
+            static const int w2 = (int)dev_knob("CLIPMI_WIDE2", 1);
+            if (w2 && qc > W2_TILE_Q && (w2 != 1 || last)) {
+                if (int rc = w2 == 8 ? launch_wide2<8>(c, st, ev) : launch_wide2<4>(c, st, ev)) return rc;
+            } else
             if (int rc = abl == 1 ? launch_wide_t<8, 1>(c, st, ev) : abl == 2 ? launch_wide_t<8, 2>(c, st, ev)
                        : abl == 3 ? launch_wide_t<8, 3>(c, st, ev)
                        : wide_waves() == 4 ? launch_wide_t<4>(c, st, ev) : launch_wide_t<8>(c, st, ev)) return rc;
 #else
-            if (int rc = launch_wide_t<8>(c, st, ev)) return rc;
+            // more than 512 queries, last segment (most of the rows, survivors rare): queries in registers, rows through the LDS ring
+            if (int rc = (last && qc > W2_TILE_Q) ? launch_wide2<4>(c, st, ev) : launch_wide_t<8>(c, st, ev)) return rc;
 #endif
             if (ev) ev_used += 2;
             launch_rescore(true, dim3(12, qc), st, static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, WIDE_CAP, slot_rows);
