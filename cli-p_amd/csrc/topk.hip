@@ -2596,6 +2596,7 @@ int wide_waves() {
 // =================================================================================================
 constexpr int W2_NB = 4;                          // ring slots
 constexpr int W2_TILE_Q = 512;                    // queries per workgroup: 8 waves x 2 groups x 32
+constexpr int W2_MIN_Q = 257;                     // query counts below this take scan_coarse_wide_kernel (one tile of 256 is half the work)
 constexpr int W2_SLOT = 16384 + 256;              // a ring slot: 16 KiB of fragments + the block's meta
 
 template <int N_>
@@ -2682,30 +2683,69 @@ __global__ void __launch_bounds__(512) scan_coarse_wide2_kernel(WideArgs a) {
             const int ma = max3(m0, m1, m2), mb = max3(m3, m4, acc[15]);
             return ((ma > mb ? ma : mb) >= dmin) & (tq_ != INFINITY);      // +inf (padding query): never; no branch in the MFMA stream
         };
-        // (list entries are written by inline asm: a compiler-visible LDS store would wait vmcnt(0) for the DMA in flight)
-        auto append = [&](const i32x16& acc, int g, float tq_, float yq_, int blk_, float2 bm_) {
-            const unsigned rbase = (unsigned)blk_ * 32u + 4u * (unsigned)h;
-            const float ay = bm_.y * yq_;
+        // A lane whose pre-test passes ("hit": one (query, block) pair with possibly a passing row) does NOT run the per-row test
+        // there: that is 16 values x (convert, fma, compare, ballot, branch) for the whole wave per hit, the wave is coupled to the
+        // other seven by the ring's barrier, and in the last segment one of the 16 (wave, group) pairs of a workgroup hits in four
+        // blocks out of five. The hit lanes drop their 16 sums + (query, first row, scale, a_max Y_q, T_q) into the wave's queue in
+        // LDS (96 bytes each, by ballot prefix); when 64 are queued every lane takes ONE entry and the 16 ballot rounds serve 64
+        // hits at once. Same per-row test, same survivors (their order in the lists differs; the lists are unordered).
+        // (All LDS traffic here is inline asm: a compiler-visible access waits vmcnt(0) for the DMA in flight.)
+        int hcount = 0;                                            // wave-uniform: entries queued
+        const unsigned hq_a = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + (size_t)NB * W2_SLOT + 8 * WIDE_WAVE_BYTES) +
+                              (unsigned)wave * (64u * 96u);
+        auto drain = [&]() {
+            const bool mine = lane < hcount;
+            const unsigned ea = hq_a + (unsigned)(mine ? lane : 0) * 96u;
+            i32x4 mt0, mt1;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2 offset:64\n\tds_read_b128 %1, %2 offset:80\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(mt0), "=&v"(mt1) : "v"(ea) : "memory");
+            const unsigned qidx = (unsigned)mt0[0], rbase = (unsigned)mt0[1];
+            const float s_ = __int_as_float(mt0[2]), ay = __int_as_float(mt0[3]), tq_ = __int_as_float(mt1[0]);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const unsigned row = rbase + (unsigned)((i & 3) + 8 * (i >> 2));
-                const float val = fmaf((float)acc[i], bm_.x, ay);
-                const bool pass = (val >= tq_) && (row <= last_row32);
-                const unsigned long long m = __ballot(pass);
-                if (m) {
-                    const int pos = npend + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (pass) {
-                        const uint2 ent = make_uint2((unsigned)((2 * wave + g) * 32 + n), row);
-                        asm volatile("ds_write_b64 %0, %1" ::"v"(list_a + (unsigned)pos * 8u), "v"(ent) : "memory");
+            for (int i4 = 0; i4 < 4; ++i4) {
+                i32x4 v;
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ea + (unsigned)i4 * 16u) : "memory");
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned row = rbase + (unsigned)(c + 8 * i4);
+                    const float val = fmaf((float)v[c], s_, ay);
+                    const bool pass = mine && (val >= tq_) && (row <= last_row32);
+                    const unsigned long long m = __ballot(pass);
+                    if (m) {
+                        const int pos = npend + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        if (pass) {
+                            const uint2 ent = make_uint2(qidx, row);
+                            asm volatile("ds_write_b64 %0, %1" ::"v"(list_a + (unsigned)pos * 8u), "v"(ent) : "memory");
+                        }
+                        npend += __builtin_popcountll(m);
                     }
-                    npend += __builtin_popcountll(m);
                 }
-                if ((i & 3) == 3 && npend > WIDE_FLUSH) {
+                if (npend > WIDE_FLUSH) {                          // <= 256 appends between two tests
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     wide_flush(list, npend, qbase, a.gcnt, a.cand, a.cap, a.overflow);
                     npend = 0;
                 }
             }
+            hcount = 0;
+        };
+        auto enqueue = [&](const i32x16& acc, int g, bool hit, int blk_, float2 bm_) {
+            const unsigned long long m = __ballot(hit);
+            if (!m) return;
+            const int nh = __builtin_popcountll(m);
+            if (hcount + nh > 64) drain();
+            if (hit) {
+                const int slot = hcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                const unsigned ea = hq_a + (unsigned)slot * 96u;
+                const i32x4 v0 = {acc[0], acc[1], acc[2], acc[3]}, v1 = {acc[4], acc[5], acc[6], acc[7]};
+                const i32x4 v2 = {acc[8], acc[9], acc[10], acc[11]}, v3 = {acc[12], acc[13], acc[14], acc[15]};
+                const i32x4 m0 = {(2 * wave + g) * 32 + n, (int)((unsigned)blk_ * 32u + 4u * (unsigned)h), __float_as_int(bm_.x),
+                                  __float_as_int(bm_.y * yq[g])};
+                const i32x4 m1 = {__float_as_int(tq[g]), 0, 0, 0};
+                asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\tds_write_b128 %0, %3 offset:32\n\t"
+                             "ds_write_b128 %0, %4 offset:48\n\tds_write_b128 %0, %5 offset:64\n\tds_write_b128 %0, %6 offset:80"
+                             ::"v"(ea), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(m0), "v"(m1) : "memory");
+            }
+            hcount += nh;
         };
         // The fragment ring never drains: the reads behind k-steps 12-15 of block k fetch k-steps 0-3 of block k + 1. Barrier b
         // publishes block b + 1 (everyone's pieces have landed) and frees block b - 1's slot for block b + NB - 1; waves 0-3 reach
@@ -2749,9 +2789,10 @@ __global__ void __launch_bounds__(512) scan_coarse_wide2_kernel(WideArgs a) {
                     asm volatile("ds_read_b64 %0, %1" : "=v"(pm) : "v"(ring_a - lane16 + (unsigned)(k & (NB - 1)) * (unsigned)W2_SLOT + 16384u));
             }
             const float2 bm = make_float2(__uint_as_float(pm.x), __uint_as_float(pm.y));
-            if (__ballot(pretest(acc0, tq[0], yq[0], bm))) append(acc0, 0, tq[0], yq[0], blk, bm);
-            if (__ballot(pretest(acc1, tq[1], yq[1], bm))) append(acc1, 1, tq[1], yq[1], blk, bm);
+            enqueue(acc0, 0, pretest(acc0, tq[0], yq[0], bm), blk, bm);
+            enqueue(acc1, 1, pretest(acc1, tq[1], yq[1], bm), blk, bm);
         }
+        if (hcount) drain();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         w2_wait_vmcnt<0>();                                   // the re-fetched tail blocks: nothing may land after the ring is reused
     }
@@ -2776,7 +2817,7 @@ __global__ void __launch_bounds__(512) scan_coarse_wide2_kernel(WideArgs a) {
 
 template <int NB>
 int launch_wide2(const WideArgs& a, hipStream_t st, hipEvent_t* ev) {
-    const size_t lds = (size_t)NB * W2_SLOT + 8 * WIDE_WAVE_BYTES;
+    const size_t lds = (size_t)NB * W2_SLOT + 8 * WIDE_WAVE_BYTES + 8 * 64 * 96;        // ring | pair lists | hit queues
     if (lds > (size_t)LDS_LIMIT) return set_err(CLIPMI_EUNSUPPORTED, "scan_coarse_wide2: %zu B of LDS", lds);
     if (int rc = opt_in_lds((const void*)scan_coarse_wide2_kernel<NB>, lds)) return rc;
     if (ev) (void)hipEventRecord(ev[0], st);
@@ -2903,18 +2944,17 @@ int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta,
             hipEvent_t* ev = (scan_ev && ev_used + 2 <= max_ev) ? scan_ev + ev_used : nullptr;
 #ifdef CLIPMI_DEV
             static const int abl = (int)dev_knob("CLIPMI_WIDE_ABL", 0);        // ablations + the 4-wave form: development build only
-            // CLIPMI_WIDE2: 0 = never the second form, 4 / 8 = every segment (ring slots), 1 (default) = as the product build: the
-            // last segment only
+            // CLIPMI_WIDE2=0: never the second form (A/B); CLIPMI_WIDE2_MINQ: smallest query count that takes it
             static const int w2 = (int)dev_knob("CLIPMI_WIDE2", 1);
-            if (w2 && qc > W2_TILE_Q && (w2 != 1 || last)) {
-                if (int rc = w2 == 8 ? launch_wide2<8>(c, st, ev) : launch_wide2<4>(c, st, ev)) return rc;
+            static const int w2_minq = (int)dev_knob("CLIPMI_WIDE2_MINQ", W2_MIN_Q);
+            if (w2 && qc >= w2_minq) {
+                if (int rc = launch_wide2<4>(c, st, ev)) return rc;
             } else
             if (int rc = abl == 1 ? launch_wide_t<8, 1>(c, st, ev) : abl == 2 ? launch_wide_t<8, 2>(c, st, ev)
                        : abl == 3 ? launch_wide_t<8, 3>(c, st, ev)
                        : wide_waves() == 4 ? launch_wide_t<4>(c, st, ev) : launch_wide_t<8>(c, st, ev)) return rc;
 #else
-            // more than 512 queries, last segment (most of the rows, survivors rare): queries in registers, rows through the LDS ring
-            if (int rc = (last && qc > W2_TILE_Q) ? launch_wide2<4>(c, st, ev) : launch_wide_t<8>(c, st, ev)) return rc;
+            if (int rc = qc >= W2_MIN_Q ? launch_wide2<4>(c, st, ev) : launch_wide_t<8>(c, st, ev)) return rc;
 #endif
             if (ev) ev_used += 2;
             launch_rescore(true, dim3(12, qc), st, static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, WIDE_CAP, slot_rows);

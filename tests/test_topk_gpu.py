@@ -465,7 +465,7 @@ def test_wide_int8_pass_is_bit_exact(clipmi, gpu, topk_oracle, N, Q, K):
     _assert_exact(D[pick], I[pick], Ds, Is, f"wide int8 vs oracle N={N} Q={Q} K={K}")
 
 
-@pytest.mark.parametrize("Q", [256, 1024])
+@pytest.mark.parametrize("Q", [256, 512, 1024])
 def test_wide_identical_rows_and_duplicate_cluster(clipmi, gpu, topk_oracle, Q):
     """The wide pass's per-wave list at its limits: (i) 300 k identical rows - every (query, row) pair of every 32-row block
     passes, lists overflow their global capacity and the exact fallback answers; (ii) 4096 consecutive duplicates of the row
