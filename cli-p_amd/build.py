@@ -127,6 +127,13 @@ def build(force=False, verbose=True, dev=False):
         if os.path.exists(STAMP):
             os.remove(STAMP)
         run([HIPCC] + LINK_FLAGS + objs + ["-o", LIB])
+        # a shared library links with undefined symbols: load it once (hipcc can drop a kernel template's host stub without a
+        # diagnostic - DESIGN 4.1i - and the first sign would be an OSError at import time on the GPU box)
+        import ctypes
+        try:
+            ctypes.CDLL(LIB)
+        except OSError as e:
+            raise RuntimeError(f"{LIB} does not load: {e}") from None
         with open(STAMP, "w") as f:
             json.dump({"digest": digest, "objects": {os.path.basename(o): d for o, d in stamps.items()}}, f)
         linked = True

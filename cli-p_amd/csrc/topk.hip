@@ -2260,11 +2260,13 @@ int launch_coarse(const CoarseArgs& a, long long nsteps, hipStream_t st, hipEven
     // queries at 10 M rows); kept apart the streams settle half a batch out of phase - one scans while the other runs
     // its pre-pass, early segments, re-scoring and selects, which DO fit beside the early segments' unpadded scans - and a
     // batch takes 0.97-1.00 ms. (Padding every scan, i.e. the 114 KiB all of them used to need: 1.02-1.04 ms.)
-    if (!PREPASS && lds < (size_t)COARSE_MAIN_LDS) lds = COARSE_MAIN_LDS;
+    // development: CLIPMI_COARSE_WGS=2 - two workgroups (8 waves, 128 KB of rows in flight) per CU, no LDS padding
+    static const int wgs = [] { const int v = (int)dev_knob("CLIPMI_COARSE_WGS", 1); return v == 2 ? 2 : 1; }();
+    if (!PREPASS && wgs == 1 && lds < (size_t)COARSE_MAIN_LDS) lds = COARSE_MAIN_LDS;
     if (lds > (size_t)LDS_LIMIT) return set_err(CLIPMI_EUNSUPPORTED, "scan_coarse: %zu B of LDS", lds);
     if (int rc = opt_in_lds((const void*)scan_coarse_kernel<512, QG, PREPASS, I8, Q2>, lds)) return rc;
     long long g_ = (nsteps + WAVES - 1) / WAVES;
-    const int grid = (int)(g_ < NUM_CU ? g_ : NUM_CU);
+    const int grid = (int)(g_ < (long long)NUM_CU * wgs ? g_ : (long long)NUM_CU * wgs);
     if (ev) (void)hipEventRecord(ev[0], st);
     hipLaunchKernelGGL((scan_coarse_kernel<512, QG, PREPASS, I8, Q2>), dim3(grid), dim3(WAVES * 64), lds, st, a);
     if (ev) (void)hipEventRecord(ev[1], st);
@@ -2595,38 +2597,38 @@ int wide_waves() {
 // The compare (integer pre-test per lane, per-row test and ballot appends behind it) is scan_coarse_wide_kernel's.
 // =================================================================================================
 constexpr int W2_NB = 4;                          // ring slots
-constexpr int W2_TILE_Q = 512;                    // queries per workgroup: 8 waves x 2 groups x 32
 constexpr int W2_MIN_Q = 257;                     // query counts below this take scan_coarse_wide_kernel (one tile of 256 is half the work)
 constexpr int W2_SLOT = 16384 + 256;              // a ring slot: 16 KiB of fragments + the block's meta
 
 template <int N_>
 __device__ __forceinline__ void w2_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
-template <int NB>
+template <int NB, int NG>      // ring slots; 32-query groups per wave (2: tiles of 512 queries, 1: tiles of 256)
 __global__ void __launch_bounds__(512) scan_coarse_wide2_kernel(WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = 16;
+    constexpr int TILE_Q = 8 * NG * 32;                       // queries of a workgroup
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
     // workgroup -> (query tile, row lane): blocks b, b + 8, ... share an XCD; the tiles of a row lane are such neighbours
-    const int ntile = (a.Q + W2_TILE_Q - 1) / W2_TILE_Q;
+    const int ntile = (a.Q + TILE_Q - 1) / TILE_Q;
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3, jb = gridDim.x >> 3;
     const int rlx = jb / ntile;
     if (j >= rlx * ntile) return;
     const int qt = j % ntile, nrl = __builtin_amdgcn_readfirstlane(rlx * 8);
     const int rl = (j / ntile) * 8 + x;
-    const int qbase = qt * W2_TILE_Q;
+    const int qbase = qt * TILE_Q;
     char* ring = smem;                                            // NB slots of 16 KiB of fragments + 256 B of block meta
     uint2* list = reinterpret_cast<uint2*>(smem + (size_t)NB * W2_SLOT + (size_t)wave * WIDE_WAVE_BYTES);
 
-    // this wave's two query groups: fragments (the wide image of coarse_prep_kernel: entry [(G 16 + s) 64 + lane]) and per-lane
+    // this wave's NG query groups: fragments (the wide image of coarse_prep_kernel: entry [(G 16 + s) 64 + lane]) and per-lane
     // thresholds - constant over the launch
-    uint4 Bq[2][KS];
-    float tq[2], yq[2];
+    uint4 Bq[NG][KS];
+    float tq[NG], yq[NG];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int G = qt * (W2_TILE_Q / 32) + 2 * wave + g;
+    for (int g = 0; g < NG; ++g) {
+        const int G = qt * (TILE_Q / 32) + NG * wave + g;
         const bool has_img = G * 32 < a.qs;                         // the image covers qs (a multiple of 64) queries
 #pragma unroll
         for (int s_ = 0; s_ < KS; ++s_)
@@ -2738,7 +2740,7 @@ __global__ void __launch_bounds__(512) scan_coarse_wide2_kernel(WideArgs a) {
                 const unsigned ea = hq_a + (unsigned)slot * 96u;
                 const i32x4 v0 = {acc[0], acc[1], acc[2], acc[3]}, v1 = {acc[4], acc[5], acc[6], acc[7]};
                 const i32x4 v2 = {acc[8], acc[9], acc[10], acc[11]}, v3 = {acc[12], acc[13], acc[14], acc[15]};
-                const i32x4 m0 = {(2 * wave + g) * 32 + n, (int)((unsigned)blk_ * 32u + 4u * (unsigned)h), __float_as_int(bm_.x),
+                const i32x4 m0 = {(NG * wave + g) * 32 + n, (int)((unsigned)blk_ * 32u + 4u * (unsigned)h), __float_as_int(bm_.x),
                                   __float_as_int(bm_.y * yq[g])};
                 const i32x4 m1 = {__float_as_int(tq[g]), 0, 0, 0};
                 asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\tds_write_b128 %0, %3 offset:32\n\t"
@@ -2769,28 +2771,33 @@ __global__ void __launch_bounds__(512) scan_coarse_wide2_kernel(WideArgs a) {
         if (late) ring_barrier(0);
         for (int k = 0; k < nk; ++k) {
             const int blk = __builtin_amdgcn_readfirstlane(first + k * nrl);
-            i32x16 acc0, acc1;
+            // (a fixed bound: with `acc[NG]` the operands of the refill's asm are type-dependent and hipcc drops the kernel's HOST
+            //  stub without a diagnostic - the library then fails to load with an undefined __device_stub__ symbol)
+            i32x16 acc[2];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { acc0[i] = 0; acc1[i] = 0; }
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[g][i] = 0;
             uint2 pm = make_uint2(0u, 0u);                    // the block's meta, read from its slot behind k-step 0
 #pragma unroll
             for (int s_ = 0; s_ < KS; ++s_) {
                 // (k-step 4's wait also retires the meta read: it is older than the fragment of k-step 5)
                 if (s_ == 4) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(A[s_ & 3]), "+v"(pm));
                 else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(A[s_ & 3]));
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[s_ & 3], __builtin_bit_cast(i32x4, Bq[0][s_]), acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[s_ & 3], __builtin_bit_cast(i32x4, Bq[1][s_]), acc1, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[s_ & 3], __builtin_bit_cast(i32x4, Bq[g][s_]), acc[g], 0, 0, 0);
                 if (s_ == KS / 2 - 1 && !late) ring_barrier(k);
                 if (s_ == KS - 1 && late && k + 1 < nk) ring_barrier(k + 1);
-                // the refill may not overtake the two MFMAs that read the register: tie it to their results
+                // the refill may not overtake the MFMAs that read the register: tie it to their results
                 const unsigned fa = s_ + 4 < KS ? frag(k, s_ + 4) : frag(k + 1, s_ + 4 - KS);
-                asm volatile("ds_read_b128 %0, %1" : "=v"(A[s_ & 3]) : "v"(fa), "v"(acc0), "v"(acc1));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(A[s_ & 3]) : "v"(fa), "v"(acc[0]), "v"(acc[NG - 1]));
                 if (s_ == 0)
                     asm volatile("ds_read_b64 %0, %1" : "=v"(pm) : "v"(ring_a - lane16 + (unsigned)(k & (NB - 1)) * (unsigned)W2_SLOT + 16384u));
             }
             const float2 bm = make_float2(__uint_as_float(pm.x), __uint_as_float(pm.y));
-            enqueue(acc0, 0, pretest(acc0, tq[0], yq[0], bm), blk, bm);
-            enqueue(acc1, 1, pretest(acc1, tq[1], yq[1], bm), blk, bm);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) enqueue(acc[g], g, pretest(acc[g], tq[g], yq[g], bm), blk, bm);
         }
         if (hcount) drain();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2799,13 +2806,13 @@ __global__ void __launch_bounds__(512) scan_coarse_wide2_kernel(WideArgs a) {
     // final publication, aggregated per workgroup (one returning global atomic per (workgroup, query))
     __syncthreads();
     unsigned* hist = reinterpret_cast<unsigned*>(smem);              // the ring is dead now
-    unsigned* gbase = hist + W2_TILE_Q;
-    unsigned* hoff = hist + 2 * W2_TILE_Q;
-    for (int i = tid; i < W2_TILE_Q; i += 512) { hist[i] = 0; hoff[i] = 0; }
+    unsigned* gbase = hist + TILE_Q;
+    unsigned* hoff = hist + 2 * TILE_Q;
+    for (int i = tid; i < TILE_Q; i += 512) { hist[i] = 0; hoff[i] = 0; }
     __syncthreads();
     for (int e = lane; e < npend; e += 64) atomicAdd(&hist[list[e].x], 1u);
     __syncthreads();
-    for (int i = tid; i < W2_TILE_Q; i += 512) gbase[i] = hist[i] ? atomicAdd(&a.gcnt[qbase + i], hist[i]) : 0u;
+    for (int i = tid; i < TILE_Q; i += 512) gbase[i] = hist[i] ? atomicAdd(&a.gcnt[qbase + i], hist[i]) : 0u;
     __syncthreads();
     for (int e = lane; e < npend; e += 64) {
         const uint2 c = list[e];
@@ -2815,16 +2822,24 @@ __global__ void __launch_bounds__(512) scan_coarse_wide2_kernel(WideArgs a) {
     }
 }
 
-template <int NB>
-int launch_wide2(const WideArgs& a, hipStream_t st, hipEvent_t* ev) {
+// groups per wave by query count: tiles of 512 queries (2 groups) where they fill (257-512, 769-1024), tiles of 256 elsewhere
+inline int wide2_groups(int Q) { return (Q > 256 && Q <= 512) || Q > 768 ? 2 : 1; }
+
+template <int NB, int NG>
+int launch_wide2_t(const WideArgs& a, hipStream_t st, hipEvent_t* ev) {
     const size_t lds = (size_t)NB * W2_SLOT + 8 * WIDE_WAVE_BYTES + 8 * 64 * 96;        // ring | pair lists | hit queues
     if (lds > (size_t)LDS_LIMIT) return set_err(CLIPMI_EUNSUPPORTED, "scan_coarse_wide2: %zu B of LDS", lds);
-    if (int rc = opt_in_lds((const void*)scan_coarse_wide2_kernel<NB>, lds)) return rc;
+    if (int rc = opt_in_lds((const void*)scan_coarse_wide2_kernel<NB, NG>, lds)) return rc;
     if (ev) (void)hipEventRecord(ev[0], st);
-    hipLaunchKernelGGL(scan_coarse_wide2_kernel<NB>, dim3(NUM_CU), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((scan_coarse_wide2_kernel<NB, NG>), dim3(NUM_CU), dim3(512), lds, st, a);
     if (ev) (void)hipEventRecord(ev[1], st);
     CLIPMI_CHECK_LAUNCH("scan_coarse_wide2_kernel");
     return 0;
+}
+
+template <int NB>
+int launch_wide2(const WideArgs& a, hipStream_t st, hipEvent_t* ev, int ng) {
+    return ng == 2 ? launch_wide2_t<NB, 2>(a, st, ev) : launch_wide2_t<NB, 1>(a, st, ev);
 }
 
 template <int WAVES, int ABL = 0>
@@ -2947,14 +2962,15 @@ int topk_wide_impl(const void* db_dev, const void* db8_dev, const float2* rmeta,
             // CLIPMI_WIDE2=0: never the second form (A/B); CLIPMI_WIDE2_MINQ: smallest query count that takes it
             static const int w2 = (int)dev_knob("CLIPMI_WIDE2", 1);
             static const int w2_minq = (int)dev_knob("CLIPMI_WIDE2_MINQ", W2_MIN_Q);
+            static const int w2_ng = (int)dev_knob("CLIPMI_WIDE2_NG", 0);              // 1 / 2: force the groups per wave (A/B)
             if (w2 && qc >= w2_minq) {
-                if (int rc = launch_wide2<4>(c, st, ev)) return rc;
+                if (int rc = launch_wide2<4>(c, st, ev, w2_ng == 1 || w2_ng == 2 ? w2_ng : wide2_groups(qc))) return rc;
             } else
             if (int rc = abl == 1 ? launch_wide_t<8, 1>(c, st, ev) : abl == 2 ? launch_wide_t<8, 2>(c, st, ev)
                        : abl == 3 ? launch_wide_t<8, 3>(c, st, ev)
                        : wide_waves() == 4 ? launch_wide_t<4>(c, st, ev) : launch_wide_t<8>(c, st, ev)) return rc;
 #else
-            if (int rc = qc >= W2_MIN_Q ? launch_wide2<4>(c, st, ev) : launch_wide_t<8>(c, st, ev)) return rc;
+            if (int rc = qc >= W2_MIN_Q ? launch_wide2<4>(c, st, ev, wide2_groups(qc)) : launch_wide_t<8>(c, st, ev)) return rc;
 #endif
             if (ev) ev_used += 2;
             launch_rescore(true, dim3(12, qc), st, static_cast<const float*>(db_dev), qg, w.cand_c, w.gcnt_c, WIDE_CAP, slot_rows);

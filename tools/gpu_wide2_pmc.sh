@@ -3,7 +3,7 @@ export CLIPMI_DEV_LIB=1   # CLIPMI_WIDE2 is read by the development library only
 # the two wide-pass kernels side by side (development): duration, clock, MFMA-busy and wait fractions of the scans of ONE call of
 # 1 024 queries at 10 M rows. usage: tools/gpu_wide2_pmc.sh
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
-for w in 0 4; do
+for w in 0 1; do
 export CLIPMI_WIDE2=$w
 echo "== CLIPMI_WIDE2=$w"
 rm -rf gpurun_out/pmcw2
