@@ -21,8 +21,8 @@ LABELS = (
     ("gemm_qkv", r"gemm256p_bf16_nt_kernel<(0|5), ?false>"),
     ("gemm_resid", r"gemm256p_bf16_nt_kernel<(2|7), ?false>"),
     ("gemm_patch", r"gemm256_bf16_nt_kernel<4>"),
-    ("scan_coarse_i8", r"scan_coarse_kernel<512, 4, false, true>"),
-    ("scan_wide_i8", r"scan_coarse_wide_kernel<8, 0>"),
+    ("scan_coarse_i8", r"scan_coarse_kernel<512, 4, false, true, false>"),
+    ("scan_wide_i8", r"scan_coarse_wide2_kernel<4, 2>"),
     ("scan_f32", r"scan_topk_f32_kernel<512, false"),
     ("attention", r"attention"),
 )

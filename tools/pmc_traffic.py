@@ -19,10 +19,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 LABELS = (
     ("scan", r"scan_topk_f32_kernel<512, false"),
-    ("scan_coarse", r"scan_coarse_kernel<512, 4, false, false>"),
-    ("scan_coarse_i8", r"scan_coarse_kernel<512, 4, false, true>"),          # the last segment (75 % of the rows)
-    ("scan_coarse_i8_pre", r"scan_coarse_kernel<512, 4, true, true>"),       # the two earlier segments of the same pass
-    ("scan_wide", r"scan_coarse_wide_kernel<8, 0>"),                          # wide pass (Q > 64): all its segments averaged
+    ("scan_coarse", r"scan_coarse_kernel<512, 4, false, false, false>"),
+    ("scan_coarse_i8", r"scan_coarse_kernel<512, 4, false, true, false>"),          # the last segment (75 % of the rows)
+    ("scan_coarse_i8_pre", r"scan_coarse_kernel<512, 4, true, true, false>"),       # the two earlier segments of the same pass
+    ("scan_wide", r"scan_coarse_wide2_kernel<4, 2>"),                        # wide pass (Q = 1024: the second form): all its segments averaged
     ("rescore", r"rescore_pairs_kernel"),
     ("gemm_c_fc", r"gemm256p_bf16_nt_kernel<(1|6), ?false>"),
     ("gemm_qkv", r"gemm256p_bf16_nt_kernel<(0|5), ?false>"),
