@@ -2585,18 +2585,19 @@ int wide_waves() {
 }
 
 // =================================================================================================
-// Wide pass, second form (more than 512 queries): QUERIES IN REGISTERS, ROWS THROUGH AN LDS RING.
+// Wide pass, second form (more than 256 queries): QUERIES IN REGISTERS, ROWS THROUGH AN LDS RING.
 //
 // scan_coarse_wide_kernel keeps a 256-query tile's image in LDS and the rows in registers: one KiB of LDS per MFMA, the rows'
 // fragments twice over (this block + the next) in 128 registers, 256 registers with spills - no room for a deeper fragment ring,
-// and four workgroups fetch every block. Here a wave owns TWO 32-query groups for the whole launch (their B fragments: 128
-// registers), a workgroup's 8 waves = a tile of 512 queries, and the 32-row blocks arrive by LDS-DMA in a ring of W2_NB 16-KiB
-// slots (the copy's block layout IS the MFMA register image, so the DMA deposits fragments as they are read): every row
-// fragment read from LDS feeds two MFMAs (half a KiB per MFMA), and two workgroups fetch a block instead of four. All waves
-// walk the same blocks; one barrier per block publishes the slot that landed and frees the one that was read.
-// The compare (integer pre-test per lane, per-row test and ballot appends behind it) is scan_coarse_wide_kernel's.
+// and four workgroups fetch every block. Here a wave owns NG (two, or one) 32-query groups for the whole launch (their B
+// fragments: 64 NG registers), a workgroup's 8 waves = a tile of 256 NG queries, and the 32-row blocks arrive by LDS-DMA in a
+// ring of NB slots (the copy's block layout IS the MFMA register image, so the DMA deposits fragments as they are read): with
+// two groups every row fragment read from LDS feeds two MFMAs (half a KiB per MFMA) and two workgroups fetch a block instead of
+// four. All 8 waves walk the same blocks; ONE barrier per block publishes the slot that landed and frees the one that was
+// read, waves 4-7 take it half a block later than waves 0-3, and the fragment ring in registers never drains.
+// The compare is scan_coarse_wide_kernel's integer pre-test per lane; lanes that pass queue their sums and the per-row test
+// runs on 64 queued hits at a time (see the kernel). One call of 1 024 queries at 10 M rows: 6.26 -> 5.46 ms.
 // =================================================================================================
-constexpr int W2_NB = 4;                          // ring slots
 constexpr int W2_MIN_Q = 257;                     // query counts below this take scan_coarse_wide_kernel (one tile of 256 is half the work)
 constexpr int W2_SLOT = 16384 + 256;              // a ring slot: 16 KiB of fragments + the block's meta
 
