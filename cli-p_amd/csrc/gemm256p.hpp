@@ -36,6 +36,18 @@ constexpr int G256P_MAX_N = 8192;
 // FP8 = true: e4m3 operands + scales as gemm256f8 (MX form: one unit-scale v_mfma_scale_f32_16x16x128_f8f6f4 per
 // accumulator tile and K-tile of 128 bytes); w_scale[N] sits in LDS beside the bias row, the tile's 256 a_scale
 // values arrive by one LDS-DMA instruction under the last K-tile.
+// 16-byte output store of the store passes. CLIPMI_GEMM_NT_STORE (compile time, development A/B): bit 0 the bf16 outputs of the
+// qkv / c_fc forms, bit 1 the split residual - with the non-temporal hint
+#ifndef CLIPMI_GEMM_NT_STORE
+#define CLIPMI_GEMM_NT_STORE 0
+#endif
+template <int BIT>
+__device__ __forceinline__ void gp_store16(void* dst, uint4 v) {
+    typedef unsigned gp_u4v __attribute__((ext_vector_type(4)));
+    if constexpr (CLIPMI_GEMM_NT_STORE & BIT) __builtin_nontemporal_store(gp_u4v{v.x, v.y, v.z, v.w}, reinterpret_cast<gp_u4v*>(dst));
+    else *reinterpret_cast<uint4*>(dst) = v;
+}
+
 template <int EPI, bool FP8 = false>
 __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_RESID_F32 || epi_is_ln(EPI) ||
@@ -562,8 +574,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                                 got.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)give.y, 0xB1, 0xf, 0xf, false);
                                 if (m < g.M && !(g.dbg & 1)) {
                                     unsigned short* dst = ((lane & 1) ? g.xlo : g.xhi) + (size_t)m * g.N + n0 + (lane & ~1) * 4;
-                                    *reinterpret_cast<uint4*>(dst) = (lane & 1) ? make_uint4(got.x, got.y, nl.x, nl.y)
-                                                                                : make_uint4(nh.x, nh.y, got.x, got.y);
+                                    gp_store16<2>(dst, (lane & 1) ? make_uint4(got.x, got.y, nl.x, nl.y) : make_uint4(nh.x, nh.y, got.x, got.y));
                                 }
                                 sa[i] = ln_lane_sum(o);
                                 sq[i] = ln_lane_sumsq(o);
@@ -685,7 +696,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                         for (int k = 0; k < 8; ++k) {
                             const int m = m0 + a * 128 + k * 16 + rlow;
                             if (m < g.M && !(g.dbg & 1))
-                                *reinterpret_cast<uint4*>(outp + (size_t)m * g.N + n0 + (lane & 31) * 8) = xs[k];
+                                gp_store16<1>(outp + (size_t)m * g.N + n0 + (lane & 31) * 8, xs[k]);
                         }
                     }
                 }
