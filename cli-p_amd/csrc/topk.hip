@@ -26,10 +26,12 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Cache policy of the once-read streams (CLIPMI_NT_MASK, compile time): bit 0 the coarse copies of the 64-query
-// passes, bit 1 the wide passes' rows, bit 2 the re-scored f32 rows, bit 3 the exact f32 scan. A set bit = the non-temporal hint
-// (`nt`): the 64-query int8 scan streams 5.2 GB per call and reads 6.15 -> 6.62 TB/s with it.
+// passes, bit 1 the first wide form's rows (65-256 queries), bit 4 the second form's, bit 2 the re-scored f32 rows, bit 3 the exact
+// f32 scan. A set bit = the non-temporal hint
+// (`nt`): the 64-query int8 scan streams 5.2 GB per call and reads 6.15 -> 6.62 TB/s with it; the first wide form (one workgroup
+// per block) gains 1-5 %; the others lose or do not move (bits 2, 3, 4 stay clear).
 #ifndef CLIPMI_NT_MASK
-#define CLIPMI_NT_MASK 1
+#define CLIPMI_NT_MASK 3
 #endif
 template <int BIT>
 __device__ __forceinline__ f32x4 ld16_f(const float* p) {
@@ -2680,9 +2682,9 @@ __global__ void __launch_bounds__(512) scan_coarse_wide2_kernel(WideArgs a) {
                 const_cast<signed char*>(a.dbc) + (size_t)b_ * (32 * 512), 0, 32 * 512, 0x00020000);
             char* dst = ring + (size_t)(k & (NB - 1)) * W2_SLOT + (size_t)(2 * wave) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) char*)dst, 16, lane16, (2 * wave) * 1024, 0,
-                                                     (CLIPMI_NT_MASK & 2) ? 2 : 0);
+                                                     (CLIPMI_NT_MASK & 16) ? 2 : 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) char*)(dst + 1024), 16, lane16,
-                                                     (2 * wave + 1) * 1024, 0, (CLIPMI_NT_MASK & 2) ? 2 : 0);
+                                                     (2 * wave + 1) * 1024, 0, (CLIPMI_NT_MASK & 16) ? 2 : 0);
             // the block's (scale, largest error norm) travels with it: 8 bytes through a buffer of 8 (lanes 2.. read past it: zeros),
             // every wave writes the same words - a third DMA per block and wave keeps the counted waits uniform. (A scalar load
             // returns out of order on lgkmcnt, a vector load shares vmcnt with the DMA and the compiler waits vmcnt(0) for it.)

@@ -3,7 +3,7 @@
 # GPU box and times it against the product library (mask = the default in csrc/topk.hip). usage: tools/gpu_nt_ab.sh "3 5 9"
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 run() {  # label
-  for q in 64 1024; do python3 tools/search_ab2.py 10000000 $q > gpurun_out/nt_run.log 2>&1 || tail -3 gpurun_out/nt_run.log; grep "^N=" gpurun_out/nt_run.log | sed "s/^/$1 /"; done
+  for q in ${NT_QS:-64 1024}; do python3 tools/search_ab2.py 10000000 $q > gpurun_out/nt_run.log 2>&1 || tail -3 gpurun_out/nt_run.log; grep "^N=" gpurun_out/nt_run.log | sed "s/^/$1 /"; done
   python3 tools/exact_timing.py 10000000 > gpurun_out/nt_run.log 2>&1 || tail -3 gpurun_out/nt_run.log; grep "^exact" gpurun_out/nt_run.log | sed "s/^/$1 /"
 }
 export CLIPMI_DEV_LIB=0
