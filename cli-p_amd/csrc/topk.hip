@@ -906,6 +906,7 @@ struct CoarseArgs {
     unsigned* gcnt;              // [128]
     long long cap;
     unsigned* overflow;          // set to 1 when a list would exceed cap
+    int abl;                     // development ablation (CLIPMI_COARSE_ABL=1): never append - timing only, results wrong
 };
 
 // Per-wave (query, row) list in LDS. One (row tile, query group) block of a step appends at most 4 rows x 64 lanes =
@@ -918,19 +919,16 @@ constexpr int COARSE_FLUSH = 512;       // flush when more than this many are pe
 constexpr int COARSE_LIST = COARSE_FLUSH + 256;
 constexpr size_t COARSE_WAVE_BYTES = (size_t)COARSE_LIST * 8 + 16;
 
-// publish a wave's pending pairs: one global atomic per pair (rare path: ~1 pair in 10^4 passes the threshold)
-__device__ __noinline__ void coarse_flush(uint2* list, int* lcnt, unsigned* gcnt, uint2* cand, long long cap, unsigned* overflow) {
+// publish a wave's n pending pairs: one global atomic per pair (rare path: ~1 pair in 10^4 passes the threshold)
+__device__ __noinline__ void coarse_flush(const uint2* list, int n, unsigned* gcnt, uint2* cand, long long cap, unsigned* overflow) {
     const int lane = threadIdx.x & 63;
     wave_lds_sync();
-    const int n = *lcnt < COARSE_LIST ? *lcnt : COARSE_LIST;
     for (int e = lane; e < n; e += 64) {
         const uint2 c = list[e];
         const unsigned pos = atomicAdd(&gcnt[c.x], 1u);
         if ((long long)pos < cap) cand[(size_t)c.x * cap + pos] = make_uint2(CAND_SLOT, c.y);
         else *overflow = 1u;
     }
-    wave_lds_sync();
-    if (lane == 0) *lcnt = 0;
     wave_lds_sync();
 }
 
@@ -987,8 +985,7 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
         }
     }
     uint2* list = reinterpret_cast<uint2*>(smem + IMG_BYTES + (size_t)wave * COARSE_WAVE_BYTES);
-    int* lcnt = reinterpret_cast<int*>(list + COARSE_LIST);
-    if (lane == 0) *lcnt = 0;
+    int npend = 0;                                     // wave-uniform: pairs pending in `list` (positions by ballot prefix)
     __syncthreads();
 
     bool active[QG];
@@ -1125,22 +1122,36 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         any |= active[qg] && (step * 32 + rt * 16 + 4 * g + r <= last_row) && (val[rt][qg][r] >= tau[qg]);
-            if (__ballot(any)) {
+            // Appends (round 4): positions by ballot prefix into a wave-uniform count, as the wide passes do. The first form took one
+            // returning LDS atomic per pair and, per (row tile, query group) block, a wave-level LDS sync + a read of the counter for
+            // the flush test - eight of each on ~60 % of the steps at 64 queries. With all appends compiled out (CLIPMI_COARSE_ABL=1)
+            // the scan is 10-45 us of 0.8 ms faster: that is what any append path can still gain. Blocks without a hit cost one ballot.
+            if (__ballot(any) && !a.abl) {
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                     for (int qg = 0; qg < QG; ++qg) {
+                        bool p[4], anyb = false;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const long long row = step * 32 + rt * 16 + 4 * g + r;
-                            if (active[qg] && row <= last_row && val[rt][qg][r] >= tau[qg]) {
-                                const int pos = atomicAdd(lcnt, 1);
-                                if (pos < COARSE_LIST) list[pos] = make_uint2((unsigned)(qg * 16 + col), (unsigned)row);
-                                else *a.overflow = 1u;       // unreachable (static_assert above); never write past the list
+                            p[r] = active[qg] && (step * 32 + rt * 16 + 4 * g + r <= last_row) && (val[rt][qg][r] >= tau[qg]);
+                            anyb |= p[r];
+                        }
+                        if (!__ballot(anyb)) continue;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const unsigned long long m = __ballot(p[r]);
+                            if (m) {
+                                const int pos = npend + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                // <= 256 appends per block behind at most COARSE_FLUSH pending: inside the list (static_assert above)
+                                if (p[r]) list[pos] = make_uint2((unsigned)(qg * 16 + col), (unsigned)(step * 32 + rt * 16 + 4 * g + r));
+                                npend += __builtin_popcountll(m);
                             }
                         }
-                        wave_lds_sync();
-                        if (*lcnt > COARSE_FLUSH) coarse_flush(list, lcnt, a.gcnt, a.cand, a.cap, a.overflow);
+                        if (npend > COARSE_FLUSH) {
+                            coarse_flush(list, npend, a.gcnt, a.cand, a.cap, a.overflow);
+                            npend = 0;
+                        }
                     }
             }
             if (!has_next) break;
@@ -1160,7 +1171,7 @@ __global__ void __launch_bounds__(256) scan_coarse_kernel(CoarseArgs a) {
     unsigned* hoff = hist + 2 * QMAXC;                               // running offsets
     if (tid < QMAXC) { hist[tid] = 0; hoff[tid] = 0; }
     __syncthreads();
-    const int n_mine = *lcnt < COARSE_LIST ? *lcnt : COARSE_LIST;
+    const int n_mine = npend;
     for (int e = lane; e < n_mine; e += 64) atomicAdd(&hist[list[e].x], 1u);
     __syncthreads();
     if (tid < QMAXC) gbase[tid] = hist[tid] ? atomicAdd(&a.gcnt[tid], hist[tid]) : 0u;
@@ -2425,6 +2436,7 @@ int topk_ip_coarse_impl(const void* db_dev, const void* dbh_dev, bool i8, const 
         CoarseArgs c;
         c.dbc = dbh_dev; c.rmeta = rmeta; c.qmeta = w.qmeta; c.qimage = w.qimage; c.q = qg; c.QA = qa; c.tauc = w.tauc; c.row0 = 0;
         c.cand = w.cand_c; c.gcnt = w.gcnt_c; c.cap = COARSE_CAP; c.overflow = w.flag;
+        c.abl = (int)dev_knob("CLIPMI_COARSE_ABL", 0);
         // rows [r0, r1) of the copy through the coarse machinery: scan -> exact re-scoring of the survivors -> select.
         // keep & 1: the K best so far stay at the head of the candidate lists (gcnt = K) and the next segment appends behind
         // them, so no row is scanned twice; `pre` only picks the kernel NAME profilers average under.
