@@ -293,7 +293,6 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     //  The tile-start barrier below publishes sbias: every wave reaches it after its ds_write + lgkmcnt(0).)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    char* const buf0 = smem;
     char* const buf1 = smem + G256_BUF;
     unsigned short* const outp = static_cast<unsigned short*>(g.out);
 

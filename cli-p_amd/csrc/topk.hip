@@ -1338,11 +1338,13 @@ __global__ void __launch_bounds__(256) rescore_pairs_kernel(const float* __restr
 // Every spin is bounded (a wave that waits too long sets the overflow flag = the exact fallback answers, still exact).
 // =================================================================================================
 constexpr int LIVE_NB = 32;                      // ladder buckets per query
+#ifdef CLIPMI_DEV                                // (LIVE_NB also sizes the product's control block: it stays outside)
 constexpr int LIVE_QN = 4096;                    // ring entries (32 KiB)
 constexpr unsigned LIVE_EMPTY = 0xffffffffu;
 constexpr int LIVE_ROW_BITS = 26;                // ring entry .y = (query << 26) | row: shards of < 2^26 rows
 constexpr int LIVE_WB = 24;                      // 32-row steps per batch of scanner work a workgroup draws (>= its scanner waves)
 constexpr int LIVE_SPIN_LIMIT = 1 << 20;         // polls before a waiting lane gives up (~ tens of ms): overflow -> fallback
+#endif
 
 __device__ __forceinline__ unsigned fkey(float f) {             // order-preserving key of a float (-0 and +0 differ: harmless)
     const unsigned u = __float_as_uint(f);
