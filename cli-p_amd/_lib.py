@@ -21,7 +21,7 @@ SYMBOLS = [
     "clipmi_encode_text_workspace_bytes", "clipmi_encode_text",
     "clipmi_topk_ip_workspace_bytes", "clipmi_topk_ip",
     "clipmi_topk_ip_coarse_workspace_bytes", "clipmi_topk_ip_coarse", "clipmi_dbg_topk_coarse_scan_ms",
-    "clipmi_rows_stats", "clipmi_rows_absmax", "clipmi_rows_to_bf16", "clipmi_i8_copy_bytes", "clipmi_i8_meta_bytes", "clipmi_quantize_rows_i8", "clipmi_topk_ip_coarse_i8", "clipmi_dbg_topk_coarse_i8_scan_ms",
+    "clipmi_rows_stats", "clipmi_rows_absmax", "clipmi_rows_order_workspace_bytes", "clipmi_rows_order_by_absmax", "clipmi_rows_to_bf16", "clipmi_i8_copy_bytes", "clipmi_i8_meta_bytes", "clipmi_quantize_rows_i8", "clipmi_topk_ip_coarse_i8", "clipmi_dbg_topk_coarse_i8_scan_ms",
     "clipmi_dbg_quantize_rows_fp8", "clipmi_dbg_gemm_fp8",
     "clipmi_merge_topk_workspace_bytes", "clipmi_merge_topk", "clipmi_merge_topk_packed",
     "clipmi_l2_normalize_rows", "clipmi_resize_crop_rgb8", "clipmi_last_error", "clipmi_abi_version",
@@ -105,6 +105,10 @@ def lib():
     L.clipmi_quantize_rows_i8.argtypes = [vp, i64, i32, vp, vp, sz, vp, sz, vp]
     L.clipmi_rows_absmax.restype = i32
     L.clipmi_rows_absmax.argtypes = [vp, i64, i32, vp, vp]
+    L.clipmi_rows_order_workspace_bytes.restype = sz
+    L.clipmi_rows_order_workspace_bytes.argtypes = [i64]
+    L.clipmi_rows_order_by_absmax.restype = i32
+    L.clipmi_rows_order_by_absmax.argtypes = [vp, i64, i32, vp, vp, sz, vp]
     L.clipmi_topk_ip_coarse_i8.restype = i32
     L.clipmi_topk_ip_coarse_i8.argtypes = [vp, vp, vp, C.c_float, i64, i32, C.c_float, vp, i32, i32, i64, vp, vp, vp, sz, vp]
     L.clipmi_dbg_topk_coarse_i8_scan_ms.restype = i32

@@ -889,6 +889,10 @@ __global__ void __launch_bounds__(256) coarse_prep_kernel(const float* __restric
 // A coarse scan appends (CAND_SLOT, slot of the copy); the re-scoring pass turns such an entry into (exact score bits, row id).
 // No score has these bits (a NaN score is stored as -inf), so an entry that was re-scored before - the K best a select keeps at
 // the head of the list - is recognised and keeps its row id.
+// INVARIANT: every writer of cand[].x - sample_scores_kernel, rescore_pairs_kernel, rescore_pairs16_kernel and the
+// heads select_topk_kernel keeps (it copies .x unchanged) - stores either CAND_SLOT with a slot, or the RAW bits of a score that is
+// not a NaN (NaN -> -inf before the store). Never an fkey()-encoded key, never raw bits of an unchecked score: 0xffffffff is a NaN
+// pattern and would be read as "slot". tests/test_topk_gpu.py::test_non_finite_queries_through_the_permuted_int8_copy holds it.
 constexpr unsigned CAND_SLOT = 0xffffffffu;
 constexpr size_t RESCORE16_LDS = 512 * 4 + 4 * 16 * 68 * 4;      // rescore_pairs16_kernel: the query + four waves' tiles of 16 row chunks
 
@@ -3166,6 +3170,129 @@ extern "C" int clipmi_rows_absmax(const float* db_dev, int64_t N, int E, float* 
     const unsigned grid = (unsigned)(want < 16 * NUM_CU ? want : 16 * NUM_CU);
     hipLaunchKernelGGL(rows_absmax_kernel, dim3(grid), dim3(256), 0, as_stream(stream), db_dev, (long long)N, E, out_dev);
     CLIPMI_CHECK_LAUNCH("rows_absmax_kernel");
+    return 0;
+}
+
+// ---- clipmi_rows_order_by_absmax: the row order of the int8 copy (slot t holds row perm[t]), built by the
+// library itself so that a C-ABI caller needs no framework sort: perm = the rows ordered by their largest |component|
+// ascending, equal maxima in row order (a stable sort). Keys are the f32 bits of the maxima (non-negative floats order as
+// their bit patterns); a least-significant-digit radix sort, four passes of 8 bits, each pass = per-block digit histogram ->
+// one exclusive scan over (digit, block) -> stable scatter (a block keeps the order of its own items: ranks by wave ballots).
+constexpr int ORD_THREADS = 256, ORD_ROUNDS = 8, ORD_TILE = ORD_THREADS * ORD_ROUNDS;
+
+__global__ void __launch_bounds__(ORD_THREADS) order_hist_kernel(const unsigned* __restrict__ keys, long long N, int shift,
+                                                                 unsigned* __restrict__ hist, unsigned nblocks) {
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * ORD_TILE;
+    for (int r = 0; r < ORD_ROUNDS; ++r) {
+        const long long i = base + r * ORD_THREADS + threadIdx.x;
+        if (i < N) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];      // digit-major: one scan gives every (digit, block) base
+}
+
+// exclusive scan of n counters in place, ONE workgroup of 1024 threads (n = 256 x blocks: 0.6 M entries at 10 M rows)
+__global__ void __launch_bounds__(1024) order_scan_kernel(unsigned* __restrict__ v, long long n) {
+    __shared__ unsigned part[1024];
+    const long long per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    unsigned s = 0;
+    for (long long i = lo; i < hi; ++i) s += v[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned add = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    unsigned run = part[threadIdx.x] - s;
+    for (long long i = lo; i < hi; ++i) {
+        const unsigned c = v[i];
+        v[i] = run;
+        run += c;
+    }
+}
+
+__global__ void __launch_bounds__(ORD_THREADS) order_scatter_kernel(const unsigned* __restrict__ keys_in, const unsigned* __restrict__ idx_in,
+                                                                    long long N, int shift, const unsigned* __restrict__ offs,
+                                                                    unsigned nblocks, unsigned* __restrict__ keys_out,
+                                                                    unsigned* __restrict__ idx_out) {
+    __shared__ unsigned run[256];              // items of this block already placed, per digit
+    __shared__ unsigned wcnt[4][256];          // this round's count per (wave, digit)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    run[tid] = 0;
+    const unsigned goff = offs[(size_t)tid * nblocks + blockIdx.x];        // thread t keeps digit t's global base
+    __shared__ unsigned gbase[256];
+    gbase[tid] = goff;
+    const long long base = (long long)blockIdx.x * ORD_TILE;
+    for (int r = 0; r < ORD_ROUNDS; ++r) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0;
+        __syncthreads();
+        const long long i = base + r * ORD_THREADS + tid;
+        const bool live = i < N;
+        const unsigned key = live ? keys_in[i] : 0u;
+        const unsigned d = (key >> shift) & 255u;
+        // lanes of this wave with the same digit (dead lanes match nobody): eight ballots
+        unsigned long long same = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bal = __ballot(live && ((d >> b) & 1u));
+            same &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        const unsigned below = (unsigned)__popcll(same & ((1ull << lane) - 1ull));
+        if (live && below == 0) wcnt[wave][d] = (unsigned)__popcll(same);
+        __syncthreads();
+        if (live) {
+            unsigned pos = gbase[d] + run[d] + below;
+            for (int w = 0; w < wave; ++w) pos += wcnt[w][d];
+            keys_out[pos] = key;
+            idx_out[pos] = idx_in ? idx_in[i] : (unsigned)i;
+        }
+        __syncthreads();
+        run[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+        // (the next round's clear of wcnt is ordered behind this read by the barrier that follows the clear's own round start:
+        //  every thread clears only its own column tid, which it alone has just read)
+    }
+}
+
+static inline size_t order_blocks(int64_t N) { return (size_t)((N + ORD_TILE - 1) / ORD_TILE); }
+
+extern "C" size_t clipmi_rows_order_workspace_bytes(int64_t N) {
+    if (N < 1 || N >= (1ll << 32) - 1) return 0;
+    // keys A | keys B | ids B | histogram [256][blocks]      (ids A is the caller's perm buffer)
+    return (3 * (size_t)N + 256 * order_blocks(N)) * sizeof(unsigned) + 64;
+}
+
+extern "C" int clipmi_rows_order_by_absmax(const float* db_dev, int64_t N, int E, uint32_t* perm_dev, void* ws_dev, size_t ws_bytes,
+                                           void* stream) {
+    if (!db_dev || !perm_dev || !ws_dev || N < 1 || E < 4 || E % 4 != 0)
+        return set_err(CLIPMI_EINVAL, "rows_order_by_absmax: bad arguments (N=%lld E=%d)", (long long)N, E);
+    const size_t need = clipmi_rows_order_workspace_bytes(N);
+    if (need == 0 || ws_bytes < need)
+        return set_err(CLIPMI_EINVAL, "rows_order_by_absmax: workspace %zu B, need %zu (clipmi_rows_order_workspace_bytes; N < 2^32 - 1)", ws_bytes, need);
+    unsigned* ka = static_cast<unsigned*>(ws_dev);
+    unsigned* kb = ka + N;
+    unsigned* ib = kb + N;
+    unsigned* hist = ib + N;
+    const unsigned nb = (unsigned)order_blocks(N);
+    int rc = clipmi_rows_absmax(db_dev, N, E, reinterpret_cast<float*>(ka), stream);
+    if (rc) return rc;
+    // passes 0, 2 write (kb, ib), passes 1, 3 write (ka, perm): the last pass lands in the caller's buffer
+    for (int pass = 0; pass < 4; ++pass) {
+        const unsigned* kin = pass & 1 ? kb : ka;
+        unsigned* kout = pass & 1 ? ka : kb;
+        const unsigned* iin = pass == 0 ? nullptr : (pass & 1 ? ib : perm_dev);
+        unsigned* iout = pass & 1 ? perm_dev : ib;
+        hipLaunchKernelGGL(order_hist_kernel, dim3(nb), dim3(ORD_THREADS), 0, as_stream(stream), kin, (long long)N, 8 * pass, hist, nb);
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), hist, 256ll * nb);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(ORD_THREADS), 0, as_stream(stream), kin, iin, (long long)N, 8 * pass,
+                           hist, nb, kout, iout);
+    }
+    CLIPMI_CHECK_LAUNCH("order_scatter_kernel");
     return 0;
 }
 

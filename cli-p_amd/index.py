@@ -160,20 +160,20 @@ class IndexFlatIP:
             # The copy holds the rows ORDERED BY THEIR LARGEST |COMPONENT| (round 4): the 32 rows of a block then share a scale
             # that is nearly each row's own (error norms x 1.265 -> x 1.000 on unit rows, ~12 % fewer exactly re-scored rows);
             # the library maps surviving slots back to row ids, results are row ids in add order as ever. The order is built
-            # once per index: the library's row maxima + one stable device sort (CLIPMI_I8_SORT=0: rows in add order).
-            perm = None
+            # once per index by the library itself (clipmi_rows_order_by_absmax: row maxima + a stable radix sort on the device;
+            # round 5 - a framework sort did this before). CLIPMI_I8_SORT=0: rows in add order.
+            perm = ws = None
             if os.environ.get("CLIPMI_I8_SORT", "1") != "0" and N > 32:
-                rowmax = torch.empty(N, dtype=torch.float32, device=db.device)
-                _lib.check(L.clipmi_rows_absmax(db.data_ptr(), N, self.d, rowmax.data_ptr(), _lib.stream_ptr(self.device)),
-                           "clipmi_rows_absmax")
-                perm = torch.argsort(rowmax, stable=True).to(torch.int32)
-                del rowmax
+                perm = torch.empty(N, dtype=torch.int32, device=db.device)
+                ws = torch.empty(L.clipmi_rows_order_workspace_bytes(N), dtype=torch.uint8, device=db.device)
+                _lib.check(L.clipmi_rows_order_by_absmax(db.data_ptr(), N, self.d, perm.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                         _lib.stream_ptr(self.device)), "clipmi_rows_order_by_absmax")
             _lib.check(L.clipmi_quantize_rows_i8(db.data_ptr(), N, self.d, perm.data_ptr() if perm is not None else None,
                                                  q8.data_ptr(), q8.numel(), meta.data_ptr(), meta.numel() * 4,
                                                  _lib.stream_ptr(self.device)), "clipmi_quantize_rows_i8")
             if perm is not None:
-                torch.cuda.current_stream(self.device).synchronize()      # perm is read by the kernel just enqueued
-            del perm
+                torch.cuda.current_stream(self.device).synchronize()      # perm / ws are read by the kernels just enqueued
+            del perm, ws
             self._rmax, amax = self._stats(meta)
             self._db8 = (q8, meta, amax)
         return self._db8 + (self._row_norm_max(),)

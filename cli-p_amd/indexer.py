@@ -113,11 +113,58 @@ def ingest_shards(db, store_path):
     return n
 
 
-def _undecodable(bad, pool):
-    """The failed files that may go to skip_db: those a decoder REJECTED. A file whose decode worker died under it (killed,
-    out of memory) failed for this run only and is retried by the next one."""
+class LostLog:
+    """Files a decode worker DIED on, counted across runs in `<store>.lost` (one hex-encoded path per line, appended by
+    whichever rank lost it: O_APPEND keeps short lines whole). A worker's death proves nothing about the file the first time
+    (an external kill, an out-of-memory kill of a neighbour): the file stays a candidate. The second death on the SAME file
+    does: it then goes to skip_db like a file the decoder rejected - otherwise a file that deterministically crashes its
+    decoder (or a decompression bomb that gets the worker killed) would cost every later run one worker."""
+
+    def __init__(self, store_path):
+        self.path = str(store_path).rstrip("/") + ".lost"
+        self.counts = {}
+        try:
+            with open(self.path, "rb") as f:
+                for ln in f:
+                    try:
+                        k = bytes.fromhex(ln.strip().decode("ascii")).decode("utf-8", "surrogateescape")
+                    except ValueError:
+                        continue
+                    self.counts[k] = self.counts.get(k, 0) + 1
+        except OSError:
+            pass
+
+    def record(self, key):
+        """Note one more worker death on `key`; returns how many there have been (this one included)."""
+        self.counts[key] = self.counts.get(key, 0) + 1
+        try:
+            fd = os.open(self.path, os.O_WRONLY | os.O_APPEND | os.O_CREAT, 0o644)
+            try:
+                os.write(fd, key.encode("utf-8", "surrogateescape").hex().encode("ascii") + b"\n")
+            finally:
+                os.close(fd)
+        except OSError:
+            pass                      # a read-only directory: the count still holds for this run
+        return self.counts[key]
+
+
+def _undecodable(bad, pool, lost_log=None):
+    """The failed files that may go to skip_db: those a decoder REJECTED, and those that have now cost a decode worker its
+    life TWICE (LostLog). A file whose worker died under it for the first time (killed, out of memory) failed for this
+    run only and is retried by the next one. (The dead worker's slot decodes in-process for the rest of the run: no program
+    is started once the GPU may be initialised - pipeline.DecodePool.)"""
     lost = getattr(pool, "lost", None)
-    return [b for b in bad if b not in lost] if lost else bad
+    if not lost:
+        return bad
+    out = []
+    for b in bad:
+        if b not in lost:
+            out.append(b)
+        elif lost_log is not None and b not in getattr(pool, "_lost_counted", set()):
+            pool.__dict__.setdefault("_lost_counted", set()).add(b)
+            if lost_log.record(b) >= 2:
+                out.append(b)
+    return out
 
 
 def encode_directories(dirs, model, db, batch, workers, ranks=None, pool=None, stop=None, store_path="vectors.lmdb"):
@@ -125,6 +172,7 @@ def encode_directories(dirs, model, db, batch, workers, ranks=None, pool=None, s
     writes `shard_path(store_path, rank)` and rank 0 ingests the shards at the end; returns True when the ranks agreed to
     stop early (`stop`: a StopFlag). pool: a pipeline.DecodePool (decode in worker processes) or None (decode on `workers`
     threads)."""
+    lost_log = LostLog(store_path) if pool is not None else None
     if ranks is None or ranks.world == 1:
         for base_path in dirs:
             print(f"CLIPing {base_path}...")
@@ -132,7 +180,7 @@ def encode_directories(dirs, model, db, batch, workers, ranks=None, pool=None, s
             for ok, feats, bad in pipeline.encode_files(model, todo, batch=batch, workers=workers, pool=pool):
                 if ok:
                     db.put_vectors(ok, feats)
-                db.mark_skipped(_undecodable(bad, pool))
+                db.mark_skipped(_undecodable(bad, pool, lost_log))
                 print("." * len(ok) + "#" * len(bad), end="", flush=True)
             print(flush=True)
         return False
@@ -169,7 +217,7 @@ def encode_directories(dirs, model, db, batch, workers, ranks=None, pool=None, s
                         ok, feats, bad = [], None, []
                 if ok:
                     shard.put_vectors(ok, feats)       # this rank's own shard: one commit per batch
-                shard.mark_skipped(_undecodable(bad, pool))
+                shard.mark_skipped(_undecodable(bad, pool, lost_log))
                 flags = ranks.all_gather_ints([len(ok), len(bad), 1 if (stop is not None and stop.set) else 0])
                 if ranks.leader:
                     print("".join("." * f[0] + "#" * f[1] for f in flags), end="", flush=True)   # rank order = list order

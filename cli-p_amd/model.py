@@ -87,7 +87,7 @@ class CLIP:
         """How encode_image cuts B images into kernel sequences: one sequence up to max_batch; above it whole-round
         chunks first and the remainder last (1740 = 870 + 870: 95.5 k -> 102.9 k images/s, 1305 = 870 + 435: 88 k -> 101 k;
         they used to be 1024 + rest). Cutting inputs BELOW max_batch at round boundaries was measured too
-        (tools/chunk_sweep.py): +10 % at 436 images, -9 % at 700 - the kernel choice per GEMM already handles a ragged last
+        (tools/attic/chunk_sweep.py): +10 % at 436 images, -9 % at 700 - the kernel choice per GEMM already handles a ragged last
         round, so those stay whole. Results do not depend on the cut (test_encode_image_batch_invariance_and_dtypes)."""
         if B <= self.max_batch:
             return [B] if B > 0 else []

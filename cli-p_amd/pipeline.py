@@ -382,7 +382,7 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
     def copy_out(decoded, chunk):
         """shared memory -> pinned staging (GPU) or a private tensor (CPU) -> device. numpy copies on purpose: a 65-MB torch
         copy_ fans out over every CPU the host shows (256 here) and its OpenMP team then spins through the container's CPU
-        share - every other batch's decode took 80 ms instead of 15 (tools/pipe_probe.py: 26.7 k images/s decode only,
+        share - every other batch's decode took 80 ms instead of 15 (tools/attic/pipe_probe.py: 26.7 k images/s decode only,
         5.9 k with a torch copy behind each batch)."""
         bigview = full = None
         if len(decoded[0]) == 4:

@@ -190,11 +190,21 @@ size_t clipmi_i8_meta_bytes(int64_t N);
  *  ABI 4, `perm_dev`: NULL, or a permutation of 0 .. N-1 (u32 [N]): slot t of the copy then holds row perm[t]. Order the rows by
  *  their largest |component| (clipmi_rows_absmax + any sort) and the 32 rows of a block share a scale that is nearly each
  *  row's own: error norms and with them the re-scored rows per query drop ~12 %. The search is exact for ANY permutation; it
- *  reports row ids - the meta buffer carries the slot -> row table behind the block meta.) */
+ *  reports row ids - the meta buffer carries the slot -> row table behind the block meta.
+ *  `perm_dev` is NOT validated (a check would need a pass and memory of its own): entries >= N become empty slots (memory-safe),
+ *  duplicate or missing rows silently drop rows from every coarse search. Build it with clipmi_rows_order_by_absmax below, which
+ *  returns a permutation by construction.) */
 int clipmi_quantize_rows_i8(const float* db_dev, int64_t N, int E, const uint32_t* perm_dev, void* out_i8_dev, size_t out_i8_bytes,
                             float* meta_dev, size_t meta_bytes, void* stream);
 /* out_dev[r] = largest |x_rk| of row r (f32 [N]); E a multiple of 4. Asynchronous on `stream`. */
 int clipmi_rows_absmax(const float* db_dev, int64_t N, int E, float* out_dev, void* stream);
+/* perm_dev[t] (u32 [N]) = the row that belongs in slot t of the int8 copy: the rows ordered by their largest |component|,
+ * ascending, equal maxima in row order (a stable radix sort of clipmi_rows_absmax's values on the device; no framework sort is
+ * needed to build the sorted copy). `ws_dev`: clipmi_rows_order_workspace_bytes(N) bytes. Asynchronous on `stream`; pass the
+ * result to clipmi_quantize_rows_i8 as `perm_dev`. Replaces nothing in the reference (its IVF lists have no such order); the
+ * index-load site is query-index.py:29. */
+size_t clipmi_rows_order_workspace_bytes(int64_t N);
+int clipmi_rows_order_by_absmax(const float* db_dev, int64_t N, int E, uint32_t* perm_dev, void* ws_dev, size_t ws_bytes, void* stream);
 int clipmi_topk_ip_coarse_i8(const void* db_dev, const void* db_i8_dev, const float* meta_dev, float amax,
                              int64_t N, int E, float rmax, const float* q_dev, int Q, int K, int64_t id_base,
                              float* out_score_dev, int64_t* out_id_dev,

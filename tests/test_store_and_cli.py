@@ -157,8 +157,15 @@ def test_ctrl_c_does_not_turn_good_files_into_skipped_files(clipmi, tmp_path, mo
         lost = next(iter(pool.lost))
     assert db.is_skipped(base + "broken.jpg") and not db.is_skipped(lost) and not db.has_vector(lost)
     assert bi.candidates(base, db) == [lost]                                   # retried by the next run
-    bi.encode_directories([base], _StubModel(), db, batch=4, workers=2)
-    assert db.count() == 6 and bi.candidates(base, db) == []
+    assert clipmi.indexer.LostLog("vectors.lmdb").counts == {lost: 1}                      # ... and remembered in vectors.lmdb.lost
+    # a file that costs a worker its life AGAIN (a decoder crash, a decompression bomb) is skipped from then on -
+    # here the next run's worker dies on the same file (the pool reports it lost once more)
+    with clipmi.pipeline.DecodePool(1) as pool2:
+        pool2.procs[0].kill()
+        pool2.procs[0].wait()
+        bi.encode_directories([base], _StubModel(), db, batch=4, workers=1, pool=pool2)
+        assert pool2.lost == {lost}
+    assert db.is_skipped(lost) and bi.candidates(base, db) == [] and db.count() == 5
     db.close()
 
 

@@ -125,6 +125,33 @@ def test_non_finite_rows_keep_a_coarse_size_database_exact(clipmi, gpu, topk_ora
         assert 4321 not in I
 
 
+@pytest.mark.parametrize("Q", [5, 64, 130])
+def test_non_finite_queries_through_the_permuted_int8_copy(clipmi, gpu, topk_oracle, Q):
+    """the candidate lists tell a fresh coarse survivor (0xffffffff, slot of the PERMUTED int8 copy) from an entry
+    that is already (score bits, row id) by the first word alone - correct only while every writer stores a NaN score as -inf.
+    Queries with NaN / +inf / -inf components make every score of theirs NaN or infinite; they travel beside ordinary queries
+    through the 64-query pass (64-pair re-scoring) and the wide pass (16-pair re-scoring) of a coarse-size database whose copy is
+    a non-trivial permutation (rows of very different maxima). Ids and score bits must equal the oracle's for every query."""
+    rng = np.random.default_rng(97 + Q)
+    N = 70000
+    db = (unit_rows(rng, N, 512) * rng.uniform(0.2, 2.0, size=(N, 1))).astype(np.float32)
+    q = unit_rows(rng, Q, 512)
+    q[1, 5] = np.nan
+    q[2, 9] = np.inf
+    q[3, 9] = -np.inf
+    q[4, :] = 0.0
+    if Q > 40:
+        q[33, 100] = np.nan
+        q[40, 0], q[40, 1] = np.inf, -np.inf           # inf - inf: NaN scores
+    idx = clipmi.IndexFlatIP(512, device=gpu, coarse="int8")
+    idx.add(db)
+    assert idx.uses_coarse()
+    D, I = idx.search(q, 51)
+    Ds, Is = topk_oracle.topk(db, q, 51)
+    _assert_exact(D, I, Ds, Is, f"non-finite queries, Q = {Q}")
+    assert (I[1] == -1).all() and (I[0] >= 0).all()
+
+
 def test_sharded_equals_single(clipmi, gpu, topk_oracle):
     """Size-independent property at scale: split N rows into R contiguous shards, search each
     with its id_base, merge with clipmi_merge_topk == single-pass result == oracle merge."""
@@ -517,6 +544,30 @@ def test_wide_pass_useless_threshold_and_anisotropic(clipmi, gpu, topk_oracle):
     _assert_exact(D, I, De, Ie, "wide anisotropic vs exact scan")
     Ds, Is = topk_oracle.topk(db, q[::5], 51)
     _assert_exact(D[::5], I[::5], Ds, Is, "wide anisotropic vs oracle")
+
+
+@pytest.mark.parametrize("N", [1, 33, 2048, 2049, 300_007])
+def test_rows_order_by_absmax_is_the_stable_sort(clipmi, gpu, N):
+    """clipmi_rows_order_by_absmax (include/clipmi.h): the permutation a stable ascending sort of the rows' largest |component|
+    gives - many equal maxima (duplicate rows, zero rows), several radix blocks, a ragged last block."""
+    import torch
+    rng = np.random.default_rng(N)
+    x = rng.standard_normal((N, 64)).astype(np.float32)
+    if N > 40:
+        x[rng.integers(0, N, N // 3)] = x[5]              # a third of the rows share one maximum
+        x[rng.integers(0, N, N // 50 + 1)] = 0.0
+        x[11, 3] = np.float32(3e38)
+        x[17, 9] = np.float32(-1e-40)                     # denormal magnitudes order by their bits too
+    L = clipmi._lib.lib()
+    xd = torch.from_numpy(x).to(gpu)
+    perm = torch.full((N,), -1, dtype=torch.int32, device=gpu)
+    ws = torch.empty(L.clipmi_rows_order_workspace_bytes(N), dtype=torch.uint8, device=gpu)
+    clipmi._lib.check(L.clipmi_rows_order_by_absmax(xd.data_ptr(), N, 64, perm.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                    clipmi._lib.stream_ptr(gpu)), "rows_order")
+    torch.cuda.synchronize()
+    want = np.argsort(np.abs(x).max(axis=1), kind="stable")
+    assert np.array_equal(perm.cpu().numpy().view(np.uint32), want.astype(np.uint32))
+    assert L.clipmi_rows_order_by_absmax(xd.data_ptr(), N, 64, perm.data_ptr(), ws.data_ptr(), ws.numel() - 1, None) == 1
 
 
 def test_quantize_rows_i8_matches_numpy(clipmi, gpu):

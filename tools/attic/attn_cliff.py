@@ -1,7 +1,7 @@
 """Attention kernel time vs batch: where does the extra round of workgroups start? (development aid)"""
 import sys, os
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import clipmi
 L = clipmi._lib.lib()
 dev = torch.device("cuda:0")

@@ -3,7 +3,7 @@ rows 4608 B apart) and on the same bytes arranged per (image, head) ([B*H][L][3]
 addressing, 19.2 KB contiguous per item). Development aid."""
 import sys, os
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import clipmi
 L_ = clipmi._lib.lib()
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """Development probe of the block-scaled FP8 GEMM (gemm256f8 BSA): which lanes / blocks a scale byte reaches."""
 import sys, os
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import clipmi
 L = clipmi._lib.lib()
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """encode_image over batch sizes with and without whole-round chunking (development aid)."""
 import sys, os, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import clipmi
 dev = torch.device("cuda:0")
 def t_ms(fn, reps):

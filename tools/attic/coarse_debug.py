@@ -1,6 +1,6 @@
 import sys, os, ctypes as C
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import clipmi
 L = clipmi._lib.lib()
 dev = torch.device("cuda:0")

@@ -2,7 +2,7 @@
 does one half's HBM-bound kernels / epilogue bursts overlap the other half's MFMA mainloops? (development aid)"""
 import sys, os, ctypes as C
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import clipmi
 hip = C.CDLL("libamdhip64.so")
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """Does replaying the encode kernel sequence as one HIP graph beat eager launches? (development aid)"""
 import sys, os
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import clipmi
 dev = torch.device("cuda:0")
 model = clipmi.CLIP(clipmi.weights.random_state_dict("ViT-B/32", seed=0), device=dev)

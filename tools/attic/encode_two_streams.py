@@ -2,7 +2,7 @@
 with the MFMA-bound kernels of the other? (development aid)"""
 import sys, os
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import clipmi
 dev = torch.device("cuda:0")
 sd = clipmi.weights.random_state_dict("ViT-B/32", seed=0)

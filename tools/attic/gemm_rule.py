@@ -1,7 +1,7 @@
 """Where does the 256x256 kernel stop beating the 128x128 one as its last round empties? (development aid)"""
 import sys, os
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import clipmi
 L = clipmi._lib.lib()
 dev = torch.device("cuda:0")

@@ -2,7 +2,7 @@
 time per launch for the ViT-B/32 shapes at B = 870 (development aid; CLIPMI_GEMM_DBG carries GM << 8 | GN << 16)."""
 import sys, os, subprocess
 os.environ.setdefault("CLIPMI_DEV_LIB", "1")   # A/B knobs: development library only
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
     sys.path.insert(0, ROOT)

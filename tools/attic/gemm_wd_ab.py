@@ -4,7 +4,7 @@ algo 2 = gemm256 (both operands by LDS-DMA), 5 = gemm256 WD, 3 = the persistent 
 import sys, os
 os.environ.setdefault("CLIPMI_DEV_LIB", "1")
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import clipmi
 L = clipmi._lib.lib()
 dev = torch.device("cuda:0")

@@ -3,7 +3,7 @@ import sys, os
 os.environ.setdefault("CLIPMI_DEV_LIB", "1")   # A/B knobs: development library only
 os.environ["CLIPMI_GEMM_DBG"] = os.environ.get("CLIPMI_GEMM_DBG", "4")
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import clipmi
 L = clipmi._lib.lib()
 dev = torch.device("cuda:0")

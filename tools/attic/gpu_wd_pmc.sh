@@ -7,7 +7,7 @@ rocprofv3 -L > gpurun_out/wd/counters.txt 2>&1
 shape=${1:-43500x3072x768}
 pass() {  # name, counters...
   n=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/wd/$n -- python3 tools/gemm_wd_ab.py $shape > gpurun_out/wd/$n.log 2>&1 || tail -5 gpurun_out/wd/$n.log
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/wd/$n -- python3 tools/attic/gemm_wd_ab.py $shape > gpurun_out/wd/$n.log 2>&1 || tail -5 gpurun_out/wd/$n.log
 }
 pass sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD
 pass ta TA_TA_BUSY_sum TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum

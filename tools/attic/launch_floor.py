@@ -1,7 +1,7 @@
 """Per-kernel cost of a chain of tiny dependent kernels on one stream (development aid): the floor a one-prompt tower pays."""
 import sys, os, ctypes as C
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import clipmi
 dev = torch.device("cuda:0")
 L = clipmi._lib.lib()

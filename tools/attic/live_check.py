@@ -3,7 +3,7 @@ import sys, os, time
 os.environ.setdefault("CLIPMI_DEV_LIB", "1")   # A/B knobs: development library only
 os.environ.setdefault("CLIPMI_LIVE", "1")      # the live scan is off by default (topk.hip)
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import clipmi
 dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000

@@ -2,7 +2,7 @@
 usage: pipe_probe.py <level>   0 decode only | 1 + copy to pinned | 2 + H2D | 3 + encode | 4 + d2h of the result"""
 import sys, os, time, tempfile
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import clipmi
 from PIL import Image
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 0

@@ -5,7 +5,7 @@ import sys, os, subprocess
 os.environ.setdefault("CLIPMI_DEV_LIB", "1")
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     import clipmi
     L = clipmi._lib.lib()
     dev = torch.device("cuda:0")
