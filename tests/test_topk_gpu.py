@@ -474,11 +474,14 @@ def test_large_query_batch_is_pipelined_and_exact(clipmi, gpu, topk_oracle, kind
     _assert_exact(Dn, In, D, I, "search()")
 
 
-@pytest.mark.parametrize("N,Q,K", [(70001, 65, 51), (100000, 256, 51), (131072, 300, 11), (90000, 640, 21), (200003, 1024, 51),
+@pytest.mark.parametrize("N,Q,K", [(70001, 65, 51), (70001, 128, 51), (80000, 191, 21), (80000, 192, 21), (70001, 200, 51),
+                                   (100000, 256, 51), (100000, 257, 51), (131072, 300, 11), (70001, 513, 51), (70001, 520, 51),
+                                   (90000, 640, 21), (70001, 777, 51), (70001, 993, 11), (200003, 1024, 51),
                                    (66000, 1100, 51), (66000, 2200, 21)])
 def test_wide_int8_pass_is_bit_exact(clipmi, gpu, topk_oracle, N, Q, K):
     """More than 64 queries in ONE call (query-index.py:111 is one index.search whatever Q): the int8 path takes them as
-    wide passes (csrc/topk.hip scan_coarse_wide_kernel: 1, 2, 3 or 4 query tiles, partial sets, a second chunk past 1024).
+    wide passes (csrc/topk.hip scan_coarse_wide_kernel below 192 queries, scan_coarse_wide2_kernel's balanced tiles from there:
+    waves with 0, 1 and 2 query groups, one and two tiles, ragged last groups, a second chunk past 1024).
     Bit-exact against the oracle on 96 of the queries (every tile / set position) and, for ALL queries, against the exact f32
     scan (clipmi_topk_ip), which the tests above pin to the oracle."""
     rng = np.random.default_rng(N + Q + K + 2)
@@ -742,7 +745,7 @@ def test_live_threshold_scan_is_bit_exact_when_enabled():
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, CLIPMI_LIVE="1", CLIPMI_DEV_LIB="1")      # the kernel lives in the development library only
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "live_check.py"), "300000", "1,16,64"], env=env,
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "attic", "live_check.py"), "300000", "1,16,64"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.count("exact: True") == 3 and "exact: False" not in r.stdout, r.stdout
@@ -752,13 +755,13 @@ def test_live_threshold_scan_is_bit_exact_when_enabled():
 def test_two_digit_query_scan_and_both_rescoring_forms_are_bit_exact():
     """Development-library variants that the product does not select for every shape: the 64-query scan with the
     query as two int8 digits (CLIPMI_COARSE_Q2=1: a tighter margin, the same exact results) and each exact re-scoring form forced
-    onto all lists (CLIPMI_RESCORE=16 / 64). Knobs are read once per process: child processes, tools/live_check.py with the live
+    onto all lists (CLIPMI_RESCORE=16 / 64). Knobs are read once per process: child processes, tools/attic/live_check.py with the live
     scan off."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for knobs in ({"CLIPMI_COARSE_Q2": "1"}, {"CLIPMI_RESCORE": "16"}, {"CLIPMI_RESCORE": "64"}):
         env = dict(os.environ, CLIPMI_LIVE="0", CLIPMI_DEV_LIB="1", **knobs)
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "live_check.py"), "300000", "1,33,64,200"], env=env,
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "attic", "live_check.py"), "300000", "1,33,64,200"], env=env,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         assert r.stdout.count("exact: True") == 4 and "exact: False" not in r.stdout, (knobs, r.stdout)
