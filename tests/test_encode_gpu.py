@@ -38,7 +38,7 @@ def _tolerances(clipmi, sd, fn, x):
     return ref, (emu - ref).abs().max().item()
 
 
-@pytest.mark.parametrize("name", ["toy_seed0", "vitb32_seed0", "vitb32_outlier", "toyl14_seed3", "vitb16_seed2", "vitl14_seed4"])
+@pytest.mark.parametrize("name", ["toy_seed0", "vitb32_seed0", "vitb32_outlier", "vitb32_realstats", "toyl14_seed3", "vitb16_seed2", "vitl14_seed4"])
 def test_encode_image_matches_oracle(clipmi, gpu, name):
     sd = clip_case.state_dict(name)
     images, _ = clip_case.inputs(name)
@@ -58,7 +58,7 @@ def test_encode_image_matches_oracle(clipmi, gpu, name):
     assert torch.allclose(gotn, got / got.norm(dim=-1, keepdim=True), atol=2e-6)
 
 
-@pytest.mark.parametrize("name", ["toy_seed0", "vitb32_seed0", "vitb32_outlier", "toyl14_seed3", "vitl14_seed4"])
+@pytest.mark.parametrize("name", ["toy_seed0", "vitb32_seed0", "vitb32_outlier", "vitb32_realstats", "toyl14_seed3", "vitl14_seed4"])
 def test_encode_text_matches_oracle(clipmi, gpu, name):
     sd = clip_case.state_dict(name)
     _, ids = clip_case.inputs(name)

@@ -208,7 +208,7 @@ def test_gemm_fp8_rejects(clipmi, gpu):
     assert L.clipmi_dbg_gemm_fp8(*args, 256, 256, 128, 0, None) == 1      # K >= 256
 
 
-@pytest.mark.parametrize("name", ["vitb32_seed0", "vitb32_outlier"])
+@pytest.mark.parametrize("name", ["vitb32_seed0", "vitb32_outlier", "vitb32_realstats"])
 def test_encode_image_fp8_weights_matches_emulation(clipmi, gpu, name):
     """The FP8 tower against (i) the fp32 oracle, bounded by the noise the oracle itself shows when ITS linear layers run on
     the quantisers the product runs (clip_oracle.linear_fp8(): row-scaled e4m3 behind LayerNorm, MX block scales - 2^(e-7)
