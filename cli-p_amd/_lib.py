@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEV_LIB = os.environ.get("CLIPMI_DEV_LIB", "") not in ("", "0")
 LIB_PATH = os.path.join(HERE, "libclipmi_dev.so" if DEV_LIB else "libclipmi.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 F32, BF16, U8 = 0, 1, 2
 
 # every symbol include/clipmi.h declares (tests check the .so exports all of them)
@@ -130,7 +130,7 @@ def lib():
     L.clipmi_dbg_gemm_bf16.restype = i32
     L.clipmi_dbg_gemm_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.clipmi_dbg_split_stats.restype = i32
-    L.clipmi_dbg_split_stats.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp]
+    L.clipmi_dbg_split_stats.argtypes = [vp, i32, vp, vp, i32, i32, vp]
     L.clipmi_dbg_gemm_ln.restype = i32
     L.clipmi_dbg_gemm_ln.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.clipmi_dbg_quantize_rows_fp8mx.restype = i32
@@ -138,7 +138,7 @@ def lib():
     L.clipmi_dbg_gemm_fp8_bsa.restype = i32
     L.clipmi_dbg_gemm_fp8_bsa.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.clipmi_dbg_gemm_resid_ln.restype = i32
-    L.clipmi_dbg_gemm_resid_ln.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.clipmi_dbg_gemm_resid_ln.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.clipmi_dbg_layernorm.restype = i32
     L.clipmi_dbg_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     L.clipmi_dbg_attention.restype = i32

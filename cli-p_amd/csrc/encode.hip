@@ -4,8 +4,9 @@
 //
 // Activation layout in HBM (all row-major, token row t = b*L + l):
 //   ln_fold towers (bf16 weights, W % 256 == 0: every real CLIP tower; gemm.hpp "LN-folded linear layers"):
-//     xhi, xlo bf16 [B*L][W]   the residual stream, split: x = hi + lo (hi = bf16(x), lo = bf16(x - hi)); hi is the A
-//                              operand of the LN-folded qkv / c_fc GEMMs, so 12-24 residual adds keep ~2^-17 relative
+//     x3   [B*L][3 W bytes]    the residual stream, split (gemm.hpp split_make): a row is W bf16 hi = bf16(x) then W u8
+//                              remainders (3 bytes per element since round 5); the hi halves are the A operand of the
+//                              LN-folded qkv / c_fc GEMMs (row pitch 3 W), 12-24 residual adds keep ~2^-17 relative
 //     ln_part f32 [B*L][W/256][2]  row statistics of x as per-256-column (sum, sum of squares)
 //     x    f32  [B*L][W]       embedding-stage output only (and scratch of non-persistent residual GEMMs)
 //   other towers (FP8 weights, toy widths):
@@ -30,8 +31,8 @@ struct Ws {
     unsigned char* a_bs;      //                  or (A produced by attention / QuickGELU) its MX block scales, rows padded to 256
     unsigned char* x8;        // weight_format 1 + ln_fold: the residual rows as e4m3 [B*L][W] (A operand of the LN-folded qkv / c_fc GEMMs)
     unsigned char* x8_bs;     //                            and their MX block scales, rows padded to 256
-    unsigned short* xhi;      // ln_fold: the residual stream kept split, x = hi + lo (bf16 [B*L][W] each, contiguous);
-    unsigned short* xlo;      //          hi is also the A operand of the LN-folded qkv / c_fc GEMMs
+    void* x3;                 // ln_fold: the residual stream kept split, rows of [W bf16 hi | W u8 lo]; the hi halves are
+                              //          also the A operand of the LN-folded qkv / c_fc GEMMs
     float* ln_part;           //          row statistics of x as per-256-column (sum, sum of squares) [B*L][W/256][2]
 };
 
@@ -57,8 +58,7 @@ size_t carve(const clipmi_tower* t, int B, void* base, size_t cap, Ws* out) {
         w.x8_bs = ar.take<unsigned char>((rows + 255) / 256 * 256 * (size_t)(W / 32));
         w.ln_part = ar.take<float>(rows * 2 * (W / 256));
     } else if (t->ln_fold) {
-        w.xhi = ar.take<unsigned short>(2 * rows * W);
-        w.xlo = w.xhi + rows * W;
+        w.x3 = ar.take<unsigned char>(rows * resid_row_bytes(W));
         w.ln_part = ar.take<float>(rows * 2 * (W / 256));
     }
     if (out) *out = w;
@@ -159,12 +159,13 @@ int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int 
 #endif
     if (t->ln_fold) {
         // LN-folded blocks (gemm.hpp): ln_1 / ln_2 never run as passes of their own and the residual stream lives split
-        // in (w.xhi, w.xlo) with its row statistics in w.ln_part; w.x (f32) is only the embedding stage's output and the
+        // in w.x3 with its row statistics in w.ln_part; w.x (f32) is only the embedding stage's output and the
         // scratch of residual GEMMs that run on a non-persistent kernel. lo_qkv_w / lo_fc_w hold W * diag(ln weight).
         auto lb_of = [&](int l) { return t->off_layers + (uint64_t)l * t->layer_stride; };
         auto ln_linear = [&](uint64_t w_off, uint64_t cb_off, uint64_t cs_off, int N, int epi) -> int {
             GemmArgs g{};
-            g.A = w.xhi; g.W = at<unsigned short>(blob, w_off); g.bias = at<float>(blob, cb_off);
+            g.A = static_cast<const unsigned short*>(w.x3); g.lda_bytes = (unsigned)resid_row_bytes(W);
+            g.W = at<unsigned short>(blob, w_off); g.bias = at<float>(blob, cb_off);
             g.colsum = at<float>(blob, cs_off); g.ln_part_in = w.ln_part;
             g.out = w.big; g.M = M; g.N = N; g.K = W;
             return launch_gemm_algo(g, epi, 0, st, probe);
@@ -173,7 +174,7 @@ int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int 
             GemmArgs g{};
             g.A = A; g.W = at<unsigned short>(blob, w_off); g.bias = at<float>(blob, b_off);
             g.M = M; g.N = W; g.K = K;
-            g.xhi = w.xhi; g.xlo = w.xlo; g.ln_part = w.ln_part; g.tmp_f32 = w.x;
+            g.x3 = w.x3; g.ln_part = w.ln_part; g.tmp_f32 = w.x;
             return launch_gemm_algo(g, EPI_BIAS_RESID_LN_F32, 0, st, probe);
         };
         // (the caller left the embedded rows split: ln_pre writes hi / lo / partials itself; the text tower, which has no
@@ -259,7 +260,7 @@ int run_head(const clipmi_tower* t, const void* blob, const Ws& w, int B, const 
     const bool split = t->ln_fold && t->weight_format == 0;      // bf16 LN-folded towers keep the residual as (hi, lo)
     LnArgs ln{split ? nullptr : w.x, at<float>(blob, t->off_ln_post_w), at<float>(blob, t->off_ln_post_b), w.pooled, rowidx,
               row_step, B, t->width, 1};
-    ln.xhi = w.xhi; ln.xlo = w.xlo;        // split: the residual stream is (hi, lo)
+    ln.x3 = w.x3;                          // split: the residual stream is rows of (hi | lo)
     if (int rc = launch_layernorm(ln, st)) return rc;
     GemmArgs g{};
     g.A = w.pooled; g.W = at<unsigned short>(blob, t->off_out_proj); g.bias = nullptr; g.out = out;
@@ -309,7 +310,7 @@ static int encode_image_impl(const clipmi_tower* t, const void* blob_dev, const 
     CLIPMI_CHECK_LAUNCH("cls_rows_kernel");
     LnArgs ln{w.x, at<float>(blob_dev, t->off_ln_pre_w), at<float>(blob_dev, t->off_ln_pre_b), w.x, nullptr, 1, B * L, W, 0};
     const bool fold8 = t->ln_fold && t->weight_format == 1;
-    if (t->ln_fold && !fold8) { ln.out_hi = w.xhi; ln.out_lo = w.xlo; ln.out_part = w.ln_part; }     // straight into the split residual
+    if (t->ln_fold && !fold8) { ln.out_x3 = w.x3; ln.out_part = w.ln_part; }     // straight into the split residual
     if (int rc = launch_layernorm(ln, st)) return rc;       // ln_pre (ln_fold 0 / FP8: in place, each wave owns its row)
 #ifdef CLIPMI_DEV
     if (fold8)     // FP8 tower with folded LayerNorms: the embedded rows' e4m3 image + statistics for the first qkv GEMM
@@ -353,7 +354,7 @@ extern "C" int clipmi_encode_text(const clipmi_tower* t, const void* blob_dev, c
     } else
 #endif
     if (t->ln_fold) {
-        if (int rc = launch_split_stats(w.x, false, w.xhi, w.xlo, w.ln_part, Q * L, W, st)) return rc;
+        if (int rc = launch_split_stats(w.x, false, w.x3, w.ln_part, Q * L, W, st)) return rc;
     }
     if (int rc = run_layers(t, blob_dev, w, Q, 1, st, nullptr)) return rc;
     return run_head(t, blob_dev, w, Q, w.rowidx, 1, out_dev, normalize, st);

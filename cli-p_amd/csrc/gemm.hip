@@ -2,7 +2,6 @@
 #include "gemm256p.hpp"
 #include "gemm_skinny.hpp"
 #ifdef CLIPMI_DEV
-#include "gemm2w.hpp"      // measured slower: development builds only
 #endif
 #include "gemm256f8.hpp"
 #include <hip/hip_ext.h>
@@ -115,7 +114,7 @@ static int launch_epi256p(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
     return 0;
 }
 
-// The residual producer of the LN-folded layers (EPI_BIAS_RESID_LN_F32) updates the split residual (xhi, xlo) and leaves
+// The residual producer of the LN-folded layers (EPI_BIAS_RESID_LN_F32) updates the split residual rows (x3) and leaves
 // the new rows' statistics partials in g.ln_part. The persistent kernel's storers do all of it on their way out; every
 // other kernel writes acc + bias as f32 into g.tmp_f32 and split_stats_kernel (add form) does the rest in one
 // LayerNorm-sized pass. Both give the same bits (same adds in the same order, canonical statistics: gemm.hpp).
@@ -156,32 +155,16 @@ static int launch_skinny(const GemmArgs& g, int epi, hipStream_t st) {
     return set_err(CLIPMI_EINVAL, "gemm_skinny: epilogue %d", epi);
 }
 
-#ifdef CLIPMI_DEV
-// the residual producer as two co-resident workgroups per CU (gemm2w.hpp)
-static bool g2w_ok(const GemmArgs& g) { return g.N % 256 == 0 && g.N <= 1024 && g.K % 32 == 0 && g.K >= 64 && g.M >= 1; }
-static int launch_g2w(const GemmArgs& g, hipStream_t st, GemmProbe* probe) {
-    static thread_local int opted[64];
-    if (!lds_opted(opted)) {
-        if (hipFuncSetAttribute((const void*)gemm2w_resid_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G2W_LDS) != hipSuccess)
-            return set_err(CLIPMI_EHIP, "hipFuncSetAttribute(gemm2w, %d B LDS)", G2W_LDS);
-    }
-    const int grid = (g.N / 256) * ((g.M + 127) / 128);
-    (void)probe;
-    hipLaunchKernelGGL(gemm2w_resid_ln_kernel, dim3(grid), dim3(256), G2W_LDS, st, g);
-    CLIPMI_CHECK_LAUNCH("gemm2w_resid_ln_kernel");
-    return 0;
-}
-#endif
-
 // algo: 0 = choose by shape, 1 = force the 128x128 kernel, 2 = force the 256x256 kernel,
 //       3 = force the persistent 256x256 kernel
 int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmProbe* probe) {
     if (epi_is_ln(epi) && (!g.ln_part_in || !g.colsum || !g.bias || g.K % 256 != 0 || g.K > 1024))
         return set_err(CLIPMI_EINVAL, "gemm: LN-folded epilogue %d needs ln_part_in, colsum, bias and K %% 256 == 0, K <= 1024", epi);
     if (epi == EPI_BIAS_RESID_LN_F32 &&
-        (!g.xhi || !g.xlo || !g.ln_part || !g.tmp_f32 || g.N % 256 != 0 || g.N > 1024 ||
-         (const char*)g.xlo < (const char*)g.xhi || (const char*)g.xlo - (const char*)g.xhi >= (1ll << 31) - (long long)256 * g.N * 2))
-        return set_err(CLIPMI_EINVAL, "gemm: EPI_BIAS_RESID_LN_F32 needs xhi <= xlo < xhi + 2 GiB, ln_part, tmp_f32 and N %% 256 == 0, N <= 1024");
+        (!g.x3 || !g.ln_part || !g.tmp_f32 || g.N % 256 != 0 || g.N > 1024 || ((size_t)g.x3 & 15) != 0))
+        return set_err(CLIPMI_EINVAL, "gemm: EPI_BIAS_RESID_LN_F32 needs x3 (16-byte aligned), ln_part, tmp_f32 and N %% 256 == 0, N <= 1024");
+    if (g.lda_bytes && (g.lda_bytes % 16 != 0 || g.lda_bytes < 2u * (unsigned)g.K))
+        return set_err(CLIPMI_EINVAL, "gemm: lda_bytes %u (need a multiple of 16, >= 2 K)", g.lda_bytes);
 #ifndef CLIPMI_DEV
     if (algo == 4 || algo == 5) return set_err(CLIPMI_EUNSUPPORTED, "algo %d exists in the development build only (libclipmi_dev.so)", algo);
 #else
@@ -193,14 +176,7 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmP
         if (epi == EPI_F32) return launch_epi256wd<EPI_F32>(g, st);
         return set_err(CLIPMI_EINVAL, "gemm256 WD: epilogue %d", epi);
     }
-    if (algo == 4) {
-        if (epi != EPI_BIAS_RESID_LN_F32 || !g2w_ok(g) || !g.A || !g.W)
-            return set_err(CLIPMI_EINVAL, "gemm2w: the residual producer only (N %% 256 == 0, N <= 1024, K %% 32 == 0, K >= 64)");
-        return launch_g2w(g, st, probe);
-    }
-    // development A/B: CLIPMI_GEMM_G2W=<max K> sends the residual producer with K <= that to gemm2w (measured slower: DESIGN 4.4g)
-    static const int g2w_maxk = (int)dev_knob("CLIPMI_GEMM_G2W", 0);
-    if (algo == 0 && epi == EPI_BIAS_RESID_LN_F32 && g.K <= g2w_maxk && g.M >= 1024 && g2w_ok(g)) return launch_g2w(g, st, probe);
+    if (algo == 4) return set_err(CLIPMI_EUNSUPPORTED, "algo 4 (gemm2w, DESIGN 4.4g) was removed in round 5: measured slower in round 3, its sources are in the history");
 #endif
     const bool ok256 = g.N % 256 == 0 && g.K % 64 == 0 && g.K >= 128;
     if (algo == 2 && !ok256) return set_err(CLIPMI_EINVAL, "gemm256: N=%d K=%d (need N %% 256 == 0, K %% 64 == 0, K >= 128)", g.N, g.K);
@@ -242,10 +218,10 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmP
                 GemmArgs a = g, b = g;
                 a.M = rows_main;
                 b.M = g.M - rows_main;
-                b.A = g.A + (size_t)rows_main * g.K;
+                b.A = g.A + (size_t)rows_main * gemm_lda(g);
                 const size_t oe = (size_t)rows_main * g.N;
                 if (epi == EPI_BIAS_RESID_LN_F32) {
-                    b.xhi = g.xhi + oe; b.xlo = g.xlo + oe; b.tmp_f32 = g.tmp_f32 + oe;
+                    b.x3 = static_cast<char*>(g.x3) + (size_t)rows_main * resid_row_bytes(g.N); b.tmp_f32 = g.tmp_f32 + oe;
                     b.ln_part = g.ln_part + (size_t)rows_main * (g.N / 256) * 2;
                 } else if (epi_is_bf16_out(epi)) {
                     b.out = static_cast<unsigned short*>(g.out) + oe;
@@ -273,7 +249,7 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmP
         const int rc = skinny ? launch_skinny(t, EPI_F32, st) : use256 ? launch_epi256<EPI_F32>(t, st, pr) : launch_gemm(t, EPI_F32, st, pr);
         if (pr) pr->epi = saved_epi;
         if (rc) return rc;
-        return launch_split_stats(g.tmp_f32, true, g.xhi, g.xlo, g.ln_part, g.M, g.N, st);
+        return launch_split_stats(g.tmp_f32, true, g.x3, g.ln_part, g.M, g.N, st);
     }
     if (!use256) return launch_gemm(g, epi, st, probe);
     if (use256p) {
@@ -423,14 +399,15 @@ extern "C" int clipmi_dbg_gemm_bf16(const void* a_dev, const void* w_dev, const 
 }
 
 // Test hooks of the LN-folded layers (gemm.hpp). `epi` = EPI_LN_BIAS_BF16 (5) or EPI_LN_BIAS_QGELU_BF16 (6), bits 8-9
-// force a kernel as in clipmi_dbg_gemm_bf16. part_dev: [M][K/256][2] statistics partials of the rows behind xhi.
-extern "C" int clipmi_dbg_gemm_ln(const void* xhi_dev, const void* wg_dev, const float* cb_dev, const float* colsum_dev,
+// force a kernel as in clipmi_dbg_gemm_bf16. part_dev: [M][K/256][2] statistics partials of the split rows x3_dev ([K bf16 hi | K u8 lo] each).
+extern "C" int clipmi_dbg_gemm_ln(const void* x3_dev, const void* wg_dev, const float* cb_dev, const float* colsum_dev,
                                   const float* part_dev, void* out_dev, int M, int N, int K, int epi, void* stream) {
     const int algo = (epi >> 8) & 3;
     epi &= 0xff;
     if (!epi_is_ln(epi)) return set_err(CLIPMI_EINVAL, "dbg_gemm_ln: epi %d", epi);
     GemmArgs g{};
-    g.A = static_cast<const unsigned short*>(xhi_dev);
+    g.A = static_cast<const unsigned short*>(x3_dev);                 // the hi halves of the split rows are the A operand
+    g.lda_bytes = (unsigned)resid_row_bytes(K);
     g.W = static_cast<const unsigned short*>(wg_dev);
     g.bias = cb_dev; g.colsum = colsum_dev; g.ln_part_in = part_dev;
     g.out = out_dev;
@@ -438,17 +415,16 @@ extern "C" int clipmi_dbg_gemm_ln(const void* xhi_dev, const void* wg_dev, const
     return launch_gemm_algo(g, epi, algo, as_stream(stream));
 }
 
-// (xhi, xlo) (split residual, bf16 [M][N] each, updated in place) += a @ w^T + bias; part = statistics partials of the
+// x3 (split residual rows [N bf16 hi | N u8 lo], updated in place) += a @ w^T + bias; part = statistics partials of the
 // new rows [M][N/256][2]; tmp_dev: f32 [M][N] scratch. algo as in clipmi_dbg_gemm_bf16 (3 = the persistent kernel's fused
 // store pass; 1 / 2 = GEMM into tmp + split_stats_kernel).
-extern "C" int clipmi_dbg_gemm_resid_ln(const void* a_dev, const void* w_dev, const float* bias_dev, void* xhi_dev,
-                                        void* xlo_dev, float* part_dev, float* tmp_dev, int M, int N, int K, int algo,
-                                        void* stream) {
+extern "C" int clipmi_dbg_gemm_resid_ln(const void* a_dev, const void* w_dev, const float* bias_dev, void* x3_dev,
+                                        float* part_dev, float* tmp_dev, int M, int N, int K, int algo, void* stream) {
     GemmArgs g{};
     g.A = static_cast<const unsigned short*>(a_dev);
     g.W = static_cast<const unsigned short*>(w_dev);
     g.bias = bias_dev;
-    g.xhi = static_cast<unsigned short*>(xhi_dev); g.xlo = static_cast<unsigned short*>(xlo_dev);
+    g.x3 = x3_dev;
     g.ln_part = part_dev; g.tmp_f32 = tmp_dev;
     g.M = M; g.N = N; g.K = K;
     static const int dbg_env = (int)dev_knob("CLIPMI_GEMM_DBG", 0);

@@ -81,8 +81,8 @@ __global__ void __launch_bounds__(512, 2) gemm256_bf16_nt_kernel(GemmArgs g) {
         int ma = m0 + row, mb = m0 + 128 + row;
         ma = ma < g.M ? ma : g.M - 1;
         mb = mb < g.M ? mb : g.M - 1;
-        src[0][i] = g.A + (size_t)ma * K + chunk;
-        src[1][i] = g.A + (size_t)mb * K + chunk;
+        src[0][i] = g.A + (size_t)ma * gemm_lda(g) + chunk;
+        src[1][i] = g.A + (size_t)mb * gemm_lda(g) + chunk;
         src[2][i] = g.W + (size_t)(n0 + row) * K + chunk;
         src[3][i] = g.W + (size_t)(n0 + 128 + row) * K + chunk;
     }

@@ -70,6 +70,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     const int ntn = g.N >> 8, mtiles = (g.M + 255) >> 8, ntiles = ntn * mtiles;
     const int K = g.K;
     const unsigned KB = FP8 ? (unsigned)K : 2u * (unsigned)K;      // bytes per operand row
+    const unsigned LDA = g.lda_bytes ? g.lda_bytes : KB;           // bytes between two A rows (split-residual rows: 3 K)
     const int nk = (int)(KB >> 7);
     const int stride = gridDim.x;
     int v = blockIdx.x;
@@ -104,9 +105,9 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
             for (int i = 0; i < 4; ++i) {
                 int lr = h * 128 + wn * 32 + i * 8 + sr_;
                 lr = lr < last ? lr : last;
-                avoff[h][i] = (unsigned)lr * KB + lane_chunk;
+                avoff[h][i] = (unsigned)lr * LDA + lane_chunk;
             }
-        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(g.A) + (size_t)mm * KB), 0, 0x7fffffff, 0x00020000);
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(g.A) + (size_t)mm * LDA), 0, 0x7fffffff, 0x00020000);
         rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(g.W) + (size_t)nn * KB), 0, 0x7fffffff, 0x00020000);
     };
     const int dma_off = wn * 32 * 128;
@@ -136,20 +137,25 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
     // (rows past M are clamped to row M-1: never stored).
     __amdgpu_buffer_rsrc_t rsO;
     int last_lr = 0;
+    // RLN: a residual row is [N bf16 hi | N u8 lo] (gemm.hpp): a piece = [256 hi values | 256 lo values] of one row and
+    // tile, 768 bytes: lanes 0-31 fetch hi, lanes 32-47 lo, lanes 48-63 nothing (the LDS row keeps its 1-KiB pitch). The
+    // descriptor sits at the tile's first hi value; the lo lanes' offset to their bytes depends on the tile's column
+    // (hi moves 2 bytes per column, lo 1), so the lane offset is rebuilt with the descriptor.
+    unsigned resid_lane_off = (unsigned)lane * 16u;
     auto set_out = [&](int mm, int nn) {
         if constexpr (RLN) {
-            // split residual: one descriptor based at the tile's first hi row covers hi and lo (xlo - xhi < 2^31 bytes)
-            rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(g.xhi + (size_t)mm * g.N + nn), 0, 0x7fffffff, 0x00020000);
+            rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<char*>(g.x3) + (size_t)mm * (3u * (unsigned)g.N) + 2u * (unsigned)nn),
+                                                    0, 0x7fffffff, 0x00020000);
             last_lr = g.M - 1 - mm;
+            int l_;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+            resid_lane_off = l_ < 32 ? (unsigned)l_ * 16u : 2u * (unsigned)g.N - (unsigned)nn + (unsigned)(l_ - 32) * 16u;
         } else if constexpr (RESID) {
             rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<float*>(g.out) + (size_t)mm * g.N + nn), 0, 0x7fffffff, 0x00020000);
             last_lr = g.M - 1 - mm;
         }
     };
-    // RLN: a 1-KiB piece = [256 hi values | 256 lo values] of one row: lanes 0-31 fetch hi, lanes 32-63 lo
-    const unsigned resid_lane_off = RLN ? (unsigned)(lane & 31) * 16u + (unsigned)(lane >> 5) * (unsigned)((const char*)g.xlo - (const char*)g.xhi)
-                                        : (unsigned)lane * 16u;
-    const unsigned resid_row_bytes = (unsigned)g.N * (RLN ? 2u : 4u);
+    const unsigned resid_row_bytes = (unsigned)g.N * (RLN ? 3u : 4u);
 #define P_ISSUE_RESID(H, rbase)                                                                                       \
     do {                                                                                                              \
         if (loader) {                                                                                                 \
@@ -158,8 +164,9 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
                 int lr_ = (rbase) + wn * 4 + i_;                                                                      \
                 lr_ = lr_ < last_lr ? lr_ : last_lr;                                                                  \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, d_ + i_ * 1024, 16, resid_lane_off,                     \
-                                                         (unsigned)lr_ * resid_row_bytes, 0, 0);                      \
+                if (!RLN || (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) < 48)            \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, d_ + i_ * 1024, 16, resid_lane_off,                 \
+                                                             (unsigned)lr_ * resid_row_bytes, 0, 0);                  \
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
@@ -533,48 +540,57 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                                 *reinterpret_cast<f32x4*>(outf + (size_t)m * g.N + n0 + lane * 4) = xs[i] + rs[i];
                         }
                     } else {
-                        // split residual (gemm.hpp): old rows = hi + lo from the DMA'd pieces ([256 hi | 256 lo] per row),
-                        // new rows o = (acc + bias) + old -> hi' = bf16(o), lo' = bf16(o - hi'), and this tile's share of the
-                        // row statistics (canonical order). Two groups of four rows (12 reads in flight each): fewer live
+                        // split residual (gemm.hpp): old rows from the DMA'd pieces ([256 bf16 hi | 256 u8 lo] per row),
+                        // new rows o = (acc + bias) + old -> (hi', lo') by split_make, and this tile's share of the row
+                        // statistics (canonical order). Two groups of four rows (12 reads in flight each): fewer live
                         // row registers than the plain form, which keeps this variant out of scratch (a reload costs a
                         // storer a vmcnt(0) = all its stores).
-                        const unsigned ra2 = ra - lane * 8;                      // + lane * 8 instead of lane * 16
+                        const unsigned ra2 = ra - lane * 8;                      // hi: + lane * 8 instead of lane * 16
+                        const unsigned ra3 = ra - lane * 12 + 512;               // lo: + 512 + lane * 4
+                        char* const x3 = static_cast<char*>(g.x3);
+                        const unsigned row_pitch = 3u * (unsigned)g.N;
+                        // where this lane's ONE 16-byte store of a row goes (bytes from the row's start): lanes 4k, 4k + 2 write
+                        // hi of 8 columns each, lane 4k + 1 lo of the quad's 16 columns, lane 4k + 3 nothing
+                        const unsigned st_off = (lane & 1) ? 2u * (unsigned)g.N + (unsigned)n0 + (unsigned)(lane & ~3) * 4u
+                                                           : ((unsigned)n0 + (unsigned)(lane & ~1) * 4u) * 2u;
 #pragma unroll
                         for (int hgrp = 0; hgrp < 2; ++hgrp) {
-                            f32x4 x0, x1, x2, x3;
-                            uint2 h0, h1, h2, h3, l0, l1, l2, l3;
-                            const unsigned rb = ra2 + hgrp * 4096;
+                            f32x4 x0, x1, x2, x3_;
+                            uint2 h0, h1, h2, h3;
+                            unsigned l0, l1, l2, l3;
+                            const unsigned rb = ra2 + hgrp * 4096, rl = ra3 + hgrp * 4096;
                             asm volatile(
                                 "ds_read_b128 %0, %12\n\tds_read_b128 %1, %13\n\tds_read_b128 %2, %14\n\tds_read_b128 %3, %15\n\t"
                                 "ds_read_b64 %4, %16\n\tds_read_b64 %5, %16 offset:1024\n\tds_read_b64 %6, %16 offset:2048\n\t"
                                 "ds_read_b64 %7, %16 offset:3072\n\t"
-                                "ds_read_b64 %8, %16 offset:512\n\tds_read_b64 %9, %16 offset:1536\n\tds_read_b64 %10, %16 offset:2560\n\t"
-                                "ds_read_b64 %11, %16 offset:3584\n\ts_waitcnt lgkmcnt(0)"
-                                : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3),
+                                "ds_read_b32 %8, %17\n\tds_read_b32 %9, %17 offset:1024\n\tds_read_b32 %10, %17 offset:2048\n\t"
+                                "ds_read_b32 %11, %17 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                                : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3_), "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3),
                                   "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
-                                : "v"(aa[4 * hgrp]), "v"(aa[4 * hgrp + 1]), "v"(aa[4 * hgrp + 2]), "v"(aa[4 * hgrp + 3]), "v"(rb)
+                                : "v"(aa[4 * hgrp]), "v"(aa[4 * hgrp + 1]), "v"(aa[4 * hgrp + 2]), "v"(aa[4 * hgrp + 3]), "v"(rb), "v"(rl)
                                 : "memory");
-                            const f32x4 xs[4] = {x0, x1, x2, x3};
+                            const f32x4 xs[4] = {x0, x1, x2, x3_};
                             const uint2 hs[4] = {h0, h1, h2, h3};
-                            const uint2 ls[4] = {l0, l1, l2, l3};
+                            const unsigned ls[4] = {l0, l1, l2, l3};
 #pragma unroll
                             for (int i4 = 0; i4 < 4; ++i4) {
                                 const int i = 4 * hgrp + i4;
                                 const f32x4 o = xs[i4] + split_join(hs[i4], ls[i4]);
                                 const int m = m0 + lr0 + i;
-                                // lanes l and l ^ 1 trade halves (two DPP quad_perm moves, no LDS traffic): the even one ends
-                                // with hi of 8 columns, the odd one with lo of the same 8: ONE 16-byte store per lane and row,
-                                // as the plain residual form issues, instead of two 8-byte ones
-                                uint2 nh, nl;
+                                uint2 nh;
+                                unsigned nl;
                                 split_make(o, nh, nl);
-                                const uint2 give = (lane & 1) ? nh : nl;
+                                // lanes l and l ^ 1 trade hi halves, lane 4k + 1 gathers the quad's four lo words (DPP quad_perm
+                                // moves, no LDS traffic): ONE 16-byte store per storing lane and row
                                 uint2 got;
-                                got.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)give.x, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-                                got.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)give.y, 0xB1, 0xf, 0xf, false);
-                                if (m < g.M && !(g.dbg & 1)) {
-                                    unsigned short* dst = ((lane & 1) ? g.xlo : g.xhi) + (size_t)m * g.N + n0 + (lane & ~1) * 4;
-                                    gp_store16<2>(dst, (lane & 1) ? make_uint4(got.x, got.y, nl.x, nl.y) : make_uint4(nh.x, nh.y, got.x, got.y));
-                                }
+                                got.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)nh.x, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+                                got.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)nh.y, 0xB1, 0xf, 0xf, false);
+                                const unsigned q0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)nl, 0x00, 0xf, 0xf, false);   // [0,0,0,0]
+                                const unsigned q2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)nl, 0xAA, 0xf, 0xf, false);   // [2,2,2,2]
+                                const unsigned q3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)nl, 0xFF, 0xf, 0xf, false);   // [3,3,3,3]
+                                if (m < g.M && (lane & 3) != 3 && !(g.dbg & 1))
+                                    gp_store16<2>(x3 + (size_t)m * row_pitch + st_off,
+                                                  (lane & 1) ? make_uint4(q0, nl, q2, q3) : make_uint4(nh.x, nh.y, got.x, got.y));
                                 sa[i] = ln_lane_sum(o);
                                 sq[i] = ln_lane_sumsq(o);
                             }

@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g) {
     const bool valid = am < g.M;
     am = valid ? am : g.M - 1;                                   // M tail: duplicate the last row, masked at the store
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(g.W + (size_t)(n0 + fr) * K + 8 * fg);
-    const bf16x8* ap = reinterpret_cast<const bf16x8*>(g.A + (size_t)am * K + 8 * fg);
+    const bf16x8* ap = reinterpret_cast<const bf16x8*>(g.A + (size_t)am * gemm_lda(g) + 8 * fg);
     const int nk = K >> 5;                                       // K-steps of 32: 4 bf16x8 apart
 
     // the epilogue's operands are requested first: their round trip then runs under the K-walk's instead of behind it (in a

@@ -8,19 +8,18 @@ namespace clipmi {
 int launch_layernorm(const LnArgs& a, hipStream_t st) {
     if (a.M < 1) return 0;
     if (a.W % 4 != 0 || a.W > 1024) return set_err(CLIPMI_EINVAL, "layernorm: W=%d (need W %% 4 == 0, W <= 1024)", a.W);
-    if (a.out_hi && (a.W % 256 != 0 || !a.out_lo || !a.out_part)) return set_err(CLIPMI_EINVAL, "layernorm: split output needs W %% 256 == 0");
+    if (a.out_x3 && (a.W % 256 != 0 || !a.out_part)) return set_err(CLIPMI_EINVAL, "layernorm: split output needs W %% 256 == 0");
     hipLaunchKernelGGL(layernorm_kernel, dim3((a.M + 3) / 4), dim3(256), 0, st, a);
     CLIPMI_CHECK_LAUNCH("layernorm_kernel");
     return 0;
 }
 
-int launch_split_stats(const float* x_or_add, bool add, unsigned short* xhi, unsigned short* xlo, float* part, int M, int W,
-                       hipStream_t st) {
+int launch_split_stats(const float* x_or_add, bool add, void* x3, float* part, int M, int W, hipStream_t st) {
     if (M < 1) return 0;
-    if (!x_or_add || !xhi || !xlo || !part || W % 256 != 0 || W < 256 || W > 1024)
+    if (!x_or_add || !x3 || !part || W % 256 != 0 || W < 256 || W > 1024)
         return set_err(CLIPMI_EINVAL, "split_stats: W=%d (need W %% 256 == 0, 256 <= W <= 1024)", W);
-    if (add) hipLaunchKernelGGL(split_stats_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x_or_add, xhi, xlo, part, M, W);
-    else hipLaunchKernelGGL(split_stats_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x_or_add, xhi, xlo, part, M, W);
+    if (add) hipLaunchKernelGGL(split_stats_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x_or_add, x3, part, M, W);
+    else hipLaunchKernelGGL(split_stats_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x_or_add, x3, part, M, W);
     CLIPMI_CHECK_LAUNCH("split_stats_kernel");
     return 0;
 }
@@ -165,8 +164,6 @@ extern "C" int clipmi_dbg_quantize_rows_fp8mx(const void* in_bf16_dev, void* out
                                       static_cast<unsigned char*>(bscale_dev), M, K, as_stream(stream));
 }
 
-extern "C" int clipmi_dbg_split_stats(const float* x_dev, int add, void* xhi_dev, void* xlo_dev, float* part_dev, int M, int W,
-                                      void* stream) {
-    return launch_split_stats(x_dev, add != 0, static_cast<unsigned short*>(xhi_dev), static_cast<unsigned short*>(xlo_dev),
-                              part_dev, M, W, as_stream(stream));
+extern "C" int clipmi_dbg_split_stats(const float* x_dev, int add, void* x3_dev, float* part_dev, int M, int W, void* stream) {
+    return launch_split_stats(x_dev, add != 0, x3_dev, part_dev, M, W, as_stream(stream));
 }

@@ -178,13 +178,11 @@ struct LnArgs {
     // quantize_rows_fp8_kernel would make of the bf16 row (the values are rounded to bf16 first)
     unsigned char* out8;
     float* scale8;
-    // split-residual input (gemm.hpp): when x == nullptr the source rows are xhi + xlo (bf16 each)
-    const unsigned short* xhi;
-    const unsigned short* xlo;
-    // split-residual OUTPUT (ln_pre of an LN-folded tower): when out_hi is set the normalised row leaves as hi / lo
-    // bf16 halves plus its canonical statistics partials [M][W/256][2] (what split_stats_kernel would make of it)
-    unsigned short* out_hi;
-    unsigned short* out_lo;
+    // split-residual input (gemm.hpp): when x == nullptr the source rows are the split rows x3 ([W bf16 hi | W u8 lo] each)
+    const void* x3;
+    // split-residual OUTPUT (ln_pre of an LN-folded tower): when out_x3 is set the normalised row leaves as a split row
+    // plus its canonical statistics partials [M][W/256][2] (what split_stats_kernel would make of it)
+    void* out_x3;
     float* out_part;
 };
 
@@ -202,8 +200,8 @@ static __global__ void __launch_bounds__(256) layernorm_kernel(LnArgs a) {
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < a.W) {
             if (a.x) v[i] = *reinterpret_cast<const f32x4*>(p + c);
-            else v[i] = split_join(*reinterpret_cast<const uint2*>(a.xhi + src_row * a.W + c),
-                                   *reinterpret_cast<const uint2*>(a.xlo + src_row * a.W + c));
+            else v[i] = split_join(*reinterpret_cast<const uint2*>(resid_hi(a.x3, (size_t)src_row, a.W) + c),
+                                   *reinterpret_cast<const unsigned*>(resid_lo(a.x3, (size_t)src_row, a.W) + c));
         }
         s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
@@ -254,7 +252,7 @@ static __global__ void __launch_bounds__(256) layernorm_kernel(LnArgs a) {
         if (lane == 0) a.scale8[r] = sc;
         return;
     }
-    if (a.out_hi) {              // W % 256 == 0 (checked by the launcher): segment i = columns 256 i .. 256 i + 255
+    if (a.out_x3) {              // W % 256 == 0 (checked by the launcher): segment i = columns 256 i .. 256 i + 255
         const int nseg = a.W >> 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -263,10 +261,11 @@ static __global__ void __launch_bounds__(256) layernorm_kernel(LnArgs a) {
                 const f32x4 g = *reinterpret_cast<const f32x4*>(a.w + c);
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(a.b + c);
                 const f32x4 y = (v[i] - mean) * rstd * g + bb;
-                uint2 nh, nl;
+                uint2 nh;
+                unsigned nl;
                 split_make(y, nh, nl);
-                *reinterpret_cast<uint2*>(a.out_hi + (size_t)r * a.W + c) = nh;
-                *reinterpret_cast<uint2*>(a.out_lo + (size_t)r * a.W + c) = nl;
+                *reinterpret_cast<uint2*>(resid_hi(a.out_x3, (size_t)r, a.W) + c) = nh;
+                *reinterpret_cast<unsigned*>(resid_lo(a.out_x3, (size_t)r, a.W) + c) = nl;
                 const float sa = ln_wave_sum(ln_lane_sum(y));
                 const float sq = ln_wave_sum(ln_lane_sumsq(y));
                 if (lane == 0) *reinterpret_cast<f32x2*>(a.out_part + ((size_t)r * nseg + i) * 2) = f32x2{sa, sq};
@@ -292,30 +291,33 @@ static __global__ void __launch_bounds__(256) layernorm_kernel(LnArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // LN-folded layers (gemm.hpp): the stand-alone producer of the split residual and its row statistics,
-//   rows = ADD ? add[m][:] + (hi + lo)[m][:] : x[m][:];   hi = bf16(rows), lo = bf16(rows - hi),
+//   rows = ADD ? add[m][:] + x3[m][:] : x[m][:];   x3[m] = split_make(rows) (gemm.hpp: W bf16 hi | W u8 lo),
 //   part[m][j] = (sum, sum of squares) of columns 256 j .. 256 j + 255
 // used where the persistent residual GEMM's own store pass is not available (the embedded rows after ln_pre; residual
 // GEMMs that run on the non-persistent kernels, whose acc + bias arrive as f32 in `add`). One wave per row,
 // W % 256 == 0, W <= 1024; statistics in the canonical order (same bits as gemm256p's storers).
 // ---------------------------------------------------------------------------------------------
 template <bool ADD>
-static __global__ void __launch_bounds__(256) split_stats_kernel(const float* __restrict__ x, unsigned short* xhi,
-                                                                 unsigned short* xlo, float* __restrict__ part, int M, int W) {
+static __global__ void __launch_bounds__(256) split_stats_kernel(const float* __restrict__ x, void* x3, float* __restrict__ part,
+                                                                 int M, int W) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
     const int nseg = W >> 8;
     const float* p = x + (size_t)r * W;
+    unsigned short* const hrow = resid_hi(x3, (size_t)r, W);
+    unsigned char* const lrow = resid_lo(x3, (size_t)r, W);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (j < nseg) {
-            const size_t at_ = (size_t)r * W + j * 256 + lane * 4;
-            f32x4 v = *reinterpret_cast<const f32x4*>(p + j * 256 + lane * 4);
-            if (ADD) v = v + split_join(*reinterpret_cast<const uint2*>(xhi + at_), *reinterpret_cast<const uint2*>(xlo + at_));
-            uint2 nh, nl;
+            const int c = j * 256 + lane * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
+            if (ADD) v = v + split_join(*reinterpret_cast<const uint2*>(hrow + c), *reinterpret_cast<const unsigned*>(lrow + c));
+            uint2 nh;
+            unsigned nl;
             split_make(v, nh, nl);
-            *reinterpret_cast<uint2*>(xhi + at_) = nh;
-            *reinterpret_cast<uint2*>(xlo + at_) = nl;
+            *reinterpret_cast<uint2*>(hrow + c) = nh;
+            *reinterpret_cast<unsigned*>(lrow + c) = nl;
             const float sa = ln_wave_sum(ln_lane_sum(v));
             const float sq = ln_wave_sum(ln_lane_sumsq(v));
             if (lane == 0) *reinterpret_cast<f32x2*>(part + ((size_t)r * nseg + j) * 2) = f32x2{sa, sq};

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CLIPMI_ABI_VERSION 4
+#define CLIPMI_ABI_VERSION 5
 
 enum {
     CLIPMI_OK = 0,
@@ -294,15 +294,16 @@ int clipmi_dbg_gemm_fp8(const void* a8_dev, const void* w8_dev, const float* a_s
                         const float* bias_dev, void* out_dev, int M, int N, int K, int epi, void* stream);
 
 /* LN-folded linear layers (tower ABI 3, csrc/gemm.hpp), kernel by kernel:
- *   split_stats   rows = add ? x + (hi + lo) : x (f32 [M][W]) -> hi = bf16(rows), lo = bf16(rows - hi), part [M][W/256][2]
+ * The residual stream is kept SPLIT (3 bytes per element since round 5 / ABI 5): a row of width W is W bf16 values hi = bf16(x)
+ * followed by W biased 8-bit remainders u, bits(x') = (bits(hi) << 16) + (u << 8) - 0x8000 - x to 15 mantissa bits; `x3` buffers are [M][3 W] bytes.
+ *   split_stats   rows = add ? x + x3 : x (f32 [M][W]) -> x3 = the split rows, part [M][W/256][2]
  *                 = per-256-column (sum, sum of squares)                                           (W % 256 == 0, <= 1024)
- *   gemm_ln       out bf16 = [quick_gelu] (rstd * (xhi wg^T - mean * colsum) + cb), (mean, rstd) from part; epi 5 | 6,
+ *   gemm_ln       out bf16 = [quick_gelu] (rstd * (hi(x3) wg^T - mean * colsum) + cb), (mean, rstd) from part; epi 5 | 6,
  *                 bits 8-9 force a kernel
- *   gemm_resid_ln (xhi, xlo) += a w^T + bias, part of the new rows; tmp = f32 [M][N] scratch; algo 3 = the persistent
+ *   gemm_resid_ln x3 += a w^T + bias, part of the new rows; tmp = f32 [M][N] scratch; algo 3 = the persistent
  *                 kernel's fused store pass, else GEMM into tmp + split_stats(add) */
-int clipmi_dbg_split_stats(const float* x_dev, int add, void* xhi_dev, void* xlo_dev, float* part_dev, int M, int W,
-                           void* stream);
-int clipmi_dbg_gemm_ln(const void* xhi_dev, const void* wg_dev, const float* cb_dev, const float* colsum_dev,
+int clipmi_dbg_split_stats(const float* x_dev, int add, void* x3_dev, float* part_dev, int M, int W, void* stream);
+int clipmi_dbg_gemm_ln(const void* x3_dev, const void* wg_dev, const float* cb_dev, const float* colsum_dev,
                        const float* part_dev, void* out_dev, int M, int N, int K, int epi, void* stream);
 /* MX block scales (round 3): e4m3 activations with one e8m0 scale per 32 consecutive values of a row, 2^(e - 7) with
  * e = floor(log2(largest magnitude of the block)). clipmi_dbg_quantize_rows_fp8mx: bf16 [M][K] -> e4m3 [M][K] + scale
@@ -312,8 +313,8 @@ int clipmi_dbg_gemm_ln(const void* xhi_dev, const void* wg_dev, const float* cb_
 int clipmi_dbg_quantize_rows_fp8mx(const void* in_bf16_dev, void* out_fp8_dev, void* bscale_dev, int M, int K, void* stream);
 int clipmi_dbg_gemm_fp8_bsa(const void* a8_dev, const void* w8_dev, const void* a_bscale_dev, const float* w_scale_dev,
                             const float* bias_dev, void* out_dev, int M, int N, int K, int epi, void* stream);
-int clipmi_dbg_gemm_resid_ln(const void* a_dev, const void* w_dev, const float* bias_dev, void* xhi_dev, void* xlo_dev,
-                             float* part_dev, float* tmp_dev, int M, int N, int K, int algo, void* stream);
+int clipmi_dbg_gemm_resid_ln(const void* a_dev, const void* w_dev, const float* bias_dev, void* x3_dev, float* part_dev,
+                             float* tmp_dev, int M, int N, int K, int algo, void* stream);
 
 /* clipmi_encode_image `reps` times with HIP events around every launch of the GEMM whose
  * epilogue is `probe_epi` (1 = MLP c_fc + QuickGELU), on `stream`; synchronises;

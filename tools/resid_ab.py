@@ -12,20 +12,17 @@ for (M, N, K) in ((43500, 768, 768), (43500, 768, 3072)):
     w = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16)
     bias = torch.randn(N, generator=g, device=dev)
     x = torch.randn(M, N, generator=g, device=dev)
-    hl = torch.zeros(2, M, N, dtype=torch.bfloat16, device=dev)
+    x3 = torch.zeros(M, 3 * N, dtype=torch.uint8, device=dev)        # split rows: N bf16 hi | N int8 lo
     part = torch.zeros(M, N // 256, 2, device=dev)
     tmp = torch.zeros(M, N, device=dev)
     def plain():
         clipmi._lib.check(L.clipmi_dbg_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), x.data_ptr(), M, N, K, 2 | (3 << 8), None), "gemm")
     def rln():
-        clipmi._lib.check(L.clipmi_dbg_gemm_resid_ln(a.data_ptr(), w.data_ptr(), bias.data_ptr(), hl[0].data_ptr(), hl[1].data_ptr(),
+        clipmi._lib.check(L.clipmi_dbg_gemm_resid_ln(a.data_ptr(), w.data_ptr(), bias.data_ptr(), x3.data_ptr(),
                                                      part.data_ptr(), tmp.data_ptr(), M, N, K, 3, None), "rln")
-    def g2w():
-        clipmi._lib.check(L.clipmi_dbg_gemm_resid_ln(a.data_ptr(), w.data_ptr(), bias.data_ptr(), hl[0].data_ptr(), hl[1].data_ptr(),
-                                                     part.data_ptr(), tmp.data_ptr(), M, N, K, 4, None), "g2w")
-    res = {"plain": [], "rln": [], "g2w": []}
+    res = {"plain": [], "rln": []}
     for rnd in range(5):
-        for name, fn in (("plain", plain), ("rln", rln), ("g2w", g2w)):
+        for name, fn in (("plain", plain), ("rln", rln)):
             for _ in range(3): fn()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -33,5 +30,5 @@ for (M, N, K) in ((43500, 768, 768), (43500, 768, 3072)):
             for _ in range(20): fn()
             e1.record(); torch.cuda.synchronize()
             res[name].append(e0.elapsed_time(e1) / 20 * 1e3)
-            x.zero_(); hl.zero_()
-    print(f"M={M} N={N} K={K}: plain {min(res['plain']):.1f} us   split-residual + stats {min(res['rln']):.1f} us   two workgroups per CU {min(res['g2w']):.1f} us", flush=True)
+            x.zero_(); x3.zero_()
+    print(f"M={M} N={N} K={K}: plain {min(res['plain']):.1f} us   split-residual + stats {min(res['rln']):.1f} us", flush=True)
