@@ -92,10 +92,40 @@ __device__ __forceinline__ float ln_lane_sumsq(f32x4 v) {
     q = __builtin_fmaf(v.z, v.z, q);
     return __builtin_fmaf(v.w, v.w, q);
 }
-// all 64 lanes end with the wave total; the xor order is part of the contract
+// Lane exchanges of the statistics reductions WITHOUT the LDS crossbar (round 5; __shfl_xor is ds_bpermute_b32: an LDS round trip
+// per step of a dependent chain - six of them per 32-row sub-pass of the residual producer's store pass): v_permlane32_swap /
+// v_permlane16_swap exchange half-waves / 16-lane rows of two registers, DPP row_ror / row_shl / row_shr / quad_perm do the rest.
+template <int CTRL>
+__device__ __forceinline__ float lane_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_xor8(float v) { return lane_dpp<0x128>(v); }                 // row_ror:8
+__device__ __forceinline__ float lane_xor4(float v, bool bit2) {                                    // bit2 = lane & 4
+    const float up = lane_dpp<0x104>(v), dn = lane_dpp<0x114>(v);     // row_shl:4 (from lane + 4), row_shr:4 (from lane - 4)
+    return bit2 ? dn : up;
+}
+__device__ __forceinline__ float lane_xor2(float v) { return lane_dpp<0x4E>(v); }                  // quad_perm [2,3,0,1]
+__device__ __forceinline__ float lane_xor1(float v) { return lane_dpp<0xB1>(v); }                  // quad_perm [1,0,3,2]
+// lanes 0-31: a + a of lane + 32; lanes 32-63: b + b of lane - 32 (the xor-32 step of two butterflies at once, each lane keeping
+// the half it is responsible for); with a == b: every lane's v + v of lane ^ 32
+__device__ __forceinline__ float lane_fold32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// rows of 16 lanes: even rows a + a of lane + 16, odd rows b + b of lane - 16
+__device__ __forceinline__ float lane_fold16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// all 64 lanes end with the wave total; the xor order (32, 16, 8, 4, 2, 1) is part of the contract
 __device__ __forceinline__ float ln_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    const bool bit2 = (__builtin_amdgcn_mbcnt_lo(~0u, 0u) & 4u) != 0;
+    v = lane_fold32(v, v);
+    v = lane_fold16(v, v);
+    v += lane_xor8(v);
+    v += lane_xor4(v, bit2);
+    v += lane_xor2(v);
+    v += lane_xor1(v);
     return v;
 }
 // (mean, rstd) from per-segment (sum, sum of squares) partials, combined left to right

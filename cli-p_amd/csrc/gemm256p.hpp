@@ -596,26 +596,25 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                             }
                         }
                         // 8 rows x (sum, sum of squares) reduced TRANSPOSED over xor 32, 16, 8 (each lane keeps half of
-                        // what it held), then over 4, 2, 1: 20 lane exchanges instead of 96, the same adds as ln_wave_sum
-                        const bool h32 = lane & 32, h16 = lane & 16, h8 = lane & 8;
+                        // what it held), then over 4, 2, 1: the same adds as ln_wave_sum, by half-wave / row swaps and DPP
+                        // moves (gemm.hpp lane_fold32 ..: no LDS round trips; rounds 2-4 ran 20 ds_bpermute in six dependent steps)
+                        const bool h8 = lane & 8, bit2 = lane & 4;
                         float a4[4], q4[4], a2[2], q2[2];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            a4[j] = (h32 ? sa[j + 4] : sa[j]) + __shfl_xor(h32 ? sa[j] : sa[j + 4], 32);
-                            q4[j] = (h32 ? sq[j + 4] : sq[j]) + __shfl_xor(h32 ? sq[j] : sq[j + 4], 32);
+                            a4[j] = lane_fold32(sa[j], sa[j + 4]);
+                            q4[j] = lane_fold32(sq[j], sq[j + 4]);
                         }
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            a2[j] = (h16 ? a4[j + 2] : a4[j]) + __shfl_xor(h16 ? a4[j] : a4[j + 2], 16);
-                            q2[j] = (h16 ? q4[j + 2] : q4[j]) + __shfl_xor(h16 ? q4[j] : q4[j + 2], 16);
+                            a2[j] = lane_fold16(a4[j], a4[j + 2]);
+                            q2[j] = lane_fold16(q4[j], q4[j + 2]);
                         }
-                        float a1 = (h8 ? a2[1] : a2[0]) + __shfl_xor(h8 ? a2[0] : a2[1], 8);
-                        float q1 = (h8 ? q2[1] : q2[0]) + __shfl_xor(h8 ? q2[0] : q2[1], 8);
-#pragma unroll
-                        for (int o_ = 4; o_ >= 1; o_ >>= 1) {
-                            a1 += __shfl_xor(a1, o_);
-                            q1 += __shfl_xor(q1, o_);
-                        }
+                        float a1 = (h8 ? a2[1] : a2[0]) + lane_xor8(h8 ? a2[0] : a2[1]);
+                        float q1 = (h8 ? q2[1] : q2[0]) + lane_xor8(h8 ? q2[0] : q2[1]);
+                        a1 += lane_xor4(a1, bit2); q1 += lane_xor4(q1, bit2);
+                        a1 += lane_xor2(a1); q1 += lane_xor2(q1);
+                        a1 += lane_xor1(a1); q1 += lane_xor1(q1);
                         const int mrow = m0 + lr0 + (lane >> 3);          // the row this lane group ended up with
                         if ((lane & 7) == 0 && mrow < g.M && !(g.dbg & 1))
                             *reinterpret_cast<f32x2*>(g.ln_part + ((size_t)mrow * nseg + seg) * 2) = f32x2{a1, q1};
