@@ -25,6 +25,14 @@
 #pragma once
 #include "gemm256f8.hpp"
 
+// K-loop ablations of the persistent kernel, TIMING ONLY (wrong results; development library built with
+// CLIPMI_EXTRA_CXXFLAGS=-DCLIPMI_GEMM_ABL=n, tools/gpu_gemm_kloop_abl.sh): bit 0 = the second A half's 8 fragment
+// reads per K-tile are skipped (stale registers): 16 instead of 24 ds_read_b128 per wave and K-tile = the 256 B of LDS reads
+// per MFMA a 128 x 128 wave tile would have; bit 1 = the B-hi half-tile's DMA fetches ONE 16-byte chunk for all lanes (same
+// instruction count and LDS writes, a quarter less traffic beyond the CU); bit 2 = the same for A-hi (half the traffic with bit 1).
+#ifndef CLIPMI_GEMM_ABL
+#define CLIPMI_GEMM_ABL 0
+#endif
 #ifndef CLIPMI_GEMM_STAMPS
 #define CLIPMI_GEMM_STAMPS 0      // 1: in-kernel time stamps (tools/gp_stamps.py); costs a few % of the K-loop
 #endif
@@ -120,7 +128,11 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
                 (__attribute__((address_space(3))) char*)(smem + (buf) * G256_BUF + (H) * G256_HALF + dma_off);       \
             const unsigned ko_ = (unsigned)(kt) * 128u;                                                               \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
-                if ((H) < 2)                                                                                          \
+                if ((H) == 3 && (CLIPMI_GEMM_ABL & 2))                                                                \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, d_ + i_ * 1024, 16, 0u, 0u, 0, 0);                  \
+                else if ((H) == 1 && (CLIPMI_GEMM_ABL & 4))                                                           \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, d_ + i_ * 1024, 16, 0u, 0u, 0, 0);                  \
+                else if ((H) < 2)                                                                                     \
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, d_ + i_ * 1024, 16, avoff[(H) & 1][i_], ko_, 0, 0); \
                 else                                                                                                  \
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, d_ + i_ * 1024, 16, wvoff,                          \
@@ -257,7 +269,7 @@ __global__ void __launch_bounds__(512, 2) gemm256p_bf16_nt_kernel(GemmArgs g) {
         P_KSTAMP(3);                                                                                \
         P_MFMA(0, bh, 1);                                                                            \
         P_KSTAMP(4);                                                                                \
-        P_READ_A(CUR, 1);                                                                            \
+        if (!(CLIPMI_GEMM_ABL & 1)) { P_READ_A(CUR, 1); }                                            \
         if (PRE) P_SLOT(3, KT, NB);                                                                 \
         __builtin_amdgcn_s_barrier();                                                                \
         P_KSTAMP(5);                                                                                \
