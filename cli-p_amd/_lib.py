@@ -27,7 +27,7 @@ SYMBOLS = [
     "clipmi_l2_normalize_rows", "clipmi_resize_crop_rgb8", "clipmi_last_error", "clipmi_abi_version",
     "clipmi_dbg_gemm_bf16", "clipmi_dbg_layernorm", "clipmi_dbg_attention", "clipmi_dbg_topk_scan_ms",
     "clipmi_dbg_encode_image_probe_ms", "clipmi_dbg_encode_image_probe3_ms",
-    "clipmi_dbg_split_stats", "clipmi_dbg_gemm_ln", "clipmi_dbg_gemm_resid_ln", "clipmi_dbg_quantize_rows_fp8mx", "clipmi_dbg_gemm_fp8_bsa",
+    "clipmi_dbg_split_stats", "clipmi_dbg_gemm_ln", "clipmi_dbg_gemm_resid_ln", "clipmi_dbg_gemm_resid_ln_leaf", "clipmi_dbg_gemm_ln_leaf", "clipmi_dbg_quantize_rows_fp8mx", "clipmi_dbg_gemm_fp8_bsa",
 ]
 
 
@@ -137,6 +137,10 @@ def lib():
     L.clipmi_dbg_quantize_rows_fp8mx.argtypes = [vp, vp, vp, i32, i32, vp]
     L.clipmi_dbg_gemm_fp8_bsa.restype = i32
     L.clipmi_dbg_gemm_fp8_bsa.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.clipmi_dbg_gemm_resid_ln_leaf.restype = i32
+    L.clipmi_dbg_gemm_resid_ln_leaf.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.clipmi_dbg_gemm_ln_leaf.restype = i32
+    L.clipmi_dbg_gemm_ln_leaf.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.clipmi_dbg_gemm_resid_ln.restype = i32
     L.clipmi_dbg_gemm_resid_ln.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.clipmi_dbg_layernorm.restype = i32

@@ -34,6 +34,7 @@ struct Ws {
     void* x3;                 // ln_fold: the residual stream kept split, rows of [W bf16 hi | W u8 lo]; the hi halves are
                               //          also the A operand of the LN-folded qkv / c_fc GEMMs
     float* ln_part;           //          row statistics of x as per-256-column (sum, sum of squares) [B*L][W/256][2]
+    float* ln_leaf;           //          <= 128 rows (one prompt, one image): the statistics as per-4-column leaves [B*L][W/4][2]
 };
 
 size_t carve(const clipmi_tower* t, int B, void* base, size_t cap, Ws* out) {
@@ -60,6 +61,7 @@ size_t carve(const clipmi_tower* t, int B, void* base, size_t cap, Ws* out) {
     } else if (t->ln_fold) {
         w.x3 = ar.take<unsigned char>(rows * resid_row_bytes(W));
         w.ln_part = ar.take<float>(rows * 2 * (W / 256));
+        if (rows <= (size_t)SKINNY_MAX_M) w.ln_leaf = ar.take<float>(rows * 2 * (W / 4));
     }
     if (out) *out = w;
     return ar.off + 256;
@@ -162,11 +164,17 @@ int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int 
         // in w.x3 with its row statistics in w.ln_part; w.x (f32) is only the embedding stage's output and the
         // scratch of residual GEMMs that run on a non-persistent kernel. lo_qkv_w / lo_fc_w hold W * diag(ln weight).
         auto lb_of = [&](int l) { return t->off_layers + (uint64_t)l * t->layer_stride; };
+        // One prompt / one image (M <= 128: the skinny kernels, ~90 dependent launches of ~4 us): the residual GEMMs update the
+        // split rows themselves and hand the statistics on as leaves (GemmArgs.ln_leaf; round 5: 24 split / statistics launches
+        // fewer per tower). `leaves`: w.ln_leaf, not w.ln_part, describes the rows in w.x3.
+        const bool leaf_mode = w.ln_leaf != nullptr && gemm_resid_writes_leaves(M, W, W) && gemm_resid_writes_leaves(M, W, 4 * W);
+        bool leaves = false;
         auto ln_linear = [&](uint64_t w_off, uint64_t cb_off, uint64_t cs_off, int N, int epi) -> int {
             GemmArgs g{};
             g.A = static_cast<const unsigned short*>(w.x3); g.lda_bytes = (unsigned)resid_row_bytes(W);
             g.W = at<unsigned short>(blob, w_off); g.bias = at<float>(blob, cb_off);
             g.colsum = at<float>(blob, cs_off); g.ln_part_in = w.ln_part;
+            if (leaves) g.ln_leaf_in = w.ln_leaf;
             g.out = w.big; g.M = M; g.N = N; g.K = W;
             return launch_gemm_algo(g, epi, 0, st, probe);
         };
@@ -175,6 +183,7 @@ int run_layers(const clipmi_tower* t, const void* blob, const Ws& w, int B, int 
             g.A = A; g.W = at<unsigned short>(blob, w_off); g.bias = at<float>(blob, b_off);
             g.M = M; g.N = W; g.K = K;
             g.x3 = w.x3; g.ln_part = w.ln_part; g.tmp_f32 = w.x;
+            if (leaf_mode) { g.ln_leaf = w.ln_leaf; leaves = true; }
             return launch_gemm_algo(g, EPI_BIAS_RESID_LN_F32, 0, st, probe);
         };
         // (the caller left the embedded rows split: ln_pre writes hi / lo / partials itself; the text tower, which has no

@@ -141,8 +141,14 @@ static int launch_skinny_t(const GemmArgs& g, hipStream_t st) {
     return 0;
 }
 
+bool gemm_resid_writes_leaves(int M, int N, int K) {
+    GemmArgs g{};
+    g.M = M; g.N = N; g.K = K;
+    return skinny_ok(g) && N % 256 == 0 && N <= 1024;
+}
+
 static int launch_skinny(const GemmArgs& g, int epi, hipStream_t st) {
-    if (!g.A || !g.W || !g.out) return set_err(CLIPMI_EINVAL, "gemm: NULL pointer");
+    if (!g.A || !g.W || (!g.out && epi != EPI_BIAS_RESID_LN_F32)) return set_err(CLIPMI_EINVAL, "gemm: NULL pointer");
     switch (epi) {
         case EPI_BIAS_BF16: return launch_skinny_t<EPI_BIAS_BF16>(g, st);
         case EPI_BIAS_QGELU_BF16: return launch_skinny_t<EPI_BIAS_QGELU_BF16>(g, st);
@@ -151,6 +157,7 @@ static int launch_skinny(const GemmArgs& g, int epi, hipStream_t st) {
         case EPI_PATCH_F32: return launch_skinny_t<EPI_PATCH_F32>(g, st);
         case EPI_LN_BIAS_BF16: return launch_skinny_t<EPI_LN_BIAS_BF16>(g, st);
         case EPI_LN_BIAS_QGELU_BF16: return launch_skinny_t<EPI_LN_BIAS_QGELU_BF16>(g, st);
+        case EPI_BIAS_RESID_LN_F32: return launch_skinny_t<EPI_BIAS_RESID_LN_F32>(g, st);     // in place + statistics leaves
     }
     return set_err(CLIPMI_EINVAL, "gemm_skinny: epilogue %d", epi);
 }
@@ -158,7 +165,7 @@ static int launch_skinny(const GemmArgs& g, int epi, hipStream_t st) {
 // algo: 0 = choose by shape, 1 = force the 128x128 kernel, 2 = force the 256x256 kernel,
 //       3 = force the persistent 256x256 kernel
 int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmProbe* probe) {
-    if (epi_is_ln(epi) && (!g.ln_part_in || !g.colsum || !g.bias || g.K % 256 != 0 || g.K > 1024))
+    if (epi_is_ln(epi) && ((!g.ln_part_in && !g.ln_leaf_in) || !g.colsum || !g.bias || g.K % 256 != 0 || g.K > 1024))
         return set_err(CLIPMI_EINVAL, "gemm: LN-folded epilogue %d needs ln_part_in, colsum, bias and K %% 256 == 0, K <= 1024", epi);
     if (epi == EPI_BIAS_RESID_LN_F32 &&
         (!g.x3 || !g.ln_part || !g.tmp_f32 || g.N % 256 != 0 || g.N > 1024 || ((size_t)g.x3 & 15) != 0))
@@ -239,6 +246,11 @@ int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmP
     // acc + bias into the f32 scratch rows + the split / statistics pass, like every non-persistent kernel)
     const bool skinny = algo == 0 && skinny_ok(g);
     if (skinny && epi != EPI_BIAS_RESID_LN_F32) return launch_skinny(g, epi, st);
+    // one prompt / one image with a leaf buffer: the skinny kernel updates the split rows itself and leaves the statistics as
+    // leaves for the skinny LN-folded consumer behind it (no scratch rows, no split / statistics launch)
+    if (epi == EPI_BIAS_RESID_LN_F32 && skinny && g.ln_leaf) return launch_skinny(g, epi, st);
+    if (g.ln_leaf_in && !(skinny && epi_is_ln(epi)))
+        return set_err(CLIPMI_EINVAL, "gemm: ln_leaf_in is read by the skinny LN-folded consumers only (M <= %d)", SKINNY_MAX_M);
     if (epi == EPI_BIAS_RESID_LN_F32 && !use256p) {
         // not the persistent kernel: acc + bias as f32 into the scratch rows, then the add + split + statistics pass
         GemmArgs t = g;
@@ -413,6 +425,36 @@ extern "C" int clipmi_dbg_gemm_ln(const void* x3_dev, const void* wg_dev, const 
     g.out = out_dev;
     g.M = M; g.N = N; g.K = K;
     return launch_gemm_algo(g, epi, algo, as_stream(stream));
+}
+
+// One prompt / one image (M <= 128, the skinny kernels): clipmi_dbg_gemm_resid_ln_leaf updates x3 in place and writes the statistics
+// leaves leaf_dev [M][N / 4][2] (no scratch rows, no partials); clipmi_dbg_gemm_ln_leaf is the LN-folded consumer reading them.
+// Together they return the bits of clipmi_dbg_gemm_resid_ln + clipmi_dbg_gemm_ln.
+extern "C" int clipmi_dbg_gemm_resid_ln_leaf(const void* a_dev, const void* w_dev, const float* bias_dev, void* x3_dev, float* leaf_dev,
+                                             int M, int N, int K, void* stream) {
+    if (!leaf_dev || !gemm_resid_writes_leaves(M, N, K))
+        return set_err(CLIPMI_EINVAL, "dbg_gemm_resid_ln_leaf: M <= %d, N %% 256 == 0, N <= 1024, K %% 32 == 0", SKINNY_MAX_M);
+    GemmArgs g{};
+    g.A = static_cast<const unsigned short*>(a_dev);
+    g.W = static_cast<const unsigned short*>(w_dev);
+    g.bias = bias_dev;
+    g.x3 = x3_dev; g.ln_leaf = leaf_dev;
+    g.ln_part = leaf_dev; g.tmp_f32 = leaf_dev;          // unused on this path (the argument check wants them non-null)
+    g.M = M; g.N = N; g.K = K;
+    return launch_gemm_algo(g, EPI_BIAS_RESID_LN_F32, 0, as_stream(stream));
+}
+
+extern "C" int clipmi_dbg_gemm_ln_leaf(const void* x3_dev, const void* wg_dev, const float* cb_dev, const float* colsum_dev,
+                                       const float* leaf_dev, void* out_dev, int M, int N, int K, int epi, void* stream) {
+    if (!epi_is_ln(epi)) return set_err(CLIPMI_EINVAL, "dbg_gemm_ln_leaf: epi %d", epi);
+    GemmArgs g{};
+    g.A = static_cast<const unsigned short*>(x3_dev);
+    g.lda_bytes = (unsigned)resid_row_bytes(K);
+    g.W = static_cast<const unsigned short*>(wg_dev);
+    g.bias = cb_dev; g.colsum = colsum_dev; g.ln_leaf_in = leaf_dev;
+    g.out = out_dev;
+    g.M = M; g.N = N; g.K = K;
+    return launch_gemm_algo(g, epi, 0, as_stream(stream));
 }
 
 // x3 (split residual rows [N bf16 hi | N u8 lo], updated in place) += a @ w^T + bias; part = statistics partials of the

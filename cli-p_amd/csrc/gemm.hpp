@@ -287,7 +287,15 @@ struct GemmArgs {
     float* ln_part;
     float* tmp_f32;
     unsigned lda_bytes;        // 0: A rows are K elements apart; LN-folded consumers pass resid_row_bytes(K)
+    // M <= 128 rows (one prompt, one image: gemm_skinny.hpp; round 5). The skinny residual producer updates the split rows IN
+    // PLACE (each wave owns its 16 columns of 16 rows) and leaves the statistics as the canonical tree's LEAVES - (sum, sum of
+    // squares) of every 4-column group, ln_leaf [M][N / 4][2] - instead of a split / statistics pass of its own; the skinny
+    // LN-folded consumer behind it (ln_leaf_in set, ln_part_in ignored) runs the tree. One launch less per residual GEMM in a chain of
+    // ~4-us launches, the same statistics bits as the tiled kernels' (batch-size invariance).
+    float* ln_leaf;
+    const float* ln_leaf_in;
 };
+constexpr int SKINNY_MAX_M = 128;       // rows up to which the skinny kernels (gemm_skinny.hpp) take a GEMM
 // elements (bf16) between two A rows
 __host__ __device__ inline size_t gemm_lda(const GemmArgs& g) { return g.lda_bytes ? (size_t)g.lda_bytes / 2 : (size_t)g.K; }
 
@@ -503,6 +511,7 @@ struct GemmProbe {
 int launch_gemm(const GemmArgs& g, int epi, hipStream_t st, GemmProbe* probe = nullptr);
 int launch_gemm_algo(const GemmArgs& g, int epi, int algo, hipStream_t st, GemmProbe* probe = nullptr);
 int launch_gemm_fp8(const GemmArgs& g, int epi, hipStream_t st, int mx = 1);      // gemm256f8.hpp: e4m3 operands + scales
+bool gemm_resid_writes_leaves(int M, int N, int K);   // the residual GEMM of this shape runs on the skinny kernel and can take ln_leaf
 bool gemm_fp8_emits_mx(int M, int N, int K);     // the QuickGELU form of this shape can write e4m3 + MX block scales (out_bscale)
 // vit_kernels.hip: f32 rows -> split residual rows x3 ([W bf16 hi | W u8 lo] each) + canonical statistics partials
 // [M][W/256][2]; with `add` (the non-persistent form of EPI_BIAS_RESID_LN_F32) the rows are add[m][:] + x3[m][:], updated in place

@@ -17,7 +17,6 @@
 
 namespace clipmi {
 
-constexpr int SKINNY_MAX_M = 128;
 // Workgroups of ONE wave when that still leaves the 256 CUs short of work (out_proj / c_proj of one prompt: 32 column
 // strips) - a CU pulls ~25-60 GB/s through its memory pipe, so a launch's weight bytes must be spread over as many CUs as
 // there are strips; four neighbouring strips per workgroup otherwise. DEPTH = K-steps of 32 in flight per wave (2 x 16 B
@@ -52,16 +51,55 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g) {
     if (epi_is_ln(EPI)) {
         cs = *reinterpret_cast<const f32x4*>(g.colsum + n);
         const int nseg = K >> 8;
-        const float* pp = g.ln_part_in + orow * 2 * nseg;
+        if (!g.ln_leaf_in) {
+            const float* pp = g.ln_part_in + orow * 2 * nseg;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i < nseg) { part[2 * i] = pp[2 * i]; part[2 * i + 1] = pp[2 * i + 1]; }
+            for (int i = 0; i < 4; ++i)
+                if (i < nseg) { part[2 * i] = pp[2 * i]; part[2 * i + 1] = pp[2 * i + 1]; }
+        }
     } else if (EPI == EPI_PATCH_F32) {
         const int b_ = am / g.np, p_ = am - b_ * g.np;
         orow = (size_t)b_ * g.L + 1 + p_;
         add = *reinterpret_cast<const f32x4*>(g.pos + (size_t)(1 + p_) * g.N + n);
     } else if (EPI == EPI_BIAS_RESID_F32) {
         add = *reinterpret_cast<const f32x4*>(static_cast<const float*>(g.out) + orow * g.N + n);
+    }
+    // EPI_BIAS_RESID_LN_F32 (round 5): the lane's four values of the split residual row, updated in place in the epilogue
+    uint2 xh = make_uint2(0u, 0u);
+    unsigned xl = 0u;
+    if (EPI == EPI_BIAS_RESID_LN_F32) {
+        xh = *reinterpret_cast<const uint2*>(resid_hi(g.x3, orow, g.N) + n);
+        xl = *reinterpret_cast<const unsigned*>(resid_lo(g.x3, orow, g.N) + n);
+    }
+    // LN-folded consumer behind such a producer: (mean, rstd) from the statistics LEAVES (GemmArgs.ln_leaf_in) by the canonical
+    // tree of ln_wave_sum. A 256-column segment has 64 leaves; lane (fr, fg) takes leaves 4 t + fg, t < 16, of its row: tree
+    // levels 32 / 16 / 8 / 4 pair t ^ 8 / 4 / 2 / 1 inside the lane, levels 2 / 1 pair lanes fg ^ 2 / fg ^ 1 (= lane ^ 32 / ^ 16).
+    if (epi_is_ln(EPI) && g.ln_leaf_in) {
+        const int nseg = K >> 8;
+        const f32x2* lf = reinterpret_cast<const f32x2*>(g.ln_leaf_in) + orow * (size_t)(K >> 2) + fg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < nseg) {
+                f32x2 v[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) v[t] = lf[64 * j + 4 * t];
+                float sm[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    float a[8], b[4];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) a[t] = v[t][c] + v[t + 8][c];          // level 32
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) b[t] = a[t] + a[t + 4];                // level 16
+                    const float c0 = b[0] + b[2], c1 = b[1] + b[3];                    // level 8
+                    float d = c0 + c1;                                                 // level 4
+                    d = lane_fold32(d, d);                                             // level 2
+                    sm[c] = lane_fold16(d, d);                                         // level 1
+                }
+                part[2 * j] = sm[0];
+                part[2 * j + 1] = sm[1];
+            }
+        }
     }
 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -96,6 +134,19 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g) {
         if (valid)
             *reinterpret_cast<uint2*>(static_cast<unsigned short*>(g.out) + orow * g.N + n) =
                 make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        return;
+    }
+    if (EPI == EPI_BIAS_RESID_LN_F32) {
+        // (acc + bias) + old row - the tiled producers' add order - then the split form in place and this lane's leaf
+        const f32x4 o = v + split_join(xh, xl);
+        uint2 nh;
+        unsigned nl;
+        split_make(o, nh, nl);
+        if (valid) {
+            *reinterpret_cast<uint2*>(resid_hi(g.x3, orow, g.N) + n) = nh;
+            *reinterpret_cast<unsigned*>(resid_lo(g.x3, orow, g.N) + n) = nl;
+            *reinterpret_cast<f32x2*>(g.ln_leaf + (orow * (size_t)(g.N >> 2) + (size_t)(n >> 2)) * 2) = f32x2{ln_lane_sum(o), ln_lane_sumsq(o)};
+        }
         return;
     }
     if (EPI == EPI_PATCH_F32 || EPI == EPI_BIAS_RESID_F32) v += add;

@@ -313,6 +313,14 @@ int clipmi_dbg_gemm_ln(const void* x3_dev, const void* wg_dev, const float* cb_d
 int clipmi_dbg_quantize_rows_fp8mx(const void* in_bf16_dev, void* out_fp8_dev, void* bscale_dev, int M, int K, void* stream);
 int clipmi_dbg_gemm_fp8_bsa(const void* a8_dev, const void* w8_dev, const void* a_bscale_dev, const float* w_scale_dev,
                             const float* bias_dev, void* out_dev, int M, int N, int K, int epi, void* stream);
+/* One prompt / one image (M <= 128 rows, csrc/gemm_skinny.hpp, round 5): the residual GEMM updates the split rows in place and writes
+ * the statistics LEAVES leaf_dev [M][N / 4][2] ((sum, sum of squares) of every 4-column group) instead of running a split /
+ * statistics pass; the LN-folded consumer behind it reads them and runs the canonical reduction tree itself. Bit for bit
+ * clipmi_dbg_gemm_resid_ln followed by clipmi_dbg_gemm_ln. */
+int clipmi_dbg_gemm_resid_ln_leaf(const void* a_dev, const void* w_dev, const float* bias_dev, void* x3_dev, float* leaf_dev,
+                                  int M, int N, int K, void* stream);
+int clipmi_dbg_gemm_ln_leaf(const void* x3_dev, const void* wg_dev, const float* cb_dev, const float* colsum_dev,
+                            const float* leaf_dev, void* out_dev, int M, int N, int K, int epi, void* stream);
 int clipmi_dbg_gemm_resid_ln(const void* a_dev, const void* w_dev, const float* bias_dev, void* x3_dev, float* part_dev,
                              float* tmp_dev, int M, int N, int K, int algo, void* stream);
 

@@ -467,6 +467,46 @@ def test_gemm_resid_ln_producer(clipmi, gpu, M, N, K):
             assert torch.equal(got, want), f"algo {algo} vs the fused store pass: {what} differs"
 
 
+@pytest.mark.parametrize("M,W,K", [(1, 512, 512), (10, 512, 2048), (77, 512, 512), (50, 768, 3072), (128, 1024, 1024), (17, 256, 1024)])
+@pytest.mark.parametrize("epi", [5, 6])
+def test_skinny_leaf_producer_and_consumer_equal_the_partials_path(clipmi, gpu, M, W, K, epi):
+    """One prompt / one image (M <= 128, round 5): the skinny residual GEMM updates the split rows in place and hands the statistics
+    on as 4-column leaves; the skinny LN-folded consumer runs the canonical reduction tree on them. Split rows and the
+    consumer's output equal, bit for bit, the residual GEMM + split_stats pass + consumer on partials - so a single prompt still
+    equals row 0 of a batch that ran on the tiled kernels."""
+    L = clipmi._lib.lib()
+    N = 3 * W
+    x0, gamma, beta, wc, bc = _ln_fold_case(gpu, M, W, N, M + W + K + epi)
+    wg, colsum, cb = clipmi.weights.ln_fold_terms(wc.float(), bc, gamma, beta)
+    wg, colsum, cb = wg.to(gpu), colsum.to(gpu), cb.to(gpu)
+    g = torch.Generator(device="cpu"); g.manual_seed(M * 3 + K)
+    a = _bf16(torch.randn(M, K, generator=g)).to(gpu)
+    wr = _bf16(torch.randn(W, K, generator=g) * K ** -0.5).to(gpu)
+    br = torch.randn(W, generator=g).to(gpu)
+    x3, _ = _split(clipmi, L, x0)
+    # reference: residual GEMM (scratch rows + split_stats) then the consumer on partials
+    x3_ref = x3.clone()
+    part = torch.full((M, W // 256, 2), float("nan"), dtype=torch.float32, device=gpu)
+    tmp = torch.empty(M, W, dtype=torch.float32, device=gpu)
+    clipmi._lib.check(L.clipmi_dbg_gemm_resid_ln(a.data_ptr(), wr.data_ptr(), br.data_ptr(), x3_ref.data_ptr(), part.data_ptr(),
+                                                 tmp.data_ptr(), M, W, K, 0, None), "resid_ln")
+    ref = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=gpu)
+    clipmi._lib.check(L.clipmi_dbg_gemm_ln(x3_ref.data_ptr(), wg.data_ptr(), cb.data_ptr(), colsum.data_ptr(), part.data_ptr(),
+                                           ref.data_ptr(), M, N, W, epi, None), "gemm_ln")
+    # leaf path
+    x3_new = x3.clone()
+    leaf = torch.full((M, W // 4, 2), float("nan"), dtype=torch.float32, device=gpu)
+    clipmi._lib.check(L.clipmi_dbg_gemm_resid_ln_leaf(a.data_ptr(), wr.data_ptr(), br.data_ptr(), x3_new.data_ptr(), leaf.data_ptr(),
+                                                      M, W, K, None), "resid_ln_leaf")
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=gpu)
+    clipmi._lib.check(L.clipmi_dbg_gemm_ln_leaf(x3_new.data_ptr(), wg.data_ptr(), cb.data_ptr(), colsum.data_ptr(), leaf.data_ptr(),
+                                                out.data_ptr(), M, N, W, epi, None), "gemm_ln_leaf")
+    torch.cuda.synchronize()
+    assert torch.equal(x3_new, x3_ref), "split rows of the in-place skinny producer differ from GEMM + split_stats"
+    assert torch.isfinite(leaf).all()
+    assert torch.equal(out, ref), "consumer on leaves differs from consumer on partials"
+
+
 @pytest.mark.parametrize("n_px", [224, 336])
 def test_resize_crop_on_device_matches_pillow(clipmi, gpu, n_px):
     """Row a2 on the device (csrc/resize.hip + the coefficient tables of decode_worker.resize_plan): bit for bit the pixels
