@@ -3227,25 +3227,39 @@ __global__ void __launch_bounds__(ORD_THREADS) order_hist_kernel(const unsigned*
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];      // digit-major: one scan gives every (digit, block) base
 }
 
-// exclusive scan of n counters in place, ONE workgroup of 1024 threads (n = 256 x blocks: 0.6 M entries at 10 M rows)
+// exclusive scan of n counters in place, ONE workgroup of 1024 threads (n = 256 x blocks: 0.6 M entries at 10 M rows): chunks of
+// 4096 entries, four consecutive ones per thread (16-byte accesses), a wave scan + the 16 wave totals per chunk, a running carry
 __global__ void __launch_bounds__(1024) order_scan_kernel(unsigned* __restrict__ v, long long n) {
-    __shared__ unsigned part[1024];
-    const long long per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
-    unsigned s = 0;
-    for (long long i = lo; i < hi; ++i) s += v[i];
-    part[threadIdx.x] = s;
+    __shared__ unsigned wtot[16];
+    __shared__ unsigned carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const unsigned add = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+    for (long long base = 0; base < n; base += 4096) {
+        const long long i0 = base + 4ll * tid;
+        unsigned x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = i0 + j < n ? v[i0 + j] : 0u;
+        const unsigned mine = x[0] + x[1] + x[2] + x[3];
+        unsigned inc = mine;                               // inclusive scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wtot[wave] = inc;
         __syncthreads();
-        part[threadIdx.x] += add;
+        unsigned before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wtot[w];
+        unsigned run = before + inc - mine;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i0 + j < n) v[i0 + j] = run;
+            run += x[j];
+        }
         __syncthreads();
-    }
-    unsigned run = part[threadIdx.x] - s;
-    for (long long i = lo; i < hi; ++i) {
-        const unsigned c = v[i];
-        v[i] = run;
-        run += c;
+        if (tid == 1023) carry_s = before + inc;            // the chunk's total joins the carry
+        __syncthreads();
     }
 }
 
