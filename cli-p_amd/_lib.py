@@ -176,3 +176,20 @@ def stream_ptr(device=None):
     """Raw hipStream_t of torch's current stream, so the library enqueues where torch does."""
     import torch
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """THE internal HIP stream that work enqueued on torch's current stream of `device` may overlap with (CLIP.encode_image's
+    second kernel sequence, IndexFlatIP's pipelined passes): ONE per (device, caller's stream) for the whole process, shared by
+    every model and index - this ROCm gives only a process's first three streams a hardware queue of their own and maps every
+    later one onto a shared fourth, where "two in flight" run back to back."""
+    import torch
+    cur = torch.cuda.current_stream(device)
+    key = (torch.device(device).index, cur.cuda_stream)
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return cur, s

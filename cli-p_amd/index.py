@@ -261,11 +261,8 @@ class IndexFlatIP:
         # lanes = the caller's stream + (batches_in_flight - 1) side streams. (Not two side streams: this ROCm gives only
         # the first three streams of a process their own hardware queue and every later one shares the fourth, so two
         # side streams created after a caller's own two ran on ONE queue, back to back - rocprofv3 Queue_Id.)
-        cur = torch.cuda.current_stream(self.device)
-        pool = self.__dict__.setdefault("_side_streams", {})
-        side = pool.get(cur.cuda_stream)
-        if side is None:
-            side = pool[cur.cuda_stream] = [torch.cuda.Stream(device=self.device) for _ in range(self.batches_in_flight - 1)]
+        cur, side1 = _lib.side_stream(self.device)            # shared with CLIP.encode_image's second sequence (_lib.side_stream)
+        side = [side1]
         lanes = [cur] + side
         for s_ in side:
             s_.wait_stream(cur)                       # q, the outputs and the index copies are ready

@@ -227,3 +227,25 @@ def test_real_checkpoint_parity_opt_in(clipmi, gpu):
         cos = _cos(got, ref).min().item()
         print(f"real weights {what}: err {err:.4g} (bf16-emulation noise {noise:.4g}), min cosine {cos:.6f}")
         assert err <= 3 * noise + 1e-3 and cos >= 0.999
+
+
+def test_encode_image_two_sequences_in_flight(clipmi, gpu):
+    """Round 5: encode_image cuts an input of at least two one-round chunks into one-round chunks that alternate between the caller's
+    stream and one internal stream (CLIP.image_lanes). Same bits as one sequence after the other on one stream, whatever comes
+    next on the caller's stream sees the finished result, and a caller's own raw stream keeps everything on that stream."""
+    model = clipmi.CLIP(clipmi.weights.random_state_dict("ViT-B/32", seed=0), device=gpu)
+    one = model.image_chunk(limit=model.max_batch // 2)
+    assert one == 435
+    B = 3 * one
+    lanes = model.image_lanes(B)
+    assert [l for _, _, l in lanes] == [0, 1, 0] and lanes[-1][1] == B
+    assert model.image_lanes(one) == [(0, one, 0)] and model.image_lanes(2 * one + 5) == [(0, 2 * one + 5, 0)]
+    g = torch.Generator(device="cpu"); g.manual_seed(3)
+    images = torch.randint(0, 256, (B, 3, 224, 224), generator=g, dtype=torch.uint8).to(gpu)
+    got = model.encode_image(images, normalize=True)
+    total = got.sum()                                     # enqueued on the caller's stream right behind the call
+    model.chunks_in_flight = 1
+    ref = model.encode_image(images, normalize=True)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref) and torch.isfinite(got).all()
+    assert torch.equal(total, ref.sum())
