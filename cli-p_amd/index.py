@@ -258,10 +258,11 @@ class IndexFlatIP:
             out_i = torch.empty((Q, K), dtype=torch.int64, device=self.device)
         else:
             out_s, out_i = out
-        # lanes = the caller's stream + (batches_in_flight - 1) side streams. (Not two side streams: this ROCm gives only
-        # the first three streams of a process their own hardware queue and every later one shares the fourth, so two
-        # side streams created after a caller's own two ran on ONE queue, back to back - rocprofv3 Queue_Id.)
-        cur, side1 = _lib.side_stream(self.device)            # shared with CLIP.encode_image's second sequence (_lib.side_stream)
+        # lanes = the caller's stream + ONE side stream, the process-wide one that CLIP.encode_image's second kernel sequence uses
+        # too (_lib.side_stream: this ROCm gives only the first three streams of a process their own hardware queue and every
+        # later one shares the fourth - two side streams created after a caller's own two ran on ONE queue, back to back:
+        # rocprofv3 Queue_Id; a side stream per model and index did the same to bench.py's search leg in round 5)
+        cur, side1 = _lib.side_stream(self.device)
         side = [side1]
         lanes = [cur] + side
         for s_ in side:
