@@ -14,12 +14,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         a = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
         w = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16)
         bias = torch.randn(N, generator=g, device=dev)
-        hl = torch.zeros(2, M, N, dtype=torch.bfloat16, device=dev)
+        x3 = torch.zeros(M, 3 * N, dtype=torch.uint8, device=dev)      # split rows: N bf16 hi | N u8 lo (round 5)
         part = torch.zeros(M, N // 256, 2, device=dev)
         tmp = torch.zeros(M, N, device=dev)
         out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
         def rln():
-            clipmi._lib.check(L.clipmi_dbg_gemm_resid_ln(a.data_ptr(), w.data_ptr(), bias.data_ptr(), hl[0].data_ptr(), hl[1].data_ptr(),
+            clipmi._lib.check(L.clipmi_dbg_gemm_resid_ln(a.data_ptr(), w.data_ptr(), bias.data_ptr(), x3.data_ptr(),
                                                          part.data_ptr(), tmp.data_ptr(), M, N, K, 3, None), "rln")
         def plain():
             clipmi._lib.check(L.clipmi_dbg_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, 0 | (3 << 8), None), "gemm")
@@ -34,7 +34,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
                 for _ in range(20): fn()
                 e1.record(); torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) / 20 * 1e3)
-                hl.zero_()
+                x3.zero_()
             best[name] = min(ts)
         print(f"grid {os.environ.get('CLIPMI_GEMM_GRID', '256'):>3} K={K}: split-residual producer {best['resid']:.1f} us, bias -> bf16 {best['bias']:.1f} us, difference {best['resid'] - best['bias']:.1f} us", flush=True)
 else:
