@@ -352,6 +352,16 @@ extern "C" int clipmi_encode_text(const clipmi_tower* t, const void* blob_dev, c
     hipStream_t st = as_stream(stream);
     const int W = t->width, L = t->tokens;
     const long long n4 = (long long)Q * L * (W / 4);
+    const bool fold8_ = t->ln_fold && t->weight_format == 1;
+    if (t->ln_fold && !fold8_ && W % 256 == 0 && W <= 1024) {
+        // LN-folded tower: embedding, split rows + statistics and the EOT rows in one launch (the bits of the three kernels below)
+        hipLaunchKernelGGL(text_embed_split_kernel, dim3((unsigned)((Q * L + 3) / 4 + 1)), dim3(256), 0, st, ids_dev,
+                           at<float>(blob_dev, t->off_tok_emb), at<float>(blob_dev, t->off_pos), w.x3, w.ln_part, w.rowidx, Q, L, W,
+                           t->vocab);
+        CLIPMI_CHECK_LAUNCH("text_embed_split_kernel");
+        if (int rc = run_layers(t, blob_dev, w, Q, 1, st, nullptr)) return rc;
+        return run_head(t, blob_dev, w, Q, w.rowidx, 1, out_dev, normalize, st);
+    }
     hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.x, ids_dev,
                        at<float>(blob_dev, t->off_tok_emb), at<float>(blob_dev, t->off_pos), Q, L, W, t->vocab);
     CLIPMI_CHECK_LAUNCH("text_embed_kernel");

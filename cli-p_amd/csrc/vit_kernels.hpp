@@ -325,6 +325,50 @@ static __global__ void __launch_bounds__(256) split_stats_kernel(const float* __
     }
 }
 
+// text_embed_kernel + split_stats_kernel<false> + eot_rows_kernel in ONE launch (LN-folded text towers; round 5: one prompt is a
+// chain of ~65 dependent launches of ~4 us, the three head kernels were three of them). Blocks [0, ceil(M / 4)): one wave per
+// row - token + positional embedding, split_make, canonical statistics, exactly the bits of the three-kernel path; block
+// ceil(M / 4): the EOT rows.
+static __global__ void __launch_bounds__(256) text_embed_split_kernel(const int* __restrict__ ids, const float* __restrict__ tok,
+                                                                      const float* __restrict__ pos, void* x3, float* __restrict__ part,
+                                                                      int* __restrict__ rowidx, int Q, int L, int W, int vocab) {
+    const int M = Q * L, nrb = (M + 3) / 4;
+    if ((int)blockIdx.x >= nrb) {
+        for (int q = threadIdx.x; q < Q; q += 256) {
+            int best = ids[(size_t)q * L], bi = 0;
+            for (int t = 1; t < L; ++t) {
+                const int v = ids[(size_t)q * L + t];
+                if (v > best) { best = v; bi = t; }
+            }
+            rowidx[q] = q * L + bi;
+        }
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const int nseg = W >> 8, t = r % L;
+    int id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    unsigned short* const hrow = resid_hi(x3, (size_t)r, W);
+    unsigned char* const lrow = resid_lo(x3, (size_t)r, W);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < nseg) {
+            const int c = j * 256 + lane * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tok + (size_t)id * W + c) + *reinterpret_cast<const f32x4*>(pos + (size_t)t * W + c);
+            uint2 nh;
+            unsigned nl;
+            split_make(v, nh, nl);
+            *reinterpret_cast<uint2*>(hrow + c) = nh;
+            *reinterpret_cast<unsigned*>(lrow + c) = nl;
+            const float sa = ln_wave_sum(ln_lane_sum(v));
+            const float sq = ln_wave_sum(ln_lane_sumsq(v));
+            if (lane == 0) *reinterpret_cast<f32x2*>(part + ((size_t)r * nseg + j) * 2) = f32x2{sa, sq};
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused attention for short sequences (L <= 16*NT; ViT-B/32: L = 50, text: L = 77), head dim 64.
 // One wave per (sequence, head). qkv bf16 [B*L][3W] (q | k | v, head h at columns 64h..64h+63
