@@ -520,7 +520,7 @@ def main():
     # into one-round chunks that alternate between the caller's stream and one internal stream (CLIP.image_lanes: 870 images =
     # two sequences of 435 in flight). The headline is ONE declared form: --encode-in-flight (default 2); both are published.
     forms = {}
-    for fl in (1, 2):
+    for fl in ((1, 2) if a.encode_in_flight == 2 else (1,)):      # (--encode-in-flight 1: the profiled runs hold ONE form only)
         model.chunks_in_flight = fl
         sp_ = {}
         dt_ = timed(enc_step, a.steps, a.warmup, dist, world, sp_)
@@ -533,7 +533,7 @@ def main():
                  dict({"value": world * B * a.steps / forms[fl][0], "ms_per_step": forms[fl][0] / a.steps * 1e3,
                        "whole_step_frac": FLOP_PER_IMAGE * B * a.steps / forms[fl][0] / 1e12 / PEAK_BF16_TFLOPS,
                        "sequences": [hi - lo for lo, hi, _ in (model.image_lanes(B) if fl == 2 else [(0, B, 0)])]}, **forms[fl][1])
-                 for fl in (1, 2)}
+                 for fl in sorted(forms)}
 
     # configs[1] reads "encode 1M images": the same step repeated until >= 1 M images per GPU have gone through
     # (about 11 s of sustained bf16 MFMA load: the clock the chip holds under it is part of the answer)
