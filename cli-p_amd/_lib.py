@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEV_LIB = os.environ.get("CLIPMI_DEV_LIB", "") not in ("", "0")
 LIB_PATH = os.path.join(HERE, "libclipmi_dev.so" if DEV_LIB else "libclipmi.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 F32, BF16, U8 = 0, 1, 2
 
 # every symbol include/clipmi.h declares (tests check the .so exports all of them)
@@ -24,7 +24,7 @@ SYMBOLS = [
     "clipmi_rows_stats", "clipmi_rows_absmax", "clipmi_rows_order_workspace_bytes", "clipmi_rows_order_by_absmax", "clipmi_rows_to_bf16", "clipmi_i8_copy_bytes", "clipmi_i8_meta_bytes", "clipmi_quantize_rows_i8", "clipmi_topk_ip_coarse_i8", "clipmi_dbg_topk_coarse_i8_scan_ms",
     "clipmi_dbg_quantize_rows_fp8", "clipmi_dbg_gemm_fp8",
     "clipmi_merge_topk_workspace_bytes", "clipmi_merge_topk", "clipmi_merge_topk_packed",
-    "clipmi_l2_normalize_rows", "clipmi_resize_crop_rgb8", "clipmi_last_error", "clipmi_abi_version",
+    "clipmi_l2_normalize_rows", "clipmi_resize_crop_rgb8", "clipmi_jpeg_workspace_bytes", "clipmi_jpeg_decode_rgb8", "clipmi_last_error", "clipmi_abi_version",
     "clipmi_dbg_gemm_bf16", "clipmi_dbg_layernorm", "clipmi_dbg_attention", "clipmi_dbg_topk_scan_ms",
     "clipmi_dbg_encode_image_probe_ms", "clipmi_dbg_encode_image_probe3_ms",
     "clipmi_dbg_split_stats", "clipmi_dbg_gemm_ln", "clipmi_dbg_gemm_resid_ln", "clipmi_dbg_gemm_resid_ln_leaf", "clipmi_dbg_gemm_ln_leaf", "clipmi_dbg_quantize_rows_fp8mx", "clipmi_dbg_gemm_fp8_bsa",
@@ -127,6 +127,10 @@ def lib():
     L.clipmi_l2_normalize_rows.argtypes = [vp, i64, i32, vp]
     L.clipmi_resize_crop_rgb8.restype = i32
     L.clipmi_resize_crop_rgb8.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp]
+    L.clipmi_jpeg_workspace_bytes.restype = i64
+    L.clipmi_jpeg_workspace_bytes.argtypes = [i64, i32]
+    L.clipmi_jpeg_decode_rgb8.restype = i32
+    L.clipmi_jpeg_decode_rgb8.argtypes = [vp, vp, i32, vp, i32, i64, i64, i64, vp, vp, vp, i64, vp]
     L.clipmi_dbg_gemm_bf16.restype = i32
     L.clipmi_dbg_gemm_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.clipmi_dbg_split_stats.restype = i32

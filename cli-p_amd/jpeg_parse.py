@@ -1,0 +1,155 @@
+"""Marker walk of a baseline JPEG file for the device decoder (csrc/jpeg.hip; SURVEY.md §8(f) next-1, reference
+build-index.py:47). numpy only - the decode workers (decode_worker.py) import this file by path, without torch.
+
+`parse` lets through what the device decodes - 8-bit baseline / extended-sequential Huffman, one interleaved scan, grey or
+YCbCr with luma sampling 1x1 / 2x1 / 2x2 and 1x1 chroma, no restart interval - and raises `Unsupported` for everything
+else (progressive, CMYK / RGB-coded, 12-bit, arithmetic coding, odd sampling, not a JPEG): those files stay with Pillow.
+That is a choice of decoder per file format, made on the host from the file's own header.
+"""
+import numpy as np
+
+TABLE_BYTES = 272
+MAX_STREAM = 1 << 28
+_NATURAL = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14,
+                     21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53,
+                     60, 61, 54, 47, 55, 62, 63])
+_INV_NATURAL = np.argsort(_NATURAL)
+
+
+class Unsupported(Exception):
+    """Not a file for the device decoder; Pillow's path takes it."""
+
+
+class Parsed:
+    __slots__ = ("width", "height", "ncomp", "hs", "vs", "quant", "tables", "stream")
+
+    def blocks(self):
+        hs, vs = (self.hs, self.vs) if self.ncomp == 3 else (1, 1)
+        mcus = -(-self.width // (8 * hs)) * -(-self.height // (8 * vs))
+        return mcus * (hs * vs + 2 if self.ncomp == 3 else 1)
+
+
+def parse(data):
+    """JPEG file bytes -> Parsed (header fields, quantisation steps in natural order, the six Huffman tables a scan can
+    name as raw 272-byte records, the entropy-coded segment without byte stuffing). Raises Unsupported."""
+    if len(data) < 4 or data[0] != 0xFF or data[1] != 0xD8:
+        raise Unsupported("not a JPEG file")
+    n = len(data)
+    i = 2
+    qt = {}
+    huff = {}
+    frame = None
+    jfif = adobe = False
+    adobe_tf = 0
+    while True:
+        if i + 4 > n or data[i] != 0xFF:
+            raise Unsupported("marker expected")
+        m = data[i + 1]
+        if m == 0xFF:
+            i += 1
+            continue
+        if m == 0xD8 or m == 0x01 or 0xD0 <= m <= 0xD7:
+            i += 2
+            continue
+        L = (data[i + 2] << 8) | data[i + 3]
+        if L < 2 or i + 2 + L > n:
+            raise Unsupported("truncated segment")
+        if m == 0xDB:
+            k = i + 4
+            while k < i + 2 + L:
+                if data[k] >> 4 or k + 65 > i + 2 + L:
+                    raise Unsupported("quantisation table")
+                qt[data[k] & 15] = data[k + 1:k + 65]
+                k += 65
+        elif m == 0xC0 or m == 0xC1:
+            if frame is not None or L < 11 or data[i + 4] != 8:
+                raise Unsupported("frame header")
+            nf = data[i + 9]
+            if L != 8 + 3 * nf:
+                raise Unsupported("frame header")
+            frame = ((data[i + 5] << 8) | data[i + 6], (data[i + 7] << 8) | data[i + 8],
+                     [(data[i + 10 + 3 * c], data[i + 11 + 3 * c] >> 4, data[i + 11 + 3 * c] & 15, data[i + 12 + 3 * c]) for c in range(nf)])
+        elif 0xC2 <= m <= 0xCF and m != 0xC4 and m != 0xC8 and m != 0xCC:
+            raise Unsupported("not a baseline frame")
+        elif m == 0xCC:
+            raise Unsupported("arithmetic coding")
+        elif m == 0xC4:
+            k = i + 4
+            while k < i + 2 + L:
+                if k + 17 > i + 2 + L:
+                    raise Unsupported("Huffman table")
+                cnt = sum(data[k + 1:k + 17])
+                if cnt > 256 or k + 17 + cnt > i + 2 + L or (data[k] >> 4) > 1 or (data[k] & 15) > 3:
+                    raise Unsupported("Huffman table")
+                huff[data[k]] = bytes(data[k + 1:k + 17 + cnt]).ljust(TABLE_BYTES, b"\0")
+                k += 17 + cnt
+        elif m == 0xDD:
+            if L != 4 or data[i + 4] or data[i + 5]:
+                raise Unsupported("restart interval")
+        elif m == 0xE0 and data[i + 4:i + 9] == b"JFIF\0":
+            jfif = True
+        elif m == 0xEE and L >= 14 and data[i + 4:i + 9] == b"Adobe":
+            adobe, adobe_tf = True, data[i + 15]
+        elif m == 0xDA:
+            break
+        i += 2 + L
+    if frame is None:
+        raise Unsupported("no frame header")
+    height, width, comps = frame
+    nc = len(comps)
+    if width == 0 or height == 0 or nc not in (1, 3):
+        raise Unsupported("frame")
+    ns = data[i + 4]
+    if ns != nc or L != 6 + 2 * ns or data[i + 5 + 2 * ns] != 0 or data[i + 6 + 2 * ns] != 63 or data[i + 7 + 2 * ns] != 0:
+        raise Unsupported("scan header")
+    out = Parsed()
+    out.width, out.height, out.ncomp = width, height, nc
+    tables = []
+    quant = np.zeros((3, 64), np.uint8)
+    for c in range(nc):
+        cid, td_ta = data[i + 5 + 2 * c], data[i + 6 + 2 * c]
+        if cid != comps[c][0]:
+            raise Unsupported("scan order")
+        dc, ac = huff.get(td_ta >> 4), huff.get(0x10 | (td_ta & 15))
+        q = qt.get(comps[c][3])
+        if dc is None or ac is None or q is None:
+            raise Unsupported("missing table")
+        tables += [dc, ac]
+        quant[c] = np.frombuffer(q, np.uint8)[_INV_NATURAL]
+    while len(tables) < 6:
+        tables += tables[:2]
+    if nc == 3:
+        ids = (comps[0][0], comps[1][0], comps[2][0])
+        # jdapimin.c default_decompress_parms: which three-component files are YCbCr
+        ycc = True if jfif else (adobe_tf != 0) if adobe else ids != (0x52, 0x47, 0x42)
+        if not ycc:
+            raise Unsupported("RGB-coded JPEG")
+        if (comps[1][1], comps[1][2], comps[2][1], comps[2][2]) != (1, 1, 1, 1) or (comps[0][1], comps[0][2]) not in ((1, 1), (2, 1), (2, 2)):
+            raise Unsupported("sampling factors")
+        out.hs, out.vs = comps[0][1], comps[0][2]
+        if out.hs == 2 and (width + 1) // 2 <= 2:
+            raise Unsupported("too narrow for fancy upsampling")
+    else:
+        out.hs = out.vs = 1
+    out.quant, out.tables = quant, tables
+    # the entropy-coded segment ends at the first marker that is not a stuffed 0xFF00
+    i += 2 + L
+    j = i
+    find = data.find
+    while True:
+        j = find(b"\xff", j)
+        if j < 0 or j + 1 >= n:
+            raise Unsupported("no end of image")
+        nxt = data[j + 1]
+        if nxt == 0:
+            j += 2
+        elif nxt == 0xFF:
+            j += 1
+        else:
+            break
+    if nxt != 0xD9:
+        raise Unsupported("marker inside the scan")         # restart markers, further scans
+    out.stream = data[i:j].replace(b"\xff\x00", b"\xff")
+    if len(out.stream) >= MAX_STREAM:
+        raise Unsupported("too large")
+    return out

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CLIPMI_ABI_VERSION 5
+#define CLIPMI_ABI_VERSION 6
 
 enum {
     CLIPMI_OK = 0,
@@ -250,6 +250,33 @@ typedef struct clipmi_resize_job {
 } clipmi_resize_job;
 int clipmi_resize_crop_rgb8(const void* raw_dev, const void* jobs_dev, int njobs, int max_rows, const int32_t* coef_dev,
                             int n_px, void* out_dev, void* scratch_dev, void* stream);
+
+/* ---- `Image.open(tfn)` on the device for baseline JPEG files (build-index.py:47, the decode in front of `transform` at :48;
+ * SURVEY.md §8(f) next-1): the bytes Pillow (libjpeg-turbo: Huffman decode, jpeg_idct_islow, fancy upsampling, 16-bit
+ * fixed-point YCbCr -> RGB) hands to the transform, bit for bit. The HOST walks the markers (cli-p_amd/jpeg.py) and lets through
+ * 8-bit baseline / extended-sequential Huffman files with one interleaved scan, 1 (grey) or 3 (YCbCr) components, luma sampling
+ * 1x1, 2x1 or 2x2 with 1x1 chroma, no restart interval; everything else stays with Pillow. Per image one record; the
+ * entropy-coded segments travel with the 0xFF00 stuffing removed, each 4-byte aligned and followed by at least 16 zero bytes.
+ * tables_dev: the batch's distinct Huffman tables, 272 bytes each (DHT's 16 counts + up to 256 symbols, zero padded).
+ * out_dev: per image height rows of width*3 RGB bytes at out_off (grey files replicated, as Image.convert("RGB") does) - the
+ * layout clipmi_resize_crop_rgb8 takes. status_dev[i]: 0 decoded; 1 invalid Huffman code; 2 the data ended early or ran
+ * over - such a file goes back to Pillow, whose error handling is the reference's. total_blocks = sum of the images' 8x8 blocks
+ * (coef_off counts in blocks), max_blocks / max_pixels = the largest image's. */
+typedef struct clipmi_jpeg_image {
+    int64_t stream_off;           /* bytes from streams_dev */
+    int64_t coef_off;             /* the image's first block in the workspace's coefficient / sample buffers */
+    int64_t out_off;              /* bytes from out_dev */
+    int32_t stream_bytes;
+    int32_t width, height;
+    int32_t ncomp;                /* 1 or 3 */
+    int32_t hs, vs;               /* luma sampling factors (1,1) (2,1) (2,2) */
+    int32_t dc_tbl[3], ac_tbl[3]; /* per component: index into tables_dev */
+    uint8_t quant[3][64];         /* per component: quantisation steps, natural (row-major) order */
+} clipmi_jpeg_image;
+int64_t clipmi_jpeg_workspace_bytes(int64_t total_blocks, int ntables);
+int clipmi_jpeg_decode_rgb8(const void* streams_dev, const void* images_dev, int n, const void* tables_dev, int ntables,
+                            int64_t total_blocks, int64_t max_blocks, int64_t max_pixels, void* out_dev, int32_t* status_dev,
+                            void* ws_dev, int64_t ws_bytes, void* stream);
 
 /* thread-local message of the last failing call on this thread ("" if none) */
 const char* clipmi_last_error(void);

@@ -1,0 +1,112 @@
+"""The JPEG decode in front of the transform (reference build-index.py:47): the CPU restatement
+(oracle/jpeg_oracle.py) against Pillow itself and against the committed Pillow outputs, and the host parser."""
+import io
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import clipmi
+from clipmi import jpeg_parse
+from oracle import jpeg_oracle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_cases.npz")
+
+
+def golden_cases():
+    d = np.load(GOLDEN)
+    return [(d[f"file_{i}"].tobytes(), d[f"rgb_{i}"]) for i in range(int(d["n"]))]
+
+
+def smooth(rng, h, w):
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([127 + 100 * np.sin(xx / 9.0 + yy / 17.0), 127 + 100 * np.cos(xx / 13.0 - yy / 7.0), (xx * 3 + yy * 2) % 256], -1)
+    return np.clip(base + rng.normal(0, 12, (h, w, 3)), 0, 255).astype(np.uint8)
+
+
+def encode(a, **kw):
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, format="JPEG", **kw)
+    return buf.getvalue()
+
+
+def test_oracle_equals_the_committed_pillow_pixels():
+    for blob, rgb in golden_cases():
+        assert np.array_equal(jpeg_oracle.decode(blob), rgb)
+
+
+def test_oracle_equals_pillow_live():
+    """Pillow is the reference's own decoder and is installed here: every supported sampling, odd sizes, three qualities,
+    noise (no end-of-block symbols) and smooth content, grey, optimised tables."""
+    rng = np.random.default_rng(11)
+    n = 0
+    for (h, w) in [(224, 224), (31, 45), (9, 8), (120, 77)]:
+        for sub in (0, 1, 2):
+            for q in (95, 60):
+                for a in (smooth(rng, h, w), rng.integers(0, 256, (h, w, 3), dtype=np.uint8)):
+                    blob = encode(a, quality=q, subsampling=sub)
+                    assert np.array_equal(jpeg_oracle.decode(blob), np.asarray(Image.open(io.BytesIO(blob)).convert("RGB")))
+                    n += 1
+    blob = encode(smooth(rng, 50, 70)[..., 1], quality=80, optimize=True)
+    assert np.array_equal(jpeg_oracle.decode(blob), np.asarray(Image.open(io.BytesIO(blob)).convert("RGB")))
+    assert n == 48
+
+
+def test_parser_reads_what_pillow_reads():
+    rng = np.random.default_rng(3)
+    for sub, (hs, vs) in ((0, (1, 1)), (1, (2, 1)), (2, (2, 2))):
+        blob = encode(smooth(rng, 41, 67), quality=88, subsampling=sub)
+        p = jpeg_parse.parse(blob)
+        im = Image.open(io.BytesIO(blob))
+        assert (p.width, p.height, p.ncomp, p.hs, p.vs) == (im.size[0], im.size[1], 3, hs, vs)
+        # quantisation steps: Pillow (>= 8.3) reports them de-zigzagged, the order the parser hands the device
+        for c, tq in enumerate((0, 1, 1)):
+            assert p.quant[c].tolist() == list(im.quantization[tq])
+        assert len(p.tables) == 6 and all(len(t) == jpeg_parse.TABLE_BYTES for t in p.tables)
+        assert p.blocks() == -(-67 // (8 * hs)) * -(-41 // (8 * vs)) * (hs * vs + 2)
+    g = jpeg_parse.parse(encode(smooth(rng, 20, 30)[..., 0], quality=70))
+    assert (g.ncomp, g.hs, g.vs, g.blocks()) == (1, 1, 1, 3 * 4)
+
+
+def test_parser_leaves_everything_else_to_pillow():
+    rng = np.random.default_rng(4)
+    a = smooth(rng, 64, 64)
+    with pytest.raises(jpeg_parse.Unsupported):
+        jpeg_parse.parse(encode(a, quality=80, progressive=True))
+    buf = io.BytesIO()
+    Image.fromarray(a).convert("CMYK").save(buf, format="JPEG")
+    with pytest.raises(jpeg_parse.Unsupported):
+        jpeg_parse.parse(buf.getvalue())
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, format="PNG")
+    with pytest.raises(jpeg_parse.Unsupported):
+        jpeg_parse.parse(buf.getvalue())
+    blob = encode(a, quality=80)
+    with pytest.raises(jpeg_parse.Unsupported):
+        jpeg_parse.parse(blob[:len(blob) // 2])               # no end-of-image marker: Pillow's error handling applies
+    with pytest.raises(jpeg_parse.Unsupported):
+        jpeg_parse.parse(encode(a[:, :4], quality=80, subsampling=2))      # 2 chroma columns: libjpeg upsamples without the filter
+    with pytest.raises(jpeg_parse.Unsupported):
+        jpeg_parse.parse(b"")
+    try:
+        blob = encode(a, quality=80, restart_marker_blocks=4)
+    except TypeError:
+        blob = None
+    if blob is not None and b"\xff\xdd" in blob:
+        with pytest.raises(jpeg_parse.Unsupported):
+            jpeg_parse.parse(blob)
+
+
+def test_pack_lays_out_aligned_streams_and_shares_tables():
+    from clipmi import jpeg
+    rng = np.random.default_rng(6)
+    items = [jpeg_parse.parse(encode(smooth(rng, 30 + 7 * k, 50 + k), quality=90, subsampling=k % 3)) for k in range(5)]
+    recs, tables, streams, out_bytes, total_blocks, max_blocks, max_pixels = jpeg.pack(items)
+    assert tables.shape == (4, jpeg_parse.TABLE_BYTES)        # Pillow's standard tables: luma / chroma x DC / AC
+    assert total_blocks == sum(it.blocks() for it in items) and max_blocks == max(it.blocks() for it in items)
+    for r, it in zip(recs, items):
+        o, n = int(r["stream_off"]), int(r["stream_bytes"])
+        assert o % 16 == 0 and streams[o:o + n].tobytes() == it.stream and not streams[o + n:o + n + 16].any()
+        assert int(r["out_off"]) % 16 == 0
+    assert out_bytes >= sum(it.width * it.height * 3 for it in items)
