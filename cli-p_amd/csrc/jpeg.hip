@@ -38,16 +38,34 @@ struct JpegImage {             // mirrors clipmi_jpeg_image (include/clipmi.h)
     unsigned char quant[3][64];
 };
 
-constexpr int JP_T = 256;          // threads per workgroup = subsequences per chunk
+constexpr int JP_T = 128;          // threads per workgroup = subsequences per chunk: ONE wave (waves that walk serial chains
+                                   // must not share a SIMD: 870 two-wave workgroups ran 3.2 x slower than one)
 constexpr int JP_SUB_BITS = 1024;  // bits per subsequence (32 words)
 constexpr int JP_FAST = 10;        // bits of the direct look-up
-constexpr int JP_RAW = 272;        // bytes of a raw table: 16 counts + 256 symbols
+constexpr int JP_RAW = 288;        // bytes of a raw table: 16 counts + 256 symbols + class (0 DC, 1 AC) + 15 zero bytes
 
+// A 16-bit table entry says everything the state machine needs about a symbol: the bits to skip (code + the value bits behind it,
+// 1..31), the step of the coefficient index (DC: 0 -> 1; AC: run + 1, 16 for ZRL, 64 = end of block) and the number of value bits.
+// (LDS per workgroup decides how many images are resident at once, and an image can be a serial chain of milliseconds.)
+__device__ __forceinline__ unsigned jp_entry(unsigned sym, unsigned len, bool ac) {
+    const unsigned s = sym & 15, r = sym >> 4;
+    const unsigned dz = !ac ? 1u : (s ? r + 1 : (r == 15 ? 16u : 64u));
+    return (len + s) | (dz << 5) | (s << 12);
+}
+#define JP_ADV(e) ((e) & 31u)
+#define JP_DZ(e) (((e) >> 5) & 127u)
+#define JP_S(e) ((e) >> 12)
+
+constexpr int JP_LONG = 8;         // canonical codes grow upwards, so the codes longer than JP_FAST bits sit under the LAST few
+                                   // JP_FAST-bit prefixes (the standard tables: 5); the last JP_LONG prefixes get a 16-bit table
 struct JpLut {
-    unsigned short fast[1 << JP_FAST];   // (length << 8) | symbol for codes of up to JP_FAST bits, 0 = longer (or invalid)
+    unsigned short fast[1 << JP_FAST];   // jp_entry of codes of up to JP_FAST bits, 0 = longer (or invalid)
+    unsigned short second[JP_LONG << (16 - JP_FAST)];   // by bits JP_FAST..15 for the last JP_LONG prefixes, 0 = invalid
     int maxcode[18];                     // largest code of length l (-1: none)
     int valoff[18];                      // symbol index of a code of length l = code + valoff[l]
     unsigned char vals[256];
+    int covered;                         // every longer code sits in `second` (else: the bit-by-bit walk)
+    int pad_[3];
 };
 static_assert(sizeof(JpLut) % 16 == 0, "tables are copied as 16-byte pieces");
 
@@ -61,20 +79,23 @@ __global__ void __launch_bounds__(256) jpeg_build_luts_kernel(const unsigned cha
     JpLut& L = luts[blockIdx.x];
     const int tid = threadIdx.x;
     for (int i = tid; i < (1 << JP_FAST); i += 256) L.fast[i] = 0;
+    for (int i = tid; i < (JP_LONG << (16 - JP_FAST)); i += 256) L.second[i] = 0;
     if (tid == 0) {
-        int code = 0, k = 0;
+        int code = 0, k = 0, covered = 1;
         for (int l = 1; l <= 16; ++l) {
             const int n = t[l - 1];
             first_code[l] = code;
             first_idx[l] = k;
             L.maxcode[l] = n ? code + n - 1 : -1;
             L.valoff[l] = k - code;
+            if (n && l > JP_FAST && (code >> (l - JP_FAST)) < (1 << JP_FAST) - JP_LONG) covered = 0;
             code = (code + n) << 1;
             k += n;
         }
         first_idx[17] = k > 256 ? 256 : k;
         L.maxcode[0] = L.maxcode[17] = -1;
         L.valoff[0] = L.valoff[17] = 0;
+        L.covered = covered;
     }
     L.vals[tid] = t[16 + tid];
     __syncthreads();
@@ -82,10 +103,17 @@ __global__ void __launch_bounds__(256) jpeg_build_luts_kernel(const unsigned cha
         int l = 1;
         while (l < 16 && tid >= first_idx[l + 1]) ++l;
         const int code = first_code[l] + (tid - first_idx[l]);
+        const unsigned short e = (unsigned short)jp_entry(t[16 + tid], (unsigned)l, t[272] != 0);
         if (l <= JP_FAST && code < (1 << l)) {
-            const unsigned short e = (unsigned short)((l << 8) | t[16 + tid]);
             const int base = code << (JP_FAST - l);
             for (int j = 0; j < (1 << (JP_FAST - l)); ++j) L.fast[base + j] = e;
+        } else if (l > JP_FAST && code < (1 << l)) {
+            const int v16 = code << (16 - l);
+            const int pre = (v16 >> (16 - JP_FAST)) - ((1 << JP_FAST) - JP_LONG);
+            if (pre >= 0) {
+                const int base = (pre << (16 - JP_FAST)) + (v16 & ((1 << (16 - JP_FAST)) - 1));
+                for (int j = 0; j < (1 << (16 - l)); ++j) L.second[base + j] = e;
+            }
         }
     }
 }
@@ -105,6 +133,28 @@ struct JpShared {
     int bad;
 };
 
+// The table entry of the symbol whose code starts the 32-bit window x (0: no such code)
+__device__ __forceinline__ unsigned jp_lookup(const JpLut& L, unsigned x, bool ac) {
+    const unsigned k = x >> (32 - JP_FAST);
+    unsigned e = L.fast[k];
+    if (!e) {
+        if (k >= (1u << JP_FAST) - JP_LONG) {
+            e = L.second[((k - ((1u << JP_FAST) - JP_LONG)) << (16 - JP_FAST)) + ((x >> 16) & ((1u << (16 - JP_FAST)) - 1))];
+        } else if (!L.covered) {
+            for (int l = JP_FAST + 1; l <= 16; ++l) {
+                const int code = (int)(x >> (32 - l));
+                if (code <= L.maxcode[l]) {
+                    e = jp_entry(L.vals[(code + L.valoff[l]) & 255], (unsigned)l, ac);
+                    break;
+                }
+            }
+        }
+    }
+    return e;
+}
+
+__device__ __forceinline__ int jp_comp(unsigned blk, int hv) { return blk < (unsigned)hv ? 0 : (int)blk - hv + 1; }
+
 // One subsequence: symbols from state (p, bz) while p < end. WRITE: also stores the coefficients of blocks ablk, ablk+1, ...
 // (stops behind block `total` - 1). Returns the number of blocks completed.
 template <bool WRITE>
@@ -122,53 +172,31 @@ __device__ __forceinline__ int jp_decode(JpShared& sh, unsigned cw0, int bpm, in
             w0 = sh.words[(r >> 5) * 33 + (r & 31)];
             w1 = sh.words[((r + 1) >> 5) * 33 + ((r + 1) & 31)];
         }
-        const unsigned s5 = p & 31;
-        const unsigned x = s5 ? (w0 << s5) | (w1 >> (32 - s5)) : w0;
-        const JpLut& L = sh.lut[comp * 2 + (z != 0)];
-        unsigned len, sym;
-        const unsigned e = L.fast[x >> (32 - JP_FAST)];
-        if (e) {
-            len = e >> 8;
-            sym = e & 255;
-        } else {
-            len = 0;
-            sym = 0;
-            for (int l = JP_FAST + 1; l <= 16; ++l) {
-                const int code = (int)(x >> (32 - l));
-                if (code <= L.maxcode[l]) {
-                    sym = L.vals[(code + L.valoff[l]) & 255];
-                    len = l;
-                    break;
-                }
-            }
-            if (!len) {                      // no such code: a wrong start state's garbage (discarded) or a corrupt file
-                if (WRITE) sh.bad = 1;
-                p += 1;
-                continue;
-            }
+        const unsigned x = (unsigned)(((((unsigned long long)w0) << 32) | w1) << (p & 31) >> 32);
+        const bool ac = z != 0;
+        const JpLut& L = sh.lut[comp * 2 + (ac ? 1 : 0)];
+        const unsigned e = jp_lookup(L, x, ac);
+        if (!e) {                            // no such code: a wrong start state's garbage (discarded) or a corrupt file
+            if (WRITE) sh.bad = 1;
+            p += 1;
+            continue;
         }
-        const unsigned s = sym & 15;
-        int v = 0;
-        if (WRITE && s) {
-            v = (int)((x << len) >> (32 - s));
-            if (v < (1 << (s - 1))) v -= (1 << s) - 1;
-        }
-        if (z == 0) {
-            if (WRITE) {
-                if (sym > 15) sh.bad = 1;
+        if (WRITE) {
+            const unsigned s = JP_S(e);
+            int v = 0;
+            if (s) {
+                v = (int)((x << (JP_ADV(e) - s)) >> (32 - s));
+                if (v < (1 << (s - 1))) v -= (1 << s) - 1;
+            }
+            if (!ac) {
                 coef[ablk * 64] = (short)v;
+            } else if (s) {
+                const unsigned k = z + JP_DZ(e) - 1;
+                coef[ablk * 64 + (k < 64 ? sh.nat[k] : 63)] = (short)v;
             }
-            p += len + s;
-            z = 1;
-        } else if (s) {
-            z += sym >> 4;
-            if (WRITE) coef[ablk * 64 + (z < 64 ? sh.nat[z] : 63)] = (short)v;
-            z += 1;
-            p += len + s;
-        } else {
-            z = (sym >> 4) == 15 ? z + 16 : 64;
-            p += len;
         }
+        p += JP_ADV(e);
+        z += JP_DZ(e);
         if (z >= 64) {
             z = 0;
             blk = blk + 1 == (unsigned)bpm ? 0 : blk + 1;
@@ -184,6 +212,52 @@ __device__ __forceinline__ int jp_decode(JpShared& sh, unsigned cw0, int bpm, in
         }
     }
     bz = (blk << 8) | z;
+    return done;
+}
+
+// The same walk as jp_decode<false>, by a whole WAVE for ONE subsequence (all arguments wave-uniform): when only one or two
+// threads of a wave have anything to re-decode - always, on images whose subsequences do not re-synchronise - a lane's serial
+// chain of look-ups (window -> LDS -> length -> next window, ~470 cycles per symbol) is the whole kernel's time. Here the 64
+// lanes look up the entries of the 64 bit offsets behind p at once, and the chain that is left is a scalar walk over registers:
+// v_readlane of the entry at the current offset, add its bit count, step the coefficient index. A window ends after 64 bits or
+// with its block (the next block may use other tables).
+__device__ __forceinline__ int jp_decode_wave(JpShared& sh, unsigned cw0, int bpm, int hv, unsigned& p_, unsigned& bz_, unsigned end) {
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    unsigned p = p_, blk = bz_ >> 8, z = bz_ & 255;
+    int done = 0;
+    while (p < end) {
+        const int c = jp_comp(blk, hv);
+        const unsigned q = p + lane;
+        const unsigned r = (q >> 5) - cw0;
+        const unsigned w0 = sh.words[(r >> 5) * 33 + (r & 31)], w1 = sh.words[((r + 1) >> 5) * 33 + ((r + 1) & 31)];
+        const unsigned x = (unsigned)(((((unsigned long long)w0) << 32) | w1) << (q & 31) >> 32);
+        const unsigned a = jp_lookup(sh.lut[2 * c + 1], x, true);
+        const unsigned room = end - p < 64u ? end - p : 64u;
+        unsigned o = 0;
+        if (z == 0) {                                    // the block's DC symbol starts the window
+            const unsigned e = __builtin_amdgcn_readfirstlane(jp_lookup(sh.lut[2 * c], x, false));
+            if (!e) {
+                p += 1;
+                continue;
+            }
+            o = JP_ADV(e);
+            z = 1;
+        }
+        while (o < room) {                               // AC symbols up to the window's or the block's end
+            const unsigned e = __builtin_amdgcn_readlane(a, o);
+            o += e ? JP_ADV(e) : 1u;                     // (no such code: one bit on, as jp_decode)
+            z += JP_DZ(e);
+            if (z >= 64) break;
+        }
+        if (z >= 64) {
+            z = 0;
+            blk = blk + 1 == (unsigned)bpm ? 0 : blk + 1;
+            ++done;
+        }
+        p += o;
+    }
+    p_ = p;
+    bz_ = (blk << 8) | z;
     return done;
 }
 
@@ -224,12 +298,9 @@ __global__ void __launch_bounds__(JP_T) jpeg_huffman_kernel(const unsigned char*
     for (unsigned c0 = 0; c0 < nsub && carry_blocks < total; c0 += JP_T) {
         __syncthreads();                                   // the previous chunk's readers are done with sh.words
         const unsigned cw0 = c0 * 32u;
-        for (int k = 0; k < 33; ++k) {                     // 256 x 32 words + 8 of the next chunk
-            const unsigned r = (unsigned)k * JP_T + tid;
-            if (k == 32 && tid >= 8) break;
+        for (unsigned r = tid; r < (unsigned)JP_T * 32u + 8u; r += JP_T) {      // the chunk's words + 8 of the next chunk
             const unsigned g = cw0 + r;
-            const unsigned w = g < nwords ? __builtin_bswap32(src[g]) : 0u;
-            sh.words[(r >> 5) * 33 + (r & 31)] = w;
+            sh.words[(r >> 5) * 33 + (r & 31)] = g < nwords ? __builtin_bswap32(src[g]) : 0u;
         }
         const unsigned i = c0 + tid;
         const bool act = i < nsub;
@@ -245,7 +316,23 @@ __global__ void __launch_bounds__(JP_T) jpeg_huffman_kernel(const unsigned char*
             const JpState prev = tid ? sh.exit_state[tid - 1] : carry;
             const bool ch = act && tid && (prev.p != start.p || prev.bz != start.bz);
             if (!__syncthreads_or(ch)) break;
-            if (ch) {
+            const unsigned long long m = __ballot(ch);
+            if (__popcll(m) <= 2) {                        // (wave-uniform) the whole wave walks each of them: jp_decode_wave
+                unsigned long long mm = m;
+                while (mm) {
+                    const int b = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    unsigned sp = __builtin_amdgcn_readlane(prev.p, b), sbz = __builtin_amdgcn_readlane(prev.bz, b);
+                    const unsigned se = __builtin_amdgcn_readlane(end, b);
+                    const int d = jp_decode_wave(sh, cw0, bpm, hv, sp, sbz, se);
+                    if ((tid & 63) == b) {
+                        start = prev;
+                        ex = JpState{sp, sbz};
+                        nb = d;
+                        sh.exit_state[tid] = ex;
+                    }
+                }
+            } else if (ch) {
                 start = prev;
                 ex = start;
                 nb = jp_decode<false>(sh, cw0, bpm, hv, ex.p, ex.bz, end, nullptr, 0, 0);

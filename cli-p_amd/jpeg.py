@@ -21,7 +21,7 @@ assert IMAGE.itemsize == 264
 
 
 def pack(items):
-    """Parsed records -> (IMAGE array, tables uint8 [nt][272], streams uint8, out_bytes, total_blocks, max_blocks, max_pixels)"""
+    """Parsed records -> (IMAGE array, tables uint8 [nt][288], streams uint8, out_bytes, total_blocks, max_blocks, max_pixels)"""
     recs = np.zeros(len(items), dtype=IMAGE)
     pool = {}
     soff = coff = ooff = 0

@@ -8,7 +8,7 @@ That is a choice of decoder per file format, made on the host from the file's ow
 """
 import numpy as np
 
-TABLE_BYTES = 272
+TABLE_BYTES = 288          # a raw table: DHT's 16 counts + up to 256 symbols (zero padded to 272) + class (0 DC, 1 AC) + 15 zero bytes
 MAX_STREAM = 1 << 28
 _NATURAL = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14,
                      21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53,
@@ -31,7 +31,7 @@ class Parsed:
 
 def parse(data):
     """JPEG file bytes -> Parsed (header fields, quantisation steps in natural order, the six Huffman tables a scan can
-    name as raw 272-byte records, the entropy-coded segment without byte stuffing). Raises Unsupported."""
+    name as raw 288-byte records, the entropy-coded segment without byte stuffing). Raises Unsupported."""
     if len(data) < 4 or data[0] != 0xFF or data[1] != 0xD8:
         raise Unsupported("not a JPEG file")
     n = len(data)
@@ -81,7 +81,9 @@ def parse(data):
                 cnt = sum(data[k + 1:k + 17])
                 if cnt > 256 or k + 17 + cnt > i + 2 + L or (data[k] >> 4) > 1 or (data[k] & 15) > 3:
                     raise Unsupported("Huffman table")
-                huff[data[k]] = bytes(data[k + 1:k + 17 + cnt]).ljust(TABLE_BYTES, b"\0")
+                if (data[k] >> 4) == 0 and cnt and max(data[k + 17:k + 17 + cnt]) > 15:
+                    raise Unsupported("DC Huffman table")               # libjpeg refuses such a table (jdhuff.c)
+                huff[data[k]] = bytes(data[k + 1:k + 17 + cnt]).ljust(272, b"\0") + bytes([data[k] >> 4]) + b"\0" * 15
                 k += 17 + cnt
         elif m == 0xDD:
             if L != 4 or data[i + 4] or data[i + 5]:

@@ -257,7 +257,8 @@ int clipmi_resize_crop_rgb8(const void* raw_dev, const void* jobs_dev, int njobs
  * 8-bit baseline / extended-sequential Huffman files with one interleaved scan, 1 (grey) or 3 (YCbCr) components, luma sampling
  * 1x1, 2x1 or 2x2 with 1x1 chroma, no restart interval; everything else stays with Pillow. Per image one record; the
  * entropy-coded segments travel with the 0xFF00 stuffing removed, each 4-byte aligned and followed by at least 16 zero bytes.
- * tables_dev: the batch's distinct Huffman tables, 272 bytes each (DHT's 16 counts + up to 256 symbols, zero padded).
+ * tables_dev: the batch's distinct Huffman tables, 288 bytes each (DHT's 16 counts + up to 256 symbols, zero padded to 272,
+ * then the table class - 0 DC, 1 AC - and 15 zero bytes).
  * out_dev: per image height rows of width*3 RGB bytes at out_off (grey files replicated, as Image.convert("RGB") does) - the
  * layout clipmi_resize_crop_rgb8 takes. status_dev[i]: 0 decoded; 1 invalid Huffman code; 2 the data ended early or ran
  * over - such a file goes back to Pillow, whose error handling is the reference's. total_blocks = sum of the images' 8x8 blocks
