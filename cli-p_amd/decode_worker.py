@@ -132,12 +132,59 @@ def decode_full(path, n_px, region):
     return w, h, total
 
 
+JPEG_HDR_INTS = 32        # header of a JPEG region (stage_jpeg): 3 w h ncomp hs vs stream_bytes blocks | r0 nrows need_h need_v left top hk vk
+                          # n_hcoef n_vcoef | stream offset, coefficient offset (bytes from the region's start)
+JPEG_QUANT_OFF = 128      # 3 x 64 quantisation steps, natural order
+JPEG_TABLES_OFF = 320     # six raw Huffman tables (jpeg_parse.TABLE_BYTES each): DC, AC per component
+JPEG_COEF_OFF = 2048      # the resize plan's coefficient blocks (int32), then the entropy-coded segment (16-byte aligned)
+_plans = {}
+
+
+def stage_jpeg(path, n_px, region):
+    """For the decode on the device (csrc/jpeg.hip): read the file, walk its markers (jpeg_parse.parse) and lay out in `region`
+    [header | quantisation steps | Huffman tables | resize plan coefficients | entropy-coded segment without byte stuffing, followed
+    by >= 16 zero bytes]. -> (w, h, bytes used); raises jpeg_parse.Unsupported for files Pillow has to decode, returns None when
+    the file does not fit the region."""
+    try:
+        from . import jpeg_parse
+    except ImportError:
+        import jpeg_parse
+    with open(path, "rb") as f:
+        data = f.read()
+    p = jpeg_parse.parse(data)
+    key = (p.width, p.height, n_px)
+    plan = _plans.get(key)
+    if plan is None:
+        if len(_plans) > 256:
+            _plans.clear()
+        plan = _plans[key] = resize_plan(p.width, p.height, n_px)
+    nh, nv = plan["hcoef"].size, plan["vcoef"].size
+    o_stream = (JPEG_COEF_OFF + 4 * (nh + nv) + 15) // 16 * 16
+    total = (o_stream + len(p.stream) + 16 + 15) // 16 * 16
+    if total > region.size:
+        return None
+    ints = np.frombuffer(region, dtype=np.int32, count=JPEG_HDR_INTS)
+    ints[:] = [3, p.width, p.height, p.ncomp, p.hs, p.vs, len(p.stream), p.blocks(), plan["r0"], plan["nrows"], plan["need_h"],
+               plan["need_v"], plan["left"], plan["top"], plan["hk"], plan["vk"], nh, nv, o_stream, JPEG_COEF_OFF] + [0] * 12
+    region[JPEG_QUANT_OFF:JPEG_QUANT_OFF + 192] = p.quant.reshape(-1)
+    region[JPEG_TABLES_OFF:JPEG_TABLES_OFF + 6 * jpeg_parse.TABLE_BYTES] = np.frombuffer(b"".join(p.tables), np.uint8)
+    if nh + nv:
+        co = np.frombuffer(region, dtype=np.int32, count=nh + nv, offset=JPEG_COEF_OFF)
+        co[:nh] = plan["hcoef"]
+        co[nh:] = plan["vcoef"]
+    region[o_stream:o_stream + len(p.stream)] = np.frombuffer(p.stream, np.uint8)
+    region[o_stream + len(p.stream):total] = 0
+    return p.width, p.height, total
+
+
 def serve(fin, fout):
     """Answer requests until stdin closes. Request line (tab separated):
          n_px | small segment or - | byte offset of the slot | big segment or - | byte offset of the region | its size |
-         path as hex (file names may contain newlines and tabs)
+         what the region may take (1 full-size pixels, 2 a parsed JPEG file, 3 both) | path as hex (file names may contain
+         newlines and tabs)
        Reply: b"0" failed | b"1" the transform's n_px x n_px pixels are in the slot (or follow, when no segment was named) |
-              b"2" + <iiq (w, h, bytes)>: the image sits at full size, with its resize plan, in the region (decode_full)."""
+              b"2" + <iiq (w, h, bytes)>: the image sits at full size, with its resize plan, in the region (decode_full) |
+              b"3" + <iiq (w, h, bytes)>: a baseline JPEG file, parsed, with its resize plan, in the region (stage_jpeg)."""
     import mmap
     import os
     import struct
@@ -162,16 +209,25 @@ def serve(fin, fout):
         if not line:
             break
         try:
-            n_px_s, shm_name, off_s, big_name, big_off_s, big_cap_s, path = line.rstrip(b"\n").split(b"\t", 6)
-            n_px, off = int(n_px_s), int(off_s)
+            n_px_s, shm_name, off_s, big_name, big_off_s, big_cap_s, mode_s, path = line.rstrip(b"\n").split(b"\t", 7)
+            n_px, off, mode = int(n_px_s), int(off_s), int(mode_s)
             fname = bytes.fromhex(path.decode("ascii")).decode("utf-8", "surrogateescape")      # hex: see DecodePool._run
             reply = None
             if big_name != b"-":
                 region = np.frombuffer(mapped(big_name.decode()), dtype=np.uint8, count=int(big_cap_s), offset=int(big_off_s))
-                full = decode_full(fname, n_px, region)
+                full = None
+                if mode & 2:
+                    try:
+                        full = stage_jpeg(fname, n_px, region)
+                    except Exception:                          # not a file for the device decoder (or unreadable: Pillow reports it)
+                        full = None
+                    if full is not None:
+                        reply = b"3" + struct.pack("<iiq", *full)
+                if full is None and mode & 1:
+                    full = decode_full(fname, n_px, region)
+                    if full is not None:
+                        reply = b"2" + struct.pack("<iiq", *full)
                 region = None
-                if full is not None:
-                    reply = b"2" + struct.pack("<iiq", *full)
             if reply is None:
                 if shm_name == b"-":
                     reply = b"1" + load_uint8(fname, n_px).tobytes()

@@ -120,32 +120,32 @@ class DecodePool:
 
     def _run(self, w, jobs, n_px, name, seg, big=None):
         """Worker w decodes its share of the batch: (slot, path) pairs -> (slot, status) with status False (failed), True
-        (the transform's pixels are in the slot) or (w, h, bytes): the image is in its region of the big segment at full
-        size, for the resize on the device. If the worker process dies (a file that crashes the decoder, an OOM kill), that
+        (the transform's pixels are in the slot) or (kind, w, h, bytes): the image is in its region of the big segment -
+        kind 2 at full size, for the resize on the device; kind 3 as a parsed JPEG file, for the decode on the device. If the worker process dies (a file that crashes the decoder, an OOM kill), that
         file is reported as failed and the rest of the share - and of every later batch - is decoded in this process: no
         program is spawned once the GPU may have been initialised."""
         import struct
         p = self.procs[w]
         ok = []
         per = 3 * n_px * n_px
-        bname, bcap = (big[0], big[1]) if big else (b"-", 0)
+        bname, bcap, bmode = (big[0], big[1], big[2]) if big else (b"-", 0, 0)
         if p is not None:
             # the whole share in one write: this thread sleeps in read() while the worker decodes (one request per round
             # trip kept 16 parent threads busy handing the GIL around)
             # the path travels hex-encoded: a file name may hold '\n' or '\t' (legal on Linux, and os.listdir returns them) -
             # raw, such a name split into two request lines and shifted every later reply of the worker by one
-            req = b"".join(b"%d\t%s\t%d\t%s\t%d\t%d\t" % (n_px, name, slot * per, bname, slot * bcap, bcap) +
+            req = b"".join(b"%d\t%s\t%d\t%s\t%d\t%d\t%d\t" % (n_px, name, slot * per, bname, slot * bcap, bcap, bmode) +
                            path.encode("utf-8", "surrogateescape").hex().encode() + b"\n" for slot, path in jobs)
             try:
                 p.stdin.write(req)
                 p.stdin.flush()
                 for slot, _ in jobs:
                     st = p.stdout.read(1)
-                    if st == b"2":
+                    if st == b"2" or st == b"3":
                         rest = p.stdout.read(16)
                         if len(rest) < 16:
                             break
-                        ok.append((slot, struct.unpack("<iiq", rest)))
+                        ok.append((slot, (int(st),) + struct.unpack("<iiq", rest)))
                     elif st == b"":
                         break
                     else:
@@ -166,14 +166,16 @@ class DecodePool:
                 ok.append((slot, False))
         return ok
 
-    def decode(self, paths, n_px, copy=True, segment=0, full_cap=0):
+    def decode(self, paths, n_px, copy=True, segment=0, full_cap=0, full_mode=1):
         """-> (uint8 array [n_ok,3,n_px,n_px], ok_paths, failed_paths), file order kept. copy=False returns a VIEW of
         the pool's shared-memory segment `segment` (all slots, plus a boolean mask of the good ones instead of the
         compacted array): valid until the next decode() into the same segment - encode_files copies it straight into
         pinned memory. One decode() at a time (the workers take one request stream).
         full_cap > 0 (with copy=False): 8-bit RGB images that need resampling and fit full_cap bytes are delivered at FULL
         size in a second segment, one region of full_cap bytes per slot (tmpfs pages exist only where written), for the
-        resize on the device; the result is then ((slots view, good mask, big view, {slot: (w, h, bytes)}), ok, bad)."""
+        resize on the device; the result is then ((slots view, good mask, big view, {slot: (kind, w, h, bytes)}), ok, bad).
+        full_mode: what a region may take - bit 0 full-size pixels (kind 2), bit 1 baseline JPEG files parsed for the decode on
+        the device (kind 3: decode_worker.stage_jpeg)."""
         n = len(paths)
         per = 3 * n_px * n_px
         seg = self._segment(max(1, n * per), segment)
@@ -182,7 +184,7 @@ class DecodePool:
         if full_cap > 0 and not copy:
             full_cap = (int(full_cap) + 15) // 16 * 16
             bseg = self._segment(max(1, n * full_cap), 2 + segment)
-            big = (bseg.name.encode(), full_cap)
+            big = (bseg.name.encode(), full_cap, int(full_mode))
         live = [w for w in range(self.n) if self.procs[w] is not None] or [0]
         futs = [self.threads.submit(self._run, w, [(i, paths[i]) for i in range(k, n, len(live))], n_px, name, seg, big)
                 for k, w in enumerate(live) if k < n]
@@ -236,13 +238,18 @@ def _load_safe(args):
         return None
 
 
-def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb=None):
+def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb=None, device_jpeg_kb=None):
     """Generator over batches: yields (ok_paths, features f32 [n,E] numpy normalised, failed_paths).
     Decode runs in the worker processes of `pool` (a DecodePool) when given, else on `workers` threads (Pillow
     releases the GIL while decoding, which is enough for large photos and not for small images).
     device_resize_mb (default $CLIPMI_DEVICE_RESIZE_MB, 0 = off; needs `pool` and a GPU): 8-bit RGB images of up to that
     many MB decoded travel at full size and are resized + cropped by clipmi_resize_crop_rgb8 - the same pixels, with the
-    workers left to decode only (Pillow's bicubic resize is half of a photo-sized file's host time)."""
+    workers left to decode only (Pillow's bicubic resize is half of a photo-sized file's host time).
+    device_jpeg_kb (default $CLIPMI_DEVICE_JPEG_KB, else 256; 0 = off; needs `pool` and a GPU): baseline JPEG files of up to that
+    many KB are not decoded on the host at all - a worker reads the file, walks its markers and removes the byte stuffing
+    (jpeg_parse.py), and clipmi_jpeg_decode_rgb8 + clipmi_resize_crop_rgb8 produce the transform's pixels in HBM, the same
+    bytes as Pillow's. Every other file (progressive, PNG, CMYK ...) and every file the device reports corrupt takes the
+    Pillow path as before."""
     import os
     n_px = model.visual.input_resolution
     dev = model.device
@@ -254,9 +261,21 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
         print(f"(shared memory too small for decode workers' batches: {pool.shm_room() >> 20} MB free in /dev/shm; "
               f"decoding on {workers} threads)")
         pool = None
-    full_cap = [int(device_resize_mb * (1 << 20)) if (use_gpu and pool is not None) else 0]     # [0]: mutable (may be switched off)
-    if full_cap[0] and pool.shm_room() < 2 * batch * (3 * n_px * n_px + full_cap[0]) + (256 << 20):
-        full_cap[0] = 0
+    if device_jpeg_kb is None:
+        device_jpeg_kb = float(os.environ.get("CLIPMI_DEVICE_JPEG_KB", "256"))
+    on_device = use_gpu and pool is not None
+    resize_cap = int(device_resize_mb * (1 << 20)) if on_device else 0
+    jpeg_cap = int(device_jpeg_kb * 1024) if on_device else 0
+
+    def room_for(cap):
+        return pool.shm_room() >= 2 * batch * (3 * n_px * n_px + cap) + (256 << 20)
+
+    if resize_cap and not room_for(max(resize_cap, jpeg_cap)):
+        resize_cap = 0
+    if jpeg_cap and not room_for(jpeg_cap):
+        jpeg_cap = 0
+    full_cap = [max(resize_cap, jpeg_cap)]               # bytes per region of the big segment; [0]: mutable (may be switched off)
+    full_mode = (1 if resize_cap else 0) | (2 if jpeg_cap else 0)
 
     # three pinned staging buffers used in turn (GPU): batch i may still be in its H2D copy while batch i+1 is filled;
     # a buffer is reused only after the copy that read it has finished. Pixels go shared memory -> pinned -> device:
@@ -286,86 +305,119 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
         big_ring.append(slot)
         return slot
 
-    def resize_on_device(devt, bigview, full, good):
-        """The full-size images of the batch: pack [pixels | plan | coefficients]... + job records into one pinned buffer,
-        one H2D copy, clipmi_resize_crop_rgb8 into their rows of devt (on the copy stream, behind devt's own copy)."""
+    def device_stage(devt, bigview, full, good):
+        """The batch's regions of the big segment -> their rows of devt, on the copy stream behind devt's own copy: ONE H2D copy
+        of the segment where it lies (it is page-locked: no packing copy on the host - packing 1 GB per batch of photo-sized
+        images with one thread was slower than Pillow's resize), then clipmi_resize_crop_rgb8 for the full-size images (kind 2)
+        and clipmi_jpeg_decode_rgb8 + clipmi_resize_crop_rgb8 for the parsed JPEG files (kind 3).
+        -> slots whose file the device decoder reported corrupt (they go back to Pillow)."""
         from . import _lib
-        from .decode_worker import PLAN_INTS
+        from . import jpeg as J
+        from .decode_worker import JPEG_COEF_OFF, JPEG_HDR_INTS, JPEG_QUANT_OFF, JPEG_TABLES_OFF, PLAN_INTS
         from .resize import JOB
+        L = _lib.lib()
+        n = len(good)
         comp = np.cumsum(good) - 1                           # slot -> row of devt
-        entries = sorted(full.items())
-        cap = bigview.size // len(good)
-        if pool.pin_segment(2 + seg_index[0]):
-            # the segment is page-locked: copy it to the device where it lies (one H2D of the used range, no packing copy
-            # on the host: packing 1 GB per batch of photo-sized images with one thread was slower than Pillow's resize)
-            L = _lib.lib()
-            jobs = np.zeros(len(entries), dtype=JOB)
-            toff, max_rows = 0, 1
-            for t, (s_, (w, h, nb)) in enumerate(entries):
-                base_ = s_ * cap
-                o_hdr = (w * h * 3 + 15) // 16 * 16
-                hd = np.frombuffer(bigview, dtype=np.int32, count=PLAN_INTS, offset=base_ + o_hdr)
-                j = jobs[t]
-                j["src_off"], j["w"], j["h"], j["r0"], j["nrows"], j["out_index"] = base_, w, h, hd[2], hd[3], comp[s_]
-                j["need_h"], j["need_v"], j["left"], j["top"], j["hk"], j["vk"] = hd[4], hd[5], hd[6], hd[7], hd[8], hd[9]
-                j["hcoef_off"] = (base_ + o_hdr) // 4 + PLAN_INTS
-                j["vcoef_off"] = j["hcoef_off"] + hd[10]
-                j["tmp_off"] = toff
-                toff += int(hd[3]) * n_px * 3
-                max_rows = max(max_rows, int(hd[3]))
-            used = (entries[-1][0] + 1) * cap
-            with torch.cuda.stream(copy_stream):
-                dbig = torch.from_numpy(bigview[:used]).to(dev, non_blocking=True)
+        cap = bigview.size // n
+        used = (max(full) + 1) * cap
+        e2 = sorted((s_, v) for s_, v in full.items() if v[0] == 2)
+        e3 = np.array(sorted(s_ for s_, v in full.items() if v[0] == 3), dtype=np.int64)
+        if not pool.pin_segment(2 + seg_index[0]):
+            # the segment could not be page-locked (locked-memory limit?): this batch goes through a pinned copy of it, the
+            # following ones take the host path
+            full_cap[0] = 0
+            slot = big_staging(used)
+            np.copyto(slot["np"][:used], bigview[:used])
+            src = slot["buf"][:used]
+        else:
+            slot = None
+            src = torch.from_numpy(bigview[:used])
+        bad_slots = []
+        with torch.cuda.stream(copy_stream):
+            dbig = src.to(dev, non_blocking=True)
+            base = dbig.data_ptr()
+            if e2:
+                jobs = np.zeros(len(e2), dtype=JOB)
+                toff, max_rows = 0, 1
+                for t, (s_, (_, w, h, nb)) in enumerate(e2):
+                    base_ = s_ * cap
+                    o_hdr = (w * h * 3 + 15) // 16 * 16
+                    hd = np.frombuffer(bigview, dtype=np.int32, count=PLAN_INTS, offset=base_ + o_hdr)
+                    j = jobs[t]
+                    j["src_off"], j["w"], j["h"], j["r0"], j["nrows"], j["out_index"] = base_, w, h, hd[2], hd[3], comp[s_]
+                    j["need_h"], j["need_v"], j["left"], j["top"], j["hk"], j["vk"] = hd[4], hd[5], hd[6], hd[7], hd[8], hd[9]
+                    j["hcoef_off"] = (base_ + o_hdr) // 4 + PLAN_INTS
+                    j["vcoef_off"] = j["hcoef_off"] + hd[10]
+                    j["tmp_off"] = toff
+                    toff += int(hd[3]) * n_px * 3
+                    max_rows = max(max_rows, int(hd[3]))
                 djobs = torch.from_numpy(jobs.view(np.uint8).reshape(-1).copy()).to(dev)
                 scratch = torch.empty(max(toff, 1), dtype=torch.uint8, device=dev)
-                rc = L.clipmi_resize_crop_rgb8(dbig.data_ptr(), djobs.data_ptr(), len(entries), max_rows, dbig.data_ptr(), n_px,
-                                               devt.data_ptr(), scratch.data_ptr(), _lib.stream_ptr(dev))
+                rc = L.clipmi_resize_crop_rgb8(base, djobs.data_ptr(), len(e2), max_rows, base, n_px, devt.data_ptr(),
+                                               scratch.data_ptr(), _lib.stream_ptr(dev))
                 _lib.check(rc, "clipmi_resize_crop_rgb8")
-                ev = torch.cuda.Event()
-                ev.record(copy_stream)
-            ev.synchronize()                                  # the segment is decoded into again two batches later
-            return ev
-        # the segment could not be page-locked (locked-memory limit?): this batch is packed into pinned memory by hand -
-        # slower than Pillow's own resize - and the following ones go back to the host path
-        full_cap[0] = 0
-        sizes = [(nb + 15) // 16 * 16 for _, (_, _, nb) in entries]
-        o_jobs = sum(sizes)
-        slot = big_staging(o_jobs + len(entries) * JOB.itemsize)
-        hv = slot["np"]
-        jobs = np.zeros(len(entries), dtype=JOB)
-        off, toff, max_rows = 0, 0, 1
-        for t, (s_, (w, h, nb)) in enumerate(entries):
-            src = bigview[s_ * cap:s_ * cap + nb]
-            np.copyto(hv[off:off + nb], src)
-            o_hdr = (w * h * 3 + 15) // 16 * 16
-            hd = np.frombuffer(src, dtype=np.int32, count=PLAN_INTS, offset=o_hdr)
-            j = jobs[t]
-            j["src_off"], j["w"], j["h"], j["r0"], j["nrows"], j["out_index"] = off, w, h, hd[2], hd[3], comp[s_]
-            j["need_h"], j["need_v"], j["left"], j["top"], j["hk"], j["vk"] = hd[4], hd[5], hd[6], hd[7], hd[8], hd[9]
-            j["hcoef_off"] = (off + o_hdr) // 4 + PLAN_INTS
-            j["vcoef_off"] = j["hcoef_off"] + hd[10]
-            j["tmp_off"] = toff
-            toff += int(hd[3]) * n_px * 3
-            max_rows = max(max_rows, int(hd[3]))
-            off += sizes[t]
-        hv[o_jobs:o_jobs + jobs.nbytes] = jobs.view(np.uint8).reshape(-1)
-        L = _lib.lib()
-        with torch.cuda.stream(copy_stream):
-            dbig = slot["buf"][:o_jobs + jobs.nbytes].to(dev, non_blocking=True)
-            scratch = torch.empty(max(toff, 1), dtype=torch.uint8, device=dev)
-            base = dbig.data_ptr()
-            rc = L.clipmi_resize_crop_rgb8(base, base + o_jobs, len(entries), max_rows, base, n_px, devt.data_ptr(),
-                                           scratch.data_ptr(), _lib.stream_ptr(dev))
-            _lib.check(rc, "clipmi_resize_crop_rgb8")
+            status = None
+            if len(e3):
+                # every field of the records comes out of the regions' headers as one strided numpy gather: no Python per image
+                n3 = len(e3)
+                st = np.lib.stride_tricks.as_strided
+                H = st(bigview[:4 * JPEG_HDR_INTS].view(np.int32), shape=(n, JPEG_HDR_INTS), strides=(cap, 4))[e3].astype(np.int64)
+                w, h, blocks, nrows = H[:, 1], H[:, 2], H[:, 7], H[:, 9]
+                recs = np.zeros(n3, dtype=J.IMAGE)
+                out_sz = (w * h * 3 + 15) // 16 * 16
+                out_off = np.cumsum(out_sz) - out_sz
+                recs["stream_off"], recs["coef_off"], recs["out_off"] = e3 * cap + H[:, 18], np.cumsum(blocks) - blocks, out_off
+                recs["stream_bytes"], recs["width"], recs["height"] = H[:, 6], w, h
+                recs["ncomp"], recs["hs"], recs["vs"] = H[:, 3], H[:, 4], H[:, 5]
+                recs["quant"] = st(bigview[JPEG_QUANT_OFF:], shape=(n, 192), strides=(cap, 1))[e3].reshape(n3, 3, 64)
+                # the Huffman tables: distinct six-table sets first (files of one encoder share theirs), then distinct tables
+                tabs = st(bigview[JPEG_TABLES_OFF:], shape=(n, 6 * J.TABLE_BYTES), strides=(cap, 1))[e3]
+                sets, pool_t, set_idx = {}, {}, np.zeros((n3, 6), np.int32)
+                for k in range(n3):
+                    key = tabs[k].tobytes()
+                    idx = sets.get(key)
+                    if idx is None:
+                        idx = sets[key] = [pool_t.setdefault(key[t * J.TABLE_BYTES:(t + 1) * J.TABLE_BYTES], len(pool_t)) for t in range(6)]
+                    set_idx[k] = idx
+                recs["dc_tbl"], recs["ac_tbl"] = set_idx[:, 0::2], set_idx[:, 1::2]
+                tables = np.frombuffer(b"".join(pool_t), np.uint8)
+                jobs = np.zeros(n3, dtype=JOB)
+                jobs["src_off"], jobs["w"], jobs["h"], jobs["r0"], jobs["nrows"], jobs["out_index"] = out_off, w, h, H[:, 8], nrows, comp[e3]
+                jobs["need_h"], jobs["need_v"], jobs["left"], jobs["top"], jobs["hk"], jobs["vk"] = (H[:, 10], H[:, 11], H[:, 12], H[:, 13],
+                                                                                                  H[:, 14], H[:, 15])
+                jobs["hcoef_off"] = (e3 * cap + JPEG_COEF_OFF) // 4
+                jobs["vcoef_off"] = jobs["hcoef_off"] + H[:, 16]
+                tmp = nrows * n_px * 3
+                jobs["tmp_off"] = np.cumsum(tmp) - tmp
+                o_tab = (recs.nbytes + 15) // 16 * 16
+                o_job = (o_tab + tables.nbytes + 15) // 16 * 16
+                small = np.zeros(o_job + jobs.nbytes, np.uint8)
+                small[:recs.nbytes] = recs.view(np.uint8).reshape(-1)
+                small[o_tab:o_tab + tables.nbytes] = tables
+                small[o_job:] = jobs.view(np.uint8).reshape(-1)
+                dsmall = torch.from_numpy(small).to(dev)
+                total_blocks = int(blocks.sum())
+                ws_bytes = int(L.clipmi_jpeg_workspace_bytes(total_blocks, len(pool_t)))
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                rgb = torch.empty(int(out_sz.sum()), dtype=torch.uint8, device=dev)
+                status = torch.empty(n3, dtype=torch.int32, device=dev)
+                sb = dsmall.data_ptr()
+                rc = L.clipmi_jpeg_decode_rgb8(base, sb, n3, sb + o_tab, len(pool_t), total_blocks, int(blocks.max()), int((w * h).max()),
+                                               rgb.data_ptr(), status.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
+                _lib.check(rc, "clipmi_jpeg_decode_rgb8")
+                scratch3 = torch.empty(max(int(tmp.sum()), 1), dtype=torch.uint8, device=dev)
+                rc = L.clipmi_resize_crop_rgb8(rgb.data_ptr(), sb + o_job, n3, int(nrows.max()), base, n_px, devt.data_ptr(),
+                                               scratch3.data_ptr(), _lib.stream_ptr(dev))
+                _lib.check(rc, "clipmi_resize_crop_rgb8")
             ev = torch.cuda.Event()
             ev.record(copy_stream)
-        slot["ev"] = ev
-        keep.append((dbig, scratch, ev))                      # alive until the kernel has run
-        while len(keep) > 4:
-            keep.pop(0)
-        return ev
-
-    keep = []
+        ev.synchronize()                                      # the segment is decoded into again two batches later
+        if slot is not None:
+            slot["ev"] = ev
+        if status is not None:
+            stc = status.cpu().numpy()
+            bad_slots = [int(s_) for s_ in e3[stc != 0]]
+        return ev, bad_slots
 
     def to_device(host, slot):
         with torch.cuda.stream(copy_stream):
@@ -393,7 +445,14 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
             return ok, bad, None, None
         if not use_gpu:
             return ok, bad, torch.from_numpy(view[good] if len(ok) != len(chunk) else view.copy()), None
-        if len(ok) == len(chunk) and pin_small and pool.pin_segment(seg_index[0]):
+        small_used = any(g_ and k not in full for k, g_ in enumerate(good)) if full else True
+        if not small_used:
+            # every image of the batch sits in the big segment (full size, or as a parsed JPEG file): nothing to copy out of
+            # the n_px x n_px slots
+            with torch.cuda.stream(copy_stream):
+                devt = torch.empty((len(ok), 3, n_px, n_px), dtype=torch.uint8, device=dev)
+            ev = None
+        elif len(ok) == len(chunk) and pin_small and pool.pin_segment(seg_index[0]):
             # the segment itself is page-locked (hipHostRegister): copy it to the device where it lies, and let this
             # thread wait for the copy (1-2 ms) - the segment is decoded into again two batches later
             devt, ev = to_device(torch.from_numpy(view), None)
@@ -406,8 +465,32 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
                 np.compress(good, view, axis=0, out=slot["np"][:len(ok)])
             devt, ev = to_device(slot["buf"][:len(ok)], slot)
         if full:
-            ev = resize_on_device(devt, bigview, full, good)
+            ev, bad_slots = device_stage(devt, bigview, full, good)
+            if bad_slots:
+                ok, bad, devt = redo_on_host(bad_slots, chunk, good, ok, bad, devt)
         return ok, bad, devt, ev
+
+    def redo_on_host(bad_slots, chunk, good, ok, bad, devt):
+        """Files the device decoder reported corrupt: Pillow decides (its error handling is the reference's) - its pixels replace
+        the row, or the file joins the failed ones and its row leaves the batch."""
+        comp = np.cumsum(good) - 1
+        drop = []
+        for s_ in bad_slots:
+            try:
+                px = torch.from_numpy(load_uint8(chunk[s_], n_px)).to(dev)
+                devt[comp[s_]].copy_(px)
+            except KeyboardInterrupt:
+                raise
+            except Exception:
+                drop.append(s_)
+        if drop:
+            gone = {chunk[s_] for s_ in drop}
+            keep_rows = torch.tensor([r for r in range(len(ok)) if r not in {int(comp[s_]) for s_ in drop}], dtype=torch.long, device=dev)
+            devt = devt.index_select(0, keep_rows)
+            ok = [p_ for p_ in ok if p_ not in gone]
+            bad = [p_ for p_ in chunk if p_ in gone or p_ in set(bad)]
+        torch.cuda.synchronize(dev)
+        return ok, bad, devt
 
     def stage(chunk):
         """The thread form: decode on `workers` threads, stack, pin, copy."""
@@ -445,7 +528,7 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
             def decode_job(j):
                 if j - 2 in copies:
                     copies[j - 2].result()                 # segment j & 1 is free again
-                return [pool.decode(chunks[j], n_px, copy=False, segment=j & 1, full_cap=full_cap[0])]
+                return [pool.decode(chunks[j], n_px, copy=False, segment=j & 1, full_cap=full_cap[0], full_mode=full_mode)]
 
             def submit(j):
                 d = dec.submit(decode_job, j)              # (the result travels in a list the copy stage empties: no

@@ -207,8 +207,8 @@ def _resize_pipeline_worker(tmp):
     with clipmi.pipeline.DecodePool(3) as pool:                     # before anything initialises the GPU
         assert not torch.cuda.is_initialized()
         model = clipmi.CLIP(clipmi.weights.random_state_dict("ViT-B/32", seed=0), device="cuda:0")
-        host = list(clipmi.pipeline.encode_files(model, files, batch=4, pool=pool, device_resize_mb=0))
-        devr = list(clipmi.pipeline.encode_files(model, files, batch=4, pool=pool, device_resize_mb=8))   # 3000x2000 stays on the host
+        host = list(clipmi.pipeline.encode_files(model, files, batch=4, pool=pool, device_resize_mb=0, device_jpeg_kb=0))
+        devr = list(clipmi.pipeline.encode_files(model, files, batch=4, pool=pool, device_resize_mb=8, device_jpeg_kb=0))   # 3000x2000 stays on the host
         (_, _, _, full), _, _ = pool.decode(files[:4], 224, copy=False, full_cap=8 << 20)
         assert sorted(full) == [0, 1, 3] or sorted(full) == [0, 1]      # photo-sized RGB files travel at full size
     assert [h[0] for h in host] == [d[0] for d in devr] and [h[2] for h in host] == [d[2] for d in devr]
@@ -216,6 +216,69 @@ def _resize_pipeline_worker(tmp):
     for h, d in zip(host, devr):
         assert np.array_equal(h[1], d[1])
     open(os.path.join(tmp, "ok"), "w").write("1")
+
+
+def _jpeg_pipeline_worker(tmp):
+    """Own process, the product's start order. Baseline JPEG files of every sampling, grey, optimised tables, already-sized,
+    tall and photo-sized, beside files the device decoder must leave to Pillow (progressive, PNG, CMYK, a file over the size
+    cap), a file whose entropy-coded data ends early (the device reports it, Pillow decides) and a broken one."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import clipmi
+    from PIL import Image
+    from test_jpeg import smooth
+    rng = np.random.default_rng(31)
+    paths = []
+
+    def put(name, img, **kw):
+        p = os.path.join(tmp, name)
+        img.save(p, **kw)
+        paths.append(p)
+        return p
+
+    for i, (w, h, sub, q) in enumerate([(224, 224, 2, 95), (640, 480, 2, 85), (300, 500, 1, 90), (224, 300, 0, 75), (1600, 1200, 2, 80),
+                                        (90, 70, 2, 60), (225, 223, 1, 92)]):
+        a = smooth(rng, h, w) if i % 2 else rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        put(f"a{i:02d}.jpg", Image.fromarray(a), quality=q, subsampling=sub)
+    put("b_grey.jpg", Image.fromarray(smooth(rng, 300, 260)[..., 0]), quality=85, optimize=True)
+    put("c_prog.jpg", Image.fromarray(smooth(rng, 400, 300)), quality=85, progressive=True)
+    put("d.png", Image.fromarray(smooth(rng, 250, 350)))
+    put("e_cmyk.jpg", Image.fromarray(smooth(rng, 240, 320)).convert("CMYK"), quality=85)
+    put("f_big.jpg", Image.fromarray(rng.integers(0, 256, (900, 1200, 3), dtype=np.uint8)), quality=95)     # > 256 KB: Pillow's
+    cut = put("g_cut.jpg", Image.fromarray(smooth(rng, 320, 320)), quality=90)
+    blob = open(cut, "rb").read()
+    open(cut, "wb").write(blob[:len(blob) * 2 // 3] + b"\xff\xd9")            # parses, but the data ends early
+    bad = os.path.join(tmp, "h_broken.jpg")
+    with open(bad, "wb") as f:
+        f.write(b"broken")
+    files = paths[:5] + [bad] + paths[5:]
+    import warnings
+    warnings.simplefilter("ignore")
+    with clipmi.pipeline.DecodePool(3) as pool:                     # before anything initialises the GPU
+        assert not torch.cuda.is_initialized()
+        model = clipmi.CLIP(clipmi.weights.random_state_dict("ViT-B/32", seed=0), device="cuda:0")
+        host = list(clipmi.pipeline.encode_files(model, files, batch=5, pool=pool, device_resize_mb=0, device_jpeg_kb=0))
+        devj = list(clipmi.pipeline.encode_files(model, files, batch=5, pool=pool, device_resize_mb=0, device_jpeg_kb=256))
+        both = list(clipmi.pipeline.encode_files(model, files, batch=5, pool=pool, device_resize_mb=8, device_jpeg_kb=256))
+        (_, _, _, full), _, _ = pool.decode(files[:5], 224, copy=False, full_cap=256 << 10, full_mode=2)
+        assert {0, 2, 3} <= set(full) and all(v[0] == 3 for v in full.values())      # (files over the size cap stay with Pillow)
+    for other in (devj, both):
+        assert [h[0] for h in host] == [d[0] for d in other] and [h[2] for h in host] == [d[2] for d in other]
+        for h, d in zip(host, other):
+            assert (h[1] is None and d[1] is None) or np.array_equal(h[1], d[1])
+    failed = [p for h in host for p in h[2]]
+    assert bad in failed and len(failed) in (1, 2)                  # the cut file: whatever Pillow decides, both paths agree
+    open(os.path.join(tmp, "ok"), "w").write("1")
+
+
+def test_pipeline_jpeg_decode_on_device_gives_the_same_vectors(tmp_path):
+    """encode_files with the JPEG decode on the device (clipmi_jpeg_decode_rgb8 + clipmi_resize_crop_rgb8) returns the
+    vectors of the all-Pillow path bit for bit, alone and beside the full-size-RGB path, with the same failed files."""
+    code = f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}); " \
+           f"import test_cli_gpu as t; t._jpeg_pipeline_worker({str(tmp_path)!r})"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert (tmp_path / "ok").read_text() == "1"
 
 
 def test_pipeline_resize_on_device_gives_the_same_vectors(tmp_path):
