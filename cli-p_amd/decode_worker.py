@@ -182,7 +182,8 @@ def serve(fin, fout):
          n_px | small segment or - | byte offset of the slot | big segment or - | byte offset of the region | its size |
          what the region may take (1 full-size pixels, 2 a parsed JPEG file, 3 both) | path as hex (file names may contain
          newlines and tabs)
-       Reply: b"0" failed | b"1" the transform's n_px x n_px pixels are in the slot (or follow, when no segment was named) |
+       Reply, 17 bytes when a segment was named (status + <iiq, zero where unused): b"0" failed | b"1" the transform's n_px x n_px
+              pixels are in the slot (no segment named: b"1" + the pixels) |
               b"2" + <iiq (w, h, bytes)>: the image sits at full size, with its resize plan, in the region (decode_full) |
               b"3" + <iiq (w, h, bytes)>: a baseline JPEG file, parsed, with its resize plan, in the region (stage_jpeg)."""
     import mmap
@@ -240,6 +241,8 @@ def serve(fin, fout):
             break
         except Exception:
             reply = b"0"
+        if len(reply) == 1:
+            reply += b"\0" * 16
         fout.write(reply)
         fout.flush()
     _close_all(segments)

@@ -139,17 +139,16 @@ class DecodePool:
             try:
                 p.stdin.write(req)
                 p.stdin.flush()
-                for slot, _ in jobs:
-                    st = p.stdout.read(1)
+                # one read for the whole share: the worker answers every file with a 17-byte record (status + <iiq), and a
+                # short read means it died - the number of whole records says on which file (a read per file kept the 16
+                # parent threads handing the GIL around: 5 ms per 435-image batch)
+                raw = p.stdout.read(17 * len(jobs))
+                for k in range(len(raw) // 17):
+                    st = raw[17 * k:17 * k + 1]
                     if st == b"2" or st == b"3":
-                        rest = p.stdout.read(16)
-                        if len(rest) < 16:
-                            break
-                        ok.append((slot, (int(st),) + struct.unpack("<iiq", rest)))
-                    elif st == b"":
-                        break
+                        ok.append((jobs[k][0], (int(st),) + struct.unpack_from("<iiq", raw, 17 * k + 1)))
                     else:
-                        ok.append((slot, st == b"1"))
+                        ok.append((jobs[k][0], st == b"1"))
             except (BrokenPipeError, OSError):
                 pass
             if len(ok) < len(jobs):                # the worker died on file len(ok): that one failed, the rest in-process
@@ -238,7 +237,7 @@ def _load_safe(args):
         return None
 
 
-def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb=None, device_jpeg_kb=None):
+def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb=None, device_jpeg_kb=None, stats=None):
     """Generator over batches: yields (ok_paths, features f32 [n,E] numpy normalised, failed_paths).
     Decode runs in the worker processes of `pool` (a DecodePool) when given, else on `workers` threads (Pillow
     releases the GIL while decoding, which is enough for large photos and not for small images).
@@ -249,8 +248,11 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
     many KB are not decoded on the host at all - a worker reads the file, walks its markers and removes the byte stuffing
     (jpeg_parse.py), and clipmi_jpeg_decode_rgb8 + clipmi_resize_crop_rgb8 produce the transform's pixels in HBM, the same
     bytes as Pillow's. Every other file (progressive, PNG, CMYK ...) and every file the device reports corrupt takes the
-    Pillow path as before."""
+    Pillow path as before.
+    stats: a dict that receives the seconds each of the three pipelined stages was busy (decode_s: worker processes, copy_s:
+    shared memory -> device incl. the decode / resize kernels, encode_s) and the files that took the device decoder (jpeg_files)."""
     import os
+    import time
     n_px = model.visual.input_resolution
     dev = model.device
     use_gpu = dev.type == "cuda"
@@ -275,6 +277,7 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
     if jpeg_cap and not room_for(jpeg_cap):
         jpeg_cap = 0
     full_cap = [max(resize_cap, jpeg_cap)]               # bytes per region of the big segment; [0]: mutable (may be switched off)
+    jpeg_state = {"files": 0}
     full_mode = (1 if resize_cap else 0) | (2 if jpeg_cap else 0)
 
     # three pinned staging buffers used in turn (GPU): batch i may still be in its H2D copy while batch i+1 is filled;
@@ -310,7 +313,8 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
         of the segment where it lies (it is page-locked: no packing copy on the host - packing 1 GB per batch of photo-sized
         images with one thread was slower than Pillow's resize), then clipmi_resize_crop_rgb8 for the full-size images (kind 2)
         and clipmi_jpeg_decode_rgb8 + clipmi_resize_crop_rgb8 for the parsed JPEG files (kind 3).
-        -> slots whose file the device decoder reported corrupt (they go back to Pillow)."""
+        -> (event behind the last kernel, what the consumer has to check once it has passed: the decoder's per-file status).
+        Returns when the segment has been copied (it is decoded into again two batches later); the kernels may still run."""
         from . import _lib
         from . import jpeg as J
         from .decode_worker import JPEG_COEF_OFF, JPEG_HDR_INTS, JPEG_QUANT_OFF, JPEG_TABLES_OFF, PLAN_INTS
@@ -332,9 +336,11 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
         else:
             slot = None
             src = torch.from_numpy(bigview[:used])
-        bad_slots = []
+        pending = {"keep": [], "status": None}
         with torch.cuda.stream(copy_stream):
             dbig = src.to(dev, non_blocking=True)
+            ev_h2d = torch.cuda.Event()
+            ev_h2d.record(copy_stream)
             base = dbig.data_ptr()
             if e2:
                 jobs = np.zeros(len(e2), dtype=JOB)
@@ -356,6 +362,7 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
                 rc = L.clipmi_resize_crop_rgb8(base, djobs.data_ptr(), len(e2), max_rows, base, n_px, devt.data_ptr(),
                                                scratch.data_ptr(), _lib.stream_ptr(dev))
                 _lib.check(rc, "clipmi_resize_crop_rgb8")
+                pending["keep"] += [djobs, scratch]
             status = None
             if len(e3):
                 # every field of the records comes out of the regions' headers as one strided numpy gather: no Python per image
@@ -409,15 +416,23 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
                 rc = L.clipmi_resize_crop_rgb8(rgb.data_ptr(), sb + o_job, n3, int(nrows.max()), base, n_px, devt.data_ptr(),
                                                scratch3.data_ptr(), _lib.stream_ptr(dev))
                 _lib.check(rc, "clipmi_resize_crop_rgb8")
+                pending["keep"] += [dsmall, ws, rgb, scratch3]
+                pending["status"], pending["slots"] = status, e3
+                used3 = int(max(v[3] for v in full.values() if v[0] == 3))
+                # regions are copied whole: size the next batches' regions by what this one needed (a file that does not fit its
+                # region takes the Pillow path; when many stop fitting, the configured size is back)
+                want = 1 << max(16, (2 * used3 - 1).bit_length())
+                if jpeg_state["files"] and n3 * 2 < jpeg_state["files"]:
+                    want = jpeg_cap
+                jpeg_state["files"] = n3
+                full_cap[0] = max(resize_cap, min(jpeg_cap, want))
             ev = torch.cuda.Event()
             ev.record(copy_stream)
-        ev.synchronize()                                      # the segment is decoded into again two batches later
+        ev_h2d.synchronize()
+        pending["keep"].append(dbig)
         if slot is not None:
             slot["ev"] = ev
-        if status is not None:
-            stc = status.cpu().numpy()
-            bad_slots = [int(s_) for s_ in e3[stc != 0]]
-        return ev, bad_slots
+        return ev, pending
 
     def to_device(host, slot):
         with torch.cuda.stream(copy_stream):
@@ -464,11 +479,11 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
             else:
                 np.compress(good, view, axis=0, out=slot["np"][:len(ok)])
             devt, ev = to_device(slot["buf"][:len(ok)], slot)
+        pending = None
         if full:
-            ev, bad_slots = device_stage(devt, bigview, full, good)
-            if bad_slots:
-                ok, bad, devt = redo_on_host(bad_slots, chunk, good, ok, bad, devt)
-        return ok, bad, devt, ev
+            ev, pending = device_stage(devt, bigview, full, good)
+            pending["chunk"], pending["good"] = chunk, good.copy()
+        return ok, bad, devt, ev, pending
 
     def redo_on_host(bad_slots, chunk, good, ok, bad, devt):
         """Files the device decoder reported corrupt: Pillow decides (its error handling is the reference's) - its pixels replace
@@ -510,12 +525,22 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
     chunks = [paths[i:i + batch] for i in range(0, len(paths), batch)]
 
     def consume(item):
-        ok, bad, devt, ev = item
+        ok, bad, devt, ev = item[:4]
+        pending = item[4] if len(item) > 4 else None
         feats = None
+        t0 = time.perf_counter()
         if devt is not None:
+            if pending is not None and pending["status"] is not None:
+                ev.synchronize()
+                stc = pending["status"].cpu().numpy()
+                if stc.any():
+                    ok, bad, devt = redo_on_host([int(s_) for s_ in pending["slots"][stc != 0]], pending["chunk"], pending["good"],
+                                                 ok, bad, devt)
             if ev is not None:
                 torch.cuda.current_stream(dev).wait_event(ev)
             feats = model.encode_image(devt, normalize=True).cpu().numpy().astype("float32")
+        if stats is not None:
+            stats["encode_s"] = stats.get("encode_s", 0.0) + time.perf_counter() - t0
         return ok, feats, bad
 
     if pool is not None:
@@ -528,11 +553,26 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
             def decode_job(j):
                 if j - 2 in copies:
                     copies[j - 2].result()                 # segment j & 1 is free again
-                return [pool.decode(chunks[j], n_px, copy=False, segment=j & 1, full_cap=full_cap[0], full_mode=full_mode)]
+                t0 = time.perf_counter()
+                r = [pool.decode(chunks[j], n_px, copy=False, segment=j & 1, full_cap=full_cap[0], full_mode=full_mode)]
+                if stats is not None:
+                    stats["decode_s"] = stats.get("decode_s", 0.0) + time.perf_counter() - t0
+                return r
+
+            def copy_job(d, j):
+                seg_index[0] = j & 1
+                dec_ = d.result().pop()
+                t0 = time.perf_counter()
+                r = copy_out(dec_, chunks[j])
+                if stats is not None:
+                    stats["copy_s"] = stats.get("copy_s", 0.0) + time.perf_counter() - t0
+                    if len(dec_[0]) == 4:
+                        stats["jpeg_files"] = stats.get("jpeg_files", 0) + sum(1 for v in dec_[0][3].values() if v[0] == 3)
+                return r
 
             def submit(j):
                 d = dec.submit(decode_job, j)              # (the result travels in a list the copy stage empties: no
-                copies[j] = cpy.submit(lambda d=d, j=j: (seg_index.__setitem__(0, j & 1), copy_out(d.result().pop(), chunks[j]))[1])   # view outlives its copy)
+                copies[j] = cpy.submit(copy_job, d, j)     # view outlives its copy)
 
             for j in range(min(2, len(chunks))):
                 submit(j)
