@@ -20,7 +20,7 @@ __all__ = ["_lib", "ClipmiError", "IndexFlatIP", "ShardedFlatIP", "METRIC_INNER_
 from . import weights  # noqa: E402
 from . import model  # noqa: E402
 from .model import CLIP, load, make_transform, available_models  # noqa: E402
-from . import tokenizer, store, pipeline, resize  # noqa: E402
+from . import tokenizer, store, pipeline, resize, jpeg, jpeg_parse  # noqa: E402
 from .tokenizer import tokenize  # noqa: E402
 from . import ranks  # noqa: E402
 from . import indexer, repl  # noqa: E402
