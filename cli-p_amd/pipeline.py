@@ -244,7 +244,7 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
     device_resize_mb (default $CLIPMI_DEVICE_RESIZE_MB, 0 = off; needs `pool` and a GPU): 8-bit RGB images of up to that
     many MB decoded travel at full size and are resized + cropped by clipmi_resize_crop_rgb8 - the same pixels, with the
     workers left to decode only (Pillow's bicubic resize is half of a photo-sized file's host time).
-    device_jpeg_kb (default $CLIPMI_DEVICE_JPEG_KB, else 256; 0 = off; needs `pool` and a GPU): baseline JPEG files of up to that
+    device_jpeg_kb (default $CLIPMI_DEVICE_JPEG_KB, else 1024; 0 = off; needs `pool` and a GPU): baseline JPEG files of up to that
     many KB are not decoded on the host at all - a worker reads the file, walks its markers and removes the byte stuffing
     (jpeg_parse.py), and clipmi_jpeg_decode_rgb8 + clipmi_resize_crop_rgb8 produce the transform's pixels in HBM, the same
     bytes as Pillow's. Every other file (progressive, PNG, CMYK ...) and every file the device reports corrupt takes the
@@ -264,7 +264,7 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
               f"decoding on {workers} threads)")
         pool = None
     if device_jpeg_kb is None:
-        device_jpeg_kb = float(os.environ.get("CLIPMI_DEVICE_JPEG_KB", "256"))
+        device_jpeg_kb = float(os.environ.get("CLIPMI_DEVICE_JPEG_KB", "1024"))
     on_device = use_gpu and pool is not None
     resize_cap = int(device_resize_mb * (1 << 20)) if on_device else 0
     jpeg_cap = int(device_jpeg_kb * 1024) if on_device else 0
@@ -421,7 +421,7 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
                 used3 = int(max(v[3] for v in full.values() if v[0] == 3))
                 # regions are copied whole: size the next batches' regions by what this one needed (a file that does not fit its
                 # region takes the Pillow path; when many stop fitting, the configured size is back)
-                want = 1 << max(16, (2 * used3 - 1).bit_length())
+                want = max(1 << 16, (used3 + used3 // 4 + 65535) // 65536 * 65536)
                 if jpeg_state["files"] and n3 * 2 < jpeg_state["files"]:
                     want = jpeg_cap
                 jpeg_state["files"] = n3

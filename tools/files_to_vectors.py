@@ -11,22 +11,23 @@ def main():
     import torch
     from PIL import Image
     rng = np.random.default_rng(0)
-    n = 2 * 870
+    n = 2 * 870 if kind != "photo2k" else 435
+    side = (224, 224) if kind != "photo2k" else (1500, 2000)
     d = tempfile.mkdtemp(prefix="clipmi_f2v_")
     try:
-        yy, xx = np.mgrid[0:224, 0:224]
+        yy, xx = np.mgrid[0:side[0], 0:side[1]]
         for i in range(n):
             if kind == "noise":
                 a = rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)
             else:
                 base = np.stack([127 + 100 * np.sin(xx / (5.0 + i % 7) + yy / 17.0), 127 + 100 * np.cos(xx / 13.0 - yy / (4.0 + i % 5)), (xx * 3 + yy * 2 + i) % 256], -1)
-                a = np.clip(base + rng.normal(0, 12, (224, 224, 3)), 0, 255).astype(np.uint8)
+                a = np.clip(base + rng.normal(0, 12, side + (3,)), 0, 255).astype(np.uint8)
             Image.fromarray(a).save(os.path.join(d, f"img_{i:05d}.jpg"), quality=95 if kind == "noise" else 85)
-        paths = sorted(os.path.join(d, f) for f in os.listdir(d)) * 5
+        paths = sorted(os.path.join(d, f) for f in os.listdir(d)) * (5 if kind != "photo2k" else 3)
         print("shm free MB", pool.shm_room() >> 20, "workers", pool.n, "file KB", os.path.getsize(paths[0]) >> 10, flush=True)
         model = clipmi.CLIP(clipmi.weights.random_state_dict("ViT-B/32", seed=0), device="cuda:0")
-        for batch in (435, 870):
-            for kb in (0, 256):
+        for batch in ((435, 870) if kind != "photo2k" else (435,)):
+            for kb in ((0, 1024) if kind != "photo2k" else (4096,)):
                 for _ in clipmi.pipeline.encode_files(model, paths[:batch], batch=batch, pool=pool, device_jpeg_kb=kb):
                     pass
                 t0 = time.perf_counter(); got = 0; st = {}
