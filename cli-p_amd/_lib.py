@@ -185,6 +185,20 @@ def stream_ptr(device=None):
 _SIDE_STREAMS = {}
 
 
+_COPY_STREAMS = {}
+
+
+def copy_stream(device):
+    """THE stream for host -> device copies that run beside the kernels (pipeline.encode_files): one per device for the whole
+    process, for the same reason as side_stream - a stream per call used up the hardware queues."""
+    import torch
+    key = torch.device(device).index
+    s = _COPY_STREAMS.get(key)
+    if s is None:
+        s = _COPY_STREAMS[key] = torch.cuda.Stream(device=device)
+    return s
+
+
 def side_stream(device):
     """THE internal HIP stream that work enqueued on torch's current stream of `device` may overlap with (CLIP.encode_image's
     second kernel sequence, IndexFlatIP's pipelined passes): ONE per (device, caller's stream) for the whole process, shared by

@@ -162,7 +162,7 @@ def stage_jpeg(path, n_px, region):
     o_stream = (JPEG_COEF_OFF + 4 * (nh + nv) + 15) // 16 * 16
     total = (o_stream + len(p.stream) + 16 + 15) // 16 * 16
     if total > region.size:
-        return None
+        return p.width, p.height, -total
     ints = np.frombuffer(region, dtype=np.int32, count=JPEG_HDR_INTS)
     ints[:] = [3, p.width, p.height, p.ncomp, p.hs, p.vs, len(p.stream), p.blocks(), plan["r0"], plan["nrows"], plan["need_h"],
                plan["need_v"], plan["left"], plan["top"], plan["hk"], plan["vk"], nh, nv, o_stream, JPEG_COEF_OFF] + [0] * 12
@@ -185,7 +185,8 @@ def serve(fin, fout):
        Reply, 17 bytes when a segment was named (status + <iiq, zero where unused): b"0" failed | b"1" the transform's n_px x n_px
               pixels are in the slot (no segment named: b"1" + the pixels) |
               b"2" + <iiq (w, h, bytes)>: the image sits at full size, with its resize plan, in the region (decode_full) |
-              b"3" + <iiq (w, h, bytes)>: a baseline JPEG file, parsed, with its resize plan, in the region (stage_jpeg)."""
+              b"3" + <iiq (w, h, bytes)>: a baseline JPEG file, parsed, with its resize plan, in the region (stage_jpeg) |
+              b"5" + <iiq (w, h, bytes)>: as b"1", and the file would have been a b"3" with a region of that many bytes."""
     import mmap
     import os
     import struct
@@ -213,7 +214,7 @@ def serve(fin, fout):
             n_px_s, shm_name, off_s, big_name, big_off_s, big_cap_s, mode_s, path = line.rstrip(b"\n").split(b"\t", 7)
             n_px, off, mode = int(n_px_s), int(off_s), int(mode_s)
             fname = bytes.fromhex(path.decode("ascii")).decode("utf-8", "surrogateescape")      # hex: see DecodePool._run
-            reply = None
+            reply = wanted = None
             if big_name != b"-":
                 region = np.frombuffer(mapped(big_name.decode()), dtype=np.uint8, count=int(big_cap_s), offset=int(big_off_s))
                 full = None
@@ -222,6 +223,8 @@ def serve(fin, fout):
                         full = stage_jpeg(fname, n_px, region)
                     except Exception:                          # not a file for the device decoder (or unreadable: Pillow reports it)
                         full = None
+                    if full is not None and full[2] < 0:
+                        full, wanted = None, (full[0], full[1], -full[2])
                     if full is not None:
                         reply = b"3" + struct.pack("<iiq", *full)
                 if full is None and mode & 1:
@@ -236,7 +239,7 @@ def serve(fin, fout):
                     slot = np.frombuffer(mapped(shm_name.decode()), dtype=np.uint8, count=3 * n_px * n_px, offset=off)
                     load_uint8(fname, n_px, out=slot.reshape(3, n_px, n_px))
                     slot = None                                # no view may outlive the request (close() refuses then)
-                    reply = b"1"
+                    reply = b"1" if wanted is None else b"5" + struct.pack("<iiq", *wanted)
         except KeyboardInterrupt:
             break
         except Exception:

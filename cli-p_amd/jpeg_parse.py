@@ -6,6 +6,8 @@ YCbCr with luma sampling 1x1 / 2x1 / 2x2 and 1x1 chroma, no restart interval - a
 else (progressive, CMYK / RGB-coded, 12-bit, arithmetic coding, odd sampling, not a JPEG): those files stay with Pillow.
 That is a choice of decoder per file format, made on the host from the file's own header.
 """
+import re
+
 import numpy as np
 
 TABLE_BYTES = 288          # a raw table: DHT's 16 counts + up to 256 symbols (zero padded to 272) + class (0 DC, 1 AC) + 15 zero bytes
@@ -14,6 +16,9 @@ _NATURAL = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12,
                      21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53,
                      60, 61, 54, 47, 55, 62, 63])
 _INV_NATURAL = np.argsort(_NATURAL)
+
+
+_MARKER = re.compile(rb"\xff[^\x00]")
 
 
 class Unsupported(Exception):
@@ -134,21 +139,22 @@ def parse(data):
     else:
         out.hs = out.vs = 1
     out.quant, out.tables = quant, tables
-    # the entropy-coded segment ends at the first marker that is not a stuffed 0xFF00
+    # the entropy-coded segment ends at the first marker that is not a stuffed 0xFF00 (one C-speed search: a photo's segment
+    # holds thousands of stuffed bytes)
     i += 2 + L
-    j = i
-    find = data.find
-    while True:
-        j = find(b"\xff", j)
-        if j < 0 or j + 1 >= n:
+    m_ = _MARKER.search(data, i)
+    if m_ is None:
+        raise Unsupported("no end of image")
+    j = m_.start()
+    nxt = data[j + 1]
+    if nxt == 0xFF:                                      # fill bytes in front of a marker: rare, walk them
+        while j + 1 < n and data[j + 1] == 0xFF:
+            j += 1
+        if j + 1 >= n:
             raise Unsupported("no end of image")
         nxt = data[j + 1]
         if nxt == 0:
-            j += 2
-        elif nxt == 0xFF:
-            j += 1
-        else:
-            break
+            raise Unsupported("fill bytes inside the scan")
     if nxt != 0xD9:
         raise Unsupported("marker inside the scan")         # restart markers, further scans
     out.stream = data[i:j].replace(b"\xff\x00", b"\xff")

@@ -49,6 +49,8 @@ class DecodePool:
         self._all_procs = list(self.procs)
         self.threads = ThreadPoolExecutor(max_workers=self.n)
         self.segs = [None, None, None, None]      # 0, 1: the n_px x n_px slots of two batches in turn; 2, 3: their full-size regions
+        self.jpeg_wanted = 0                      # largest region a JPEG file asked for and did not get (encode_files sizes by it)
+        self.jpeg_cap_hint = 0                    # the region size the last encode_files call ended with
 
     def _segment(self, nbytes, which=0):
         from multiprocessing import shared_memory
@@ -147,6 +149,9 @@ class DecodePool:
                     st = raw[17 * k:17 * k + 1]
                     if st == b"2" or st == b"3":
                         ok.append((jobs[k][0], (int(st),) + struct.unpack_from("<iiq", raw, 17 * k + 1)))
+                    elif st == b"5":                       # Pillow decoded it; a larger region would have taken the file itself
+                        self.jpeg_wanted = max(self.jpeg_wanted, struct.unpack_from("<iiq", raw, 17 * k + 1)[2])
+                        ok.append((jobs[k][0], True))
                     else:
                         ok.append((jobs[k][0], st == b"1"))
             except (BrokenPipeError, OSError):
@@ -256,7 +261,10 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
     n_px = model.visual.input_resolution
     dev = model.device
     use_gpu = dev.type == "cuda"
-    copy_stream = torch.cuda.Stream(device=dev) if use_gpu else None
+    copy_stream = None
+    if use_gpu:
+        from . import _lib as _l
+        copy_stream = _l.copy_stream(dev)
     if device_resize_mb is None:
         device_resize_mb = float(os.environ.get("CLIPMI_DEVICE_RESIZE_MB", "0"))
     if pool is not None and pool.shm_room() < 2 * batch * 3 * n_px * n_px + (64 << 20):
@@ -276,8 +284,10 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
         resize_cap = 0
     if jpeg_cap and not room_for(jpeg_cap):
         jpeg_cap = 0
-    full_cap = [max(resize_cap, jpeg_cap)]               # bytes per region of the big segment; [0]: mutable (may be switched off)
-    jpeg_state = {"files": 0}
+    # regions are copied to the device whole, so JPEG regions start small (or where the pool's last call ended) and follow the
+    # files: a file that does not fit is decoded by Pillow this once and says what it would have needed (DecodePool.jpeg_wanted)
+    jpeg_now = min(jpeg_cap, pool.jpeg_cap_hint or (128 << 10)) if jpeg_cap else 0
+    full_cap = [max(resize_cap, jpeg_now)]               # bytes per region of the big segment; [0]: mutable (may be switched off)
     full_mode = (1 if resize_cap else 0) | (2 if jpeg_cap else 0)
 
     # three pinned staging buffers used in turn (GPU): batch i may still be in its H2D copy while batch i+1 is filled;
@@ -313,8 +323,11 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
         of the segment where it lies (it is page-locked: no packing copy on the host - packing 1 GB per batch of photo-sized
         images with one thread was slower than Pillow's resize), then clipmi_resize_crop_rgb8 for the full-size images (kind 2)
         and clipmi_jpeg_decode_rgb8 + clipmi_resize_crop_rgb8 for the parsed JPEG files (kind 3).
-        -> (event behind the last kernel, what the consumer has to check once it has passed: the decoder's per-file status).
-        Returns when the segment has been copied (it is decoded into again two batches later); the kernels may still run."""
+        The copy stream carries the copies only; the kernels go to the process's ONE side stream (_lib.side_stream: this ROCm gives a
+        process three hardware queues) behind an event, so that the next batch's copy runs beside this batch's kernels instead of
+        behind them, and the consumer finds them queued in front of its encode step.
+        -> (event behind the kernels, pending: what the consumer checks afterwards - the decoder's per-file status). Returns when the
+        segment has been copied (it is decoded into again two batches later)."""
         from . import _lib
         from . import jpeg as J
         from .decode_worker import JPEG_COEF_OFF, JPEG_HDR_INTS, JPEG_QUANT_OFF, JPEG_TABLES_OFF, PLAN_INTS
@@ -336,11 +349,9 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
         else:
             slot = None
             src = torch.from_numpy(bigview[:used])
-        pending = {"keep": [], "status": None}
+        pending = {"keep": [], "status": None, "launch": []}
         with torch.cuda.stream(copy_stream):
             dbig = src.to(dev, non_blocking=True)
-            ev_h2d = torch.cuda.Event()
-            ev_h2d.record(copy_stream)
             base = dbig.data_ptr()
             if e2:
                 jobs = np.zeros(len(e2), dtype=JOB)
@@ -359,11 +370,14 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
                     max_rows = max(max_rows, int(hd[3]))
                 djobs = torch.from_numpy(jobs.view(np.uint8).reshape(-1).copy()).to(dev)
                 scratch = torch.empty(max(toff, 1), dtype=torch.uint8, device=dev)
-                rc = L.clipmi_resize_crop_rgb8(base, djobs.data_ptr(), len(e2), max_rows, base, n_px, devt.data_ptr(),
-                                               scratch.data_ptr(), _lib.stream_ptr(dev))
-                _lib.check(rc, "clipmi_resize_crop_rgb8")
                 pending["keep"] += [djobs, scratch]
-            status = None
+
+                def resize_full(djobs=djobs, scratch=scratch, n2=len(e2), max_rows=max_rows):
+                    rc = L.clipmi_resize_crop_rgb8(base, djobs.data_ptr(), n2, max_rows, base, n_px, devt.data_ptr(),
+                                                   scratch.data_ptr(), _lib.stream_ptr(dev))
+                    _lib.check(rc, "clipmi_resize_crop_rgb8")
+
+                pending["launch"].append(resize_full)
             if len(e3):
                 # every field of the records comes out of the regions' headers as one strided numpy gather: no Python per image
                 n3 = len(e3)
@@ -408,30 +422,34 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
                 rgb = torch.empty(int(out_sz.sum()), dtype=torch.uint8, device=dev)
                 status = torch.empty(n3, dtype=torch.int32, device=dev)
-                sb = dsmall.data_ptr()
-                rc = L.clipmi_jpeg_decode_rgb8(base, sb, n3, sb + o_tab, len(pool_t), total_blocks, int(blocks.max()), int((w * h).max()),
-                                               rgb.data_ptr(), status.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
-                _lib.check(rc, "clipmi_jpeg_decode_rgb8")
                 scratch3 = torch.empty(max(int(tmp.sum()), 1), dtype=torch.uint8, device=dev)
-                rc = L.clipmi_resize_crop_rgb8(rgb.data_ptr(), sb + o_job, n3, int(nrows.max()), base, n_px, devt.data_ptr(),
-                                               scratch3.data_ptr(), _lib.stream_ptr(dev))
-                _lib.check(rc, "clipmi_resize_crop_rgb8")
+                nt, mb, mp, mr = len(pool_t), int(blocks.max()), int((w * h).max()), int(nrows.max())
+
+                def decode_jpeg():
+                    sb = dsmall.data_ptr()
+                    rc = L.clipmi_jpeg_decode_rgb8(base, sb, n3, sb + o_tab, nt, total_blocks, mb, mp, rgb.data_ptr(), status.data_ptr(),
+                                                   ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
+                    _lib.check(rc, "clipmi_jpeg_decode_rgb8")
+                    rc = L.clipmi_resize_crop_rgb8(rgb.data_ptr(), sb + o_job, n3, mr, base, n_px, devt.data_ptr(), scratch3.data_ptr(),
+                                                   _lib.stream_ptr(dev))
+                    _lib.check(rc, "clipmi_resize_crop_rgb8")
+
+                pending["launch"].append(decode_jpeg)
                 pending["keep"] += [dsmall, ws, rgb, scratch3]
                 pending["status"], pending["slots"] = status, e3
-                used3 = int(max(v[3] for v in full.values() if v[0] == 3))
-                # regions are copied whole: size the next batches' regions by what this one needed (a file that does not fit its
-                # region takes the Pillow path; when many stop fitting, the configured size is back)
-                want = max(1 << 16, (used3 + used3 // 4 + 65535) // 65536 * 65536)
-                if jpeg_state["files"] and n3 * 2 < jpeg_state["files"]:
-                    want = jpeg_cap
-                jpeg_state["files"] = n3
-                full_cap[0] = max(resize_cap, min(jpeg_cap, want))
+            ev_copy = torch.cuda.Event()
+            ev_copy.record(copy_stream)
+        side = _lib.side_stream(dev)[1]
+        with torch.cuda.stream(side):
+            side.wait_event(ev_copy)
+            for launch in pending["launch"]:
+                launch()
             ev = torch.cuda.Event()
-            ev.record(copy_stream)
-        ev_h2d.synchronize()
+            ev.record(side)
+        ev_copy.synchronize()                                 # the segment is decoded into again two batches later
         pending["keep"].append(dbig)
         if slot is not None:
-            slot["ev"] = ev
+            slot["ev"] = ev_copy
         return ev, pending
 
     def to_device(host, slot):
@@ -483,6 +501,13 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
         if full:
             ev, pending = device_stage(devt, bigview, full, good)
             pending["chunk"], pending["good"] = chunk, good.copy()
+        if jpeg_cap and full_cap[0]:
+            # the next batches' JPEG regions: 1.25 x the largest file this batch held or turned away
+            used3 = max([int(v[3]) for v in (full or {}).values() if v[0] == 3] + [pool.jpeg_wanted])
+            pool.jpeg_wanted = 0
+            if used3:
+                pool.jpeg_cap_hint = min(jpeg_cap, max(1 << 16, (used3 + used3 // 4 + 65535) // 65536 * 65536))
+                full_cap[0] = max(resize_cap, pool.jpeg_cap_hint)
         return ok, bad, devt, ev, pending
 
     def redo_on_host(bad_slots, chunk, good, ok, bad, devt):
@@ -530,15 +555,15 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
         feats = None
         t0 = time.perf_counter()
         if devt is not None:
-            if pending is not None and pending["status"] is not None:
-                ev.synchronize()
-                stc = pending["status"].cpu().numpy()
-                if stc.any():
-                    ok, bad, devt = redo_on_host([int(s_) for s_ in pending["slots"][stc != 0]], pending["chunk"], pending["good"],
-                                                 ok, bad, devt)
             if ev is not None:
                 torch.cuda.current_stream(dev).wait_event(ev)
             feats = model.encode_image(devt, normalize=True).cpu().numpy().astype("float32")
+            if pending is not None and pending["status"] is not None:
+                stc = pending["status"].cpu().numpy()         # (behind the encode step: nothing waits for it in the common case)
+                if stc.any():
+                    ok, bad, devt = redo_on_host([int(s_) for s_ in pending["slots"][stc != 0]], pending["chunk"],
+                                                 pending["good"], ok, bad, devt)
+                    feats = model.encode_image(devt, normalize=True).cpu().numpy().astype("float32") if len(ok) else None
         if stats is not None:
             stats["encode_s"] = stats.get("encode_s", 0.0) + time.perf_counter() - t0
         return ok, feats, bad
