@@ -42,6 +42,7 @@ constexpr int JP_T = 128;          // threads per workgroup = subsequences per c
                                    // must not share a SIMD: 870 two-wave workgroups ran 3.2 x slower than one)
 constexpr int JP_SUB_BITS = 1024;  // bits per subsequence (32 words)
 constexpr int JP_FAST = 10;        // bits of the direct look-up
+constexpr int JP_SPEC = 3;         // speculative rounds before the rounds turn serial (jpeg_huffman_kernel)
 constexpr int JP_RAW = 288;        // bytes of a raw table: 16 counts + 256 symbols + class (0 DC, 1 AC) + 15 zero bytes
 
 // A 16-bit table entry says everything the state machine needs about a symbol: the bits to skip (code + the value bits behind it,
@@ -125,10 +126,11 @@ struct JpState {
 
 struct JpShared {
     JpLut lut[6];                              // [component][DC, AC]
-    unsigned words[JP_T * 33 + 40];            // the chunk's big-endian words, subsequence i at 33 i (bank spread)
+    unsigned words[JP_T * 33 + 40];            // the chunk's big-endian words, word i at i + i / 32 (subsequence i at 33 i: bank spread)
     JpState exit_state[JP_T];
     int blocks[JP_T];
     unsigned char nat[64];
+    int first[2];
     int end_p;
     int bad;
 };
@@ -169,8 +171,8 @@ __device__ __forceinline__ int jp_decode(JpShared& sh, unsigned cw0, int bpm, in
         if (gw != cur) {
             cur = gw;
             const unsigned r = gw - cw0;
-            w0 = sh.words[(r >> 5) * 33 + (r & 31)];
-            w1 = sh.words[((r + 1) >> 5) * 33 + ((r + 1) & 31)];
+            w0 = sh.words[r + (r >> 5)];                   // (word i sits at i + i / 32)
+            w1 = sh.words[r + 1 + ((r + 1) >> 5)];
         }
         const unsigned x = (unsigned)(((((unsigned long long)w0) << 32) | w1) << (p & 31) >> 32);
         const bool ac = z != 0;
@@ -229,7 +231,7 @@ __device__ __forceinline__ int jp_decode_wave(JpShared& sh, unsigned cw0, int bp
         const int c = jp_comp(blk, hv);
         const unsigned q = p + lane;
         const unsigned r = (q >> 5) - cw0;
-        const unsigned w0 = sh.words[(r >> 5) * 33 + (r & 31)], w1 = sh.words[((r + 1) >> 5) * 33 + ((r + 1) & 31)];
+        const unsigned w0 = sh.words[r + (r >> 5)], w1 = sh.words[r + 1 + ((r + 1) >> 5)];        // (word i sits at i + i / 32)
         const unsigned x = (unsigned)(((((unsigned long long)w0) << 32) | w1) << (q & 31) >> 32);
         const unsigned a = jp_lookup(sh.lut[2 * c + 1], x, true);
         const unsigned room = end - p < 64u ? end - p : 64u;
@@ -243,11 +245,13 @@ __device__ __forceinline__ int jp_decode_wave(JpShared& sh, unsigned cw0, int bp
             o = JP_ADV(e);
             z = 1;
         }
-        while (o < room) {                               // AC symbols up to the window's or the block's end
-            const unsigned e = __builtin_amdgcn_readlane(a, o);
-            o += e ? JP_ADV(e) : 1u;                     // (no such code: one bit on, as jp_decode)
-            z += JP_DZ(e);
-            if (z >= 64) break;
+        if (o < room) {                                  // AC symbols up to the window's or the block's end
+            const unsigned a1 = a ? a : 1u;              // (no such code: one bit on, no step - as jp_decode)
+            do {
+                const unsigned e = __builtin_amdgcn_readlane(a1, o);
+                o += JP_ADV(e);
+                z += JP_DZ(e);
+            } while ((o < room) & (z < 64));
         }
         if (z >= 64) {
             z = 0;
@@ -300,7 +304,7 @@ __global__ void __launch_bounds__(JP_T) jpeg_huffman_kernel(const unsigned char*
         const unsigned cw0 = c0 * 32u;
         for (unsigned r = tid; r < (unsigned)JP_T * 32u + 8u; r += JP_T) {      // the chunk's words + 8 of the next chunk
             const unsigned g = cw0 + r;
-            sh.words[(r >> 5) * 33 + (r & 31)] = g < nwords ? __builtin_bswap32(src[g]) : 0u;
+            sh.words[r + (r >> 5)] = g < nwords ? __builtin_bswap32(src[g]) : 0u;
         }
         const unsigned i = c0 + tid;
         const bool act = i < nsub;
@@ -311,11 +315,22 @@ __global__ void __launch_bounds__(JP_T) jpeg_huffman_kernel(const unsigned char*
         __syncthreads();
         if (act) nb = jp_decode<false>(sh, cw0, bpm, hv, ex.p, ex.bz, end, nullptr, 0, 0);
         sh.exit_state[tid] = ex;
-        for (int round = 0; round < JP_T; ++round) {
+        // Rounds. The first JP_SPEC are speculative: every thread whose predecessor's exit state moved decodes again - on
+        // photographs that is all it takes. When states still move after that (noise: nothing re-synchronises), only the FIRST
+        // such thread decodes per round - everything in front of it is final, everything behind it would decode garbage, and one
+        // active lane runs the chain at twice the speed of a wave of diverging ones. Either way the fixed point is the
+        // sequential decode: thread 0 is exact, and a thread that decodes from a final predecessor is final.
+        if (tid == 0) sh.first[0] = sh.first[1] = JP_T;
+        for (int round = 0; round < JP_SPEC + JP_T; ++round) {
             __syncthreads();
             const JpState prev = tid ? sh.exit_state[tid - 1] : carry;
-            const bool ch = act && tid && (prev.p != start.p || prev.bz != start.bz);
+            bool ch = act && tid && (prev.p != start.p || prev.bz != start.bz);
+            if (round >= JP_SPEC && ch) atomicMin(&sh.first[round & 1], tid);
             if (!__syncthreads_or(ch)) break;
+            if (round >= JP_SPEC) {
+                ch = ch && tid == sh.first[round & 1];
+                if (tid == 0) sh.first[(round + 1) & 1] = JP_T;
+            }
             const unsigned long long m = __ballot(ch);
             if (__popcll(m) <= 2) {                        // (wave-uniform) the whole wave walks each of them: jp_decode_wave
                 unsigned long long mm = m;
