@@ -2,9 +2,9 @@
 // `transform(...)`, reference build-index.py:47-48). Pillow decodes with libjpeg-turbo (third-party, absent from the
 // reference tree); its published algorithm is restated here for the subset the host parser (cli-p_amd/jpeg.py) lets
 // through - 8-bit baseline / extended-sequential Huffman, one interleaved scan, grey or YCbCr with luma sampling 1x1 /
-// 2x1 / 2x2 and 1x1 chroma, no restart interval - and produces Pillow's bytes (tests/test_jpeg_gpu.py compares with
+// 2x1 / 2x2 and 1x1 chroma, with or without restart intervals - and produces Pillow's bytes (tests/test_jpeg_gpu.py compares with
 // Pillow itself; oracle/jpeg_oracle.py is the CPU restatement, pinned against Pillow in tests/test_jpeg.py).
-// Everything else (progressive, CMYK, restart markers, PNG, ...) stays with Pillow in the decode workers.
+// Everything else (progressive, CMYK, PNG, ...) stays with Pillow in the decode workers.
 //
 // Kernels, one batch of images per call:
 //   jpeg_build_luts_kernel   canonical Huffman codes of the batch's distinct DHT tables -> 10-bit look-up + slow-path arrays
@@ -19,6 +19,8 @@
 //                            Weissenberger & Schmidt); on noise images without end-of-block symbols it degenerates to the
 //                            serial chain, one subsequence per round, and still ends. A scan of the blocks completed per
 //                            subsequence gives every thread its first block; a last pass writes the coefficients.
+//                            Files with restart intervals need none of that: every interval starts on a byte the host found,
+//                            at a known block, with fresh DC predictions - one thread walks one interval.
 //   jpeg_dc_kernel           DC prediction: per-component running sums over the blocks in scan order
 //   jpeg_idct_kernel         jidctint.c's jpeg_idct_islow with the dequantisation folded in, one block per thread
 //   jpeg_color_kernel        jdsample.c's fancy (triangle) upsampling with jdmainct.c's edge rows + jdcolor.c's
@@ -29,12 +31,13 @@ namespace clipmi {
 namespace {
 
 struct JpegImage {             // mirrors clipmi_jpeg_image (include/clipmi.h)
-    long long stream_off, coef_off, out_off;
+    long long stream_off, coef_off, out_off, intervals_off;
     int stream_bytes;
     int width, height;
     int ncomp;
     int hs, vs;
     int dc_tbl[3], ac_tbl[3];
+    int restart_interval, n_intervals;
     unsigned char quant[3][64];
 };
 
@@ -159,9 +162,11 @@ __device__ __forceinline__ int jp_comp(unsigned blk, int hv) { return blk < (uns
 
 // One subsequence: symbols from state (p, bz) while p < end. WRITE: also stores the coefficients of blocks ablk, ablk+1, ...
 // (stops behind block `total` - 1). Returns the number of blocks completed.
-template <bool WRITE>
+// GLOBAL: the words come straight from the image's segment in memory (restart intervals: a thread walks a whole interval).
+template <bool WRITE, bool GLOBAL = false>
 __device__ __forceinline__ int jp_decode(JpShared& sh, unsigned cw0, int bpm, int hv, unsigned& p, unsigned& bz, unsigned end,
-                                         short* __restrict__ coef, long long ablk, long long total) {
+                                         short* __restrict__ coef, long long ablk, long long total,
+                                         const unsigned* __restrict__ src = nullptr, unsigned nwords = 0) {
     unsigned blk = bz >> 8, z = bz & 255;
     int done = 0;
     unsigned cur = ~0u, w0 = 0, w1 = 0;
@@ -170,9 +175,14 @@ __device__ __forceinline__ int jp_decode(JpShared& sh, unsigned cw0, int bpm, in
         const unsigned gw = p >> 5;
         if (gw != cur) {
             cur = gw;
-            const unsigned r = gw - cw0;
-            w0 = sh.words[r + (r >> 5)];                   // (word i sits at i + i / 32)
-            w1 = sh.words[r + 1 + ((r + 1) >> 5)];
+            if (GLOBAL) {
+                w0 = gw < nwords ? __builtin_bswap32(src[gw]) : 0u;
+                w1 = gw + 1 < nwords ? __builtin_bswap32(src[gw + 1]) : 0u;
+            } else {
+                const unsigned r = gw - cw0;
+                w0 = sh.words[r + (r >> 5)];               // (word i sits at i + i / 32)
+                w1 = sh.words[r + 1 + ((r + 1) >> 5)];
+            }
         }
         const unsigned x = (unsigned)(((((unsigned long long)w0) << 32) | w1) << (p & 31) >> 32);
         const bool ac = z != 0;
@@ -296,6 +306,26 @@ __global__ void __launch_bounds__(JP_T) jpeg_huffman_kernel(const unsigned char*
         sh.end_p = -1;
         sh.bad = 0;
     }
+    if (im.restart_interval > 0) {
+        // Restart intervals: every interval starts on a byte the host knows, with fresh DC predictions, and its first block is
+        // k * interval * blocks per MCU - independent chains, one thread each, no synchronisation to find.
+        if (tid == 0) sh.first[0] = 0;
+        __syncthreads();
+        const unsigned* offs = reinterpret_cast<const unsigned*>(streams + im.intervals_off);
+        const long long nmcu = mx * my, ri = im.restart_interval;
+        for (int k = tid; k < im.n_intervals; k += JP_T) {
+            unsigned p = offs[k] * 8u, bz = 0;
+            const unsigned end = (k + 1 < im.n_intervals ? offs[k + 1] : (unsigned)im.stream_bytes) * 8u;
+            const long long left = nmcu - k * ri, want = (left < ri ? left : ri) * bpm;
+            const int done = end <= nbits && p <= end
+                                 ? jp_decode<true, true>(sh, 0, bpm, hv, p, bz, end, coef, k * ri * bpm, k * ri * bpm + want, src, nwords)
+                                 : -1;
+            if (done != want || p > end) sh.first[0] = 1;          // the interval's data ended early or ran over
+        }
+        __syncthreads();
+        if (tid == 0) status[blockIdx.x] = sh.bad ? 1 : (sh.first[0] || (long long)im.n_intervals * ri < nmcu ? 2 : 0);
+        return;
+    }
     JpState carry{0u, 0u};
     long long carry_blocks = 0;
     const unsigned nsub = (nbits + JP_SUB_BITS - 1) / JP_SUB_BITS;
@@ -392,6 +422,20 @@ __global__ void __launch_bounds__(256) jpeg_dc_kernel(const JpegImage* __restric
     const long long per = (nmcu + 255) / 256;
     const long long m0 = per * tid, m1 = m0 + per < nmcu ? m0 + per : nmcu;
     short* coef = coef_all + im.coef_off * 64;
+    if (im.restart_interval > 0) {                      // predictions start at 0 in every restart interval: a thread per interval
+        const long long ri = im.restart_interval;
+        for (long long k = tid; k * ri < nmcu; k += 256) {
+            int run[3] = {0, 0, 0};
+            const long long e = (k + 1) * ri < nmcu ? (k + 1) * ri : nmcu;
+            for (long long m = k * ri; m < e; ++m)
+                for (int b = 0; b < bpm; ++b) {
+                    const int c = b < hv ? 0 : b - hv + 1;
+                    run[c] += coef[(m * bpm + b) * 64];
+                    coef[(m * bpm + b) * 64] = (short)run[c];
+                }
+        }
+        return;
+    }
     int s[3] = {0, 0, 0};
     for (long long m = m0; m < m1; ++m)
         for (int b = 0; b < bpm; ++b) s[b < hv ? 0 : b - hv + 1] += coef[(m * bpm + b) * 64];
@@ -578,7 +622,7 @@ extern "C" int64_t clipmi_jpeg_workspace_bytes(int64_t total_blocks, int ntables
 extern "C" int clipmi_jpeg_decode_rgb8(const void* streams_dev, const void* images_dev, int n, const void* tables_dev, int ntables,
                                        int64_t total_blocks, int64_t max_blocks, int64_t max_pixels, void* out_dev, int32_t* status_dev,
                                        void* ws_dev, int64_t ws_bytes, void* stream) {
-    static_assert(sizeof(JpegImage) == sizeof(clipmi_jpeg_image) && sizeof(JpegImage) == 264, "clipmi_jpeg_image layout");
+    static_assert(sizeof(JpegImage) == sizeof(clipmi_jpeg_image) && sizeof(JpegImage) == 280, "clipmi_jpeg_image layout");
     if (n == 0) return 0;
     if (!streams_dev || !images_dev || !tables_dev || !out_dev || !status_dev || !ws_dev || n < 0 || ntables < 1 || total_blocks < 1 ||
         max_blocks < 1 || max_blocks > total_blocks || max_pixels < 1)

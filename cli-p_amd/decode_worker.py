@@ -133,7 +133,8 @@ def decode_full(path, n_px, region):
 
 
 JPEG_HDR_INTS = 32        # header of a JPEG region (stage_jpeg): 3 w h ncomp hs vs stream_bytes blocks | r0 nrows need_h need_v left top hk vk
-                          # n_hcoef n_vcoef | stream offset, coefficient offset (bytes from the region's start)
+                          # n_hcoef n_vcoef | stream offset, coefficient offset (bytes from the region's start) | restart interval,
+                          # number of intervals, offset of their uint32 byte offsets into the segment
 JPEG_QUANT_OFF = 128      # 3 x 64 quantisation steps, natural order
 JPEG_TABLES_OFF = 320     # six raw Huffman tables (jpeg_parse.TABLE_BYTES each): DC, AC per component
 JPEG_COEF_OFF = 2048      # the resize plan's coefficient blocks (int32), then the entropy-coded segment (16-byte aligned)
@@ -160,12 +161,14 @@ def stage_jpeg(path, n_px, region):
         plan = _plans[key] = resize_plan(p.width, p.height, n_px)
     nh, nv = plan["hcoef"].size, plan["vcoef"].size
     o_stream = (JPEG_COEF_OFF + 4 * (nh + nv) + 15) // 16 * 16
-    total = (o_stream + len(p.stream) + 16 + 15) // 16 * 16
+    o_int = (o_stream + len(p.stream) + 16 + 15) // 16 * 16
+    n_int = len(p.starts) if p.ri else 0
+    total = (o_int + 4 * n_int + 15) // 16 * 16
     if total > region.size:
         return p.width, p.height, -total
     ints = np.frombuffer(region, dtype=np.int32, count=JPEG_HDR_INTS)
     ints[:] = [3, p.width, p.height, p.ncomp, p.hs, p.vs, len(p.stream), p.blocks(), plan["r0"], plan["nrows"], plan["need_h"],
-               plan["need_v"], plan["left"], plan["top"], plan["hk"], plan["vk"], nh, nv, o_stream, JPEG_COEF_OFF] + [0] * 12
+               plan["need_v"], plan["left"], plan["top"], plan["hk"], plan["vk"], nh, nv, o_stream, JPEG_COEF_OFF, p.ri, n_int, o_int] + [0] * 9
     region[JPEG_QUANT_OFF:JPEG_QUANT_OFF + 192] = p.quant.reshape(-1)
     region[JPEG_TABLES_OFF:JPEG_TABLES_OFF + 6 * jpeg_parse.TABLE_BYTES] = np.frombuffer(b"".join(p.tables), np.uint8)
     if nh + nv:
@@ -174,6 +177,8 @@ def stage_jpeg(path, n_px, region):
         co[nh:] = plan["vcoef"]
     region[o_stream:o_stream + len(p.stream)] = np.frombuffer(p.stream, np.uint8)
     region[o_stream + len(p.stream):total] = 0
+    if n_int:
+        np.frombuffer(region, dtype=np.uint32, count=n_int, offset=o_int)[:] = p.starts
     return p.width, p.height, total
 
 

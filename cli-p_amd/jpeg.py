@@ -3,7 +3,7 @@
 The host walks the markers and removes the 0xFF00 byte stuffing; csrc/jpeg.hip does the rest (Huffman decode in
 self-synchronising subsequences, DC prediction, jpeg_idct_islow, fancy upsampling, YCbCr -> RGB) and leaves Pillow's
 bytes in HBM: rows of width*3 RGB bytes per image, the layout `clipmi_resize_crop_rgb8` takes (resize.py). Files this
-parser does not let through (progressive, CMYK / RGB-coded, restart intervals, 12-bit, odd sampling, anything that is not a
+parser does not let through (progressive, CMYK / RGB-coded, 12-bit, odd sampling, anything that is not a
 JPEG) raise `Unsupported` and stay with Pillow in the decode workers - that is a choice of decoder per file format, made
 on the host from the file's own header; a file the device then reports as corrupt (status != 0) goes the same way, so
 that Pillow's error handling stays the reference's.
@@ -14,10 +14,10 @@ import torch
 from . import _lib
 from .jpeg_parse import TABLE_BYTES, Parsed, Unsupported, parse  # noqa: F401
 
-IMAGE = np.dtype([("stream_off", "<i8"), ("coef_off", "<i8"), ("out_off", "<i8"), ("stream_bytes", "<i4"), ("width", "<i4"),
-                  ("height", "<i4"), ("ncomp", "<i4"), ("hs", "<i4"), ("vs", "<i4"), ("dc_tbl", "<i4", 3), ("ac_tbl", "<i4", 3),
-                  ("quant", "u1", (3, 64))], align=True)
-assert IMAGE.itemsize == 264
+IMAGE = np.dtype([("stream_off", "<i8"), ("coef_off", "<i8"), ("out_off", "<i8"), ("intervals_off", "<i8"), ("stream_bytes", "<i4"),
+                  ("width", "<i4"), ("height", "<i4"), ("ncomp", "<i4"), ("hs", "<i4"), ("vs", "<i4"), ("dc_tbl", "<i4", 3),
+                  ("ac_tbl", "<i4", 3), ("restart_interval", "<i4"), ("n_intervals", "<i4"), ("quant", "u1", (3, 64))], align=True)
+assert IMAGE.itemsize == 280
 
 
 def pack(items):
@@ -38,6 +38,12 @@ def pack(items):
         pieces.append(it.stream)
         pieces.append(b"\0" * pad)
         soff += len(it.stream) + pad
+        if it.ri:                                            # restart intervals: their byte offsets travel behind the segment
+            r["restart_interval"], r["n_intervals"], r["intervals_off"] = it.ri, len(it.starts), soff
+            raw = it.starts.astype("<u4").tobytes()
+            raw += b"\0" * ((-len(raw)) % 16)
+            pieces.append(raw)
+            soff += len(raw)
         nb = it.blocks()
         coff += nb
         ooff += (it.width * it.height * 3 + 15) // 16 * 16

@@ -2,8 +2,8 @@
 build-index.py:47). numpy only - the decode workers (decode_worker.py) import this file by path, without torch.
 
 `parse` lets through what the device decodes - 8-bit baseline / extended-sequential Huffman, one interleaved scan, grey or
-YCbCr with luma sampling 1x1 / 2x1 / 2x2 and 1x1 chroma, no restart interval - and raises `Unsupported` for everything
-else (progressive, CMYK / RGB-coded, 12-bit, arithmetic coding, odd sampling, not a JPEG): those files stay with Pillow.
+YCbCr with luma sampling 1x1 / 2x1 / 2x2 and 1x1 chroma, with or without restart intervals - and raises `Unsupported` for
+everything else (progressive, CMYK / RGB-coded, 12-bit, arithmetic coding, odd sampling, not a JPEG): those files stay with Pillow.
 That is a choice of decoder per file format, made on the host from the file's own header.
 """
 import re
@@ -12,6 +12,7 @@ import numpy as np
 
 TABLE_BYTES = 288          # a raw table: DHT's 16 counts + up to 256 symbols (zero padded to 272) + class (0 DC, 1 AC) + 15 zero bytes
 MAX_STREAM = 1 << 28
+MAX_INTERVALS = 1 << 16
 _NATURAL = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14,
                      21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53,
                      60, 61, 54, 47, 55, 62, 63])
@@ -26,12 +27,15 @@ class Unsupported(Exception):
 
 
 class Parsed:
-    __slots__ = ("width", "height", "ncomp", "hs", "vs", "quant", "tables", "stream")
+    __slots__ = ("width", "height", "ncomp", "hs", "vs", "quant", "tables", "stream", "ri", "starts")
+    # ri: restart interval in MCUs (0: none); starts: uint32 byte offsets into `stream` of the restart intervals (None without)
+
+    def mcus(self):
+        hs, vs = (self.hs, self.vs) if self.ncomp == 3 else (1, 1)
+        return -(-self.width // (8 * hs)) * -(-self.height // (8 * vs))
 
     def blocks(self):
-        hs, vs = (self.hs, self.vs) if self.ncomp == 3 else (1, 1)
-        mcus = -(-self.width // (8 * hs)) * -(-self.height // (8 * vs))
-        return mcus * (hs * vs + 2 if self.ncomp == 3 else 1)
+        return self.mcus() * (self.hs * self.vs + 2 if self.ncomp == 3 else 1)
 
 
 def parse(data):
@@ -44,6 +48,7 @@ def parse(data):
     qt = {}
     huff = {}
     frame = None
+    ri = 0
     jfif = adobe = False
     adobe_tf = 0
     while True:
@@ -91,8 +96,9 @@ def parse(data):
                 huff[data[k]] = bytes(data[k + 1:k + 17 + cnt]).ljust(272, b"\0") + bytes([data[k] >> 4]) + b"\0" * 15
                 k += 17 + cnt
         elif m == 0xDD:
-            if L != 4 or data[i + 4] or data[i + 5]:
+            if L != 4:
                 raise Unsupported("restart interval")
+            ri = (data[i + 4] << 8) | data[i + 5]
         elif m == 0xE0 and data[i + 4:i + 9] == b"JFIF\0":
             jfif = True
         elif m == 0xEE and L >= 14 and data[i + 4:i + 9] == b"Adobe":
@@ -139,25 +145,51 @@ def parse(data):
     else:
         out.hs = out.vs = 1
     out.quant, out.tables = quant, tables
-    # the entropy-coded segment ends at the first marker that is not a stuffed 0xFF00 (one C-speed search: a photo's segment
+    # the entropy-coded segment ends at the first marker that is not a stuffed 0xFF00 (C-speed searches: a photo's segment
     # holds thousands of stuffed bytes)
     i += 2 + L
-    m_ = _MARKER.search(data, i)
-    if m_ is None:
-        raise Unsupported("no end of image")
-    j = m_.start()
-    nxt = data[j + 1]
-    if nxt == 0xFF:                                      # fill bytes in front of a marker: rare, walk them
-        while j + 1 < n and data[j + 1] == 0xFF:
-            j += 1
-        if j + 1 >= n:
+    out.ri, out.starts = ri, None
+    if ri:
+        # restart intervals: RSTn markers, numbered 0..7 in turn (jdmarker.c read_restart_marker), separate them; every
+        # interval starts on a byte with fresh DC predictions - an independent chain for the device. The markers are dropped.
+        want = -(-out.mcus() // ri)
+        if want > MAX_INTERVALS:
+            raise Unsupported("too many restart intervals")
+        parts, count, seg = [], 0, i
+        for m_ in _MARKER.finditer(data, i):
+            j = m_.start()
+            nxt = data[j + 1]
+            if nxt == 0xD0 + (count & 7) and count + 1 < want:
+                parts.append(data[seg:j].replace(b"\xff\x00", b"\xff"))
+                count += 1
+                seg = j + 2
+                continue
+            if nxt != 0xD9 or count + 1 != want:
+                raise Unsupported("marker inside the scan")
+            parts.append(data[seg:j].replace(b"\xff\x00", b"\xff"))
+            break
+        else:
             raise Unsupported("no end of image")
+        lens = np.fromiter((len(x) for x in parts), dtype=np.int64, count=len(parts))
+        out.starts = (np.cumsum(lens) - lens).astype(np.uint32)
+        out.stream = b"".join(parts)
+    else:
+        m_ = _MARKER.search(data, i)
+        if m_ is None:
+            raise Unsupported("no end of image")
+        j = m_.start()
         nxt = data[j + 1]
-        if nxt == 0:
-            raise Unsupported("fill bytes inside the scan")
-    if nxt != 0xD9:
-        raise Unsupported("marker inside the scan")         # restart markers, further scans
-    out.stream = data[i:j].replace(b"\xff\x00", b"\xff")
+        if nxt == 0xFF:                                      # fill bytes in front of a marker: rare, walk them
+            while j + 1 < n and data[j + 1] == 0xFF:
+                j += 1
+            if j + 1 >= n:
+                raise Unsupported("no end of image")
+            nxt = data[j + 1]
+            if nxt == 0:
+                raise Unsupported("fill bytes inside the scan")
+        if nxt != 0xD9:
+            raise Unsupported("marker inside the scan")         # further scans
+        out.stream = data[i:j].replace(b"\xff\x00", b"\xff")
     if len(out.stream) >= MAX_STREAM:
         raise Unsupported("too large")
     return out

@@ -255,7 +255,7 @@ int clipmi_resize_crop_rgb8(const void* raw_dev, const void* jobs_dev, int njobs
  * SURVEY.md §8(f) next-1): the bytes Pillow (libjpeg-turbo: Huffman decode, jpeg_idct_islow, fancy upsampling, 16-bit
  * fixed-point YCbCr -> RGB) hands to the transform, bit for bit. The HOST walks the markers (cli-p_amd/jpeg.py) and lets through
  * 8-bit baseline / extended-sequential Huffman files with one interleaved scan, 1 (grey) or 3 (YCbCr) components, luma sampling
- * 1x1, 2x1 or 2x2 with 1x1 chroma, no restart interval; everything else stays with Pillow. Per image one record; the
+ * 1x1, 2x1 or 2x2 with 1x1 chroma, with or without restart intervals; everything else stays with Pillow. Per image one record; the
  * entropy-coded segments travel with the 0xFF00 stuffing removed, each 4-byte aligned and followed by at least 16 zero bytes.
  * tables_dev: the batch's distinct Huffman tables, 288 bytes each (DHT's 16 counts + up to 256 symbols, zero padded to 272,
  * then the table class - 0 DC, 1 AC - and 15 zero bytes).
@@ -267,11 +267,14 @@ typedef struct clipmi_jpeg_image {
     int64_t stream_off;           /* bytes from streams_dev */
     int64_t coef_off;             /* the image's first block in the workspace's coefficient / sample buffers */
     int64_t out_off;              /* bytes from out_dev */
+    int64_t intervals_off;        /* restart intervals: bytes from streams_dev to n_intervals uint32 byte offsets into the segment */
     int32_t stream_bytes;
     int32_t width, height;
     int32_t ncomp;                /* 1 or 3 */
     int32_t hs, vs;               /* luma sampling factors (1,1) (2,1) (2,2) */
     int32_t dc_tbl[3], ac_tbl[3]; /* per component: index into tables_dev */
+    int32_t restart_interval;     /* MCUs per restart interval (DRI), 0 = none */
+    int32_t n_intervals;          /* ceil(MCUs / restart_interval); the RSTn markers themselves are removed from the segment */
     uint8_t quant[3][64];         /* per component: quantisation steps, natural (row-major) order */
 } clipmi_jpeg_image;
 int64_t clipmi_jpeg_workspace_bytes(int64_t total_blocks, int ntables);

@@ -7,7 +7,7 @@ The arithmetic lives in third-party dependencies that are ABSENT from /root/refe
 reference's setup.sh) and, inside it, libjpeg-turbo (this image: Pillow 12.2.0, libjpeg-turbo with the v6b API,
 `PIL.features.version("jpg") == "6.2"`). This file restates their published algorithm for the subset the device
 decoder takes (csrc/jpeg.hip): 8-bit baseline / extended-sequential Huffman JPEG (SOF0 / SOF1), one interleaved scan,
-1 or 3 components, luma sampling 1x1, 2x1 or 2x2 with 1x1 chroma, no restart interval -
+1 or 3 components, luma sampling 1x1, 2x1 or 2x2 with 1x1 chroma, with or without restart intervals -
   * jdhuff.c   canonical Huffman decode, EXTEND, DC prediction, jpeg_natural_order;
   * jidctint.c `jpeg_idct_islow` (JDCT_ISLOW is Pillow's method), dequantisation folded in, output range-limited;
   * jdsample.c `h2v1_fancy_upsample` / `h2v2_fancy_upsample` (do_fancy_upsampling is libjpeg's default) with
@@ -26,16 +26,17 @@ NATURAL = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 
 
 
 class Unsupported(Exception):
-    """A JPEG the device decoder does not take (progressive, CMYK, restart intervals, ...): Pillow's path decodes it."""
+    """A JPEG the device decoder does not take (progressive, CMYK, ...): Pillow's path decodes it."""
 
 
 def parse(data):
     """Marker walk -> dict(width, height, comps=[(id, h, v, tq)], qt={id: 64 ints in zigzag order},
-    huff={(cls, id): (bits[16], vals)}, scan=[(comp index, td, ta)], stream=unstuffed entropy-coded bytes)."""
+    huff={(cls, id): (bits[16], vals)}, scan=[(comp index, td, ta)], stream=unstuffed entropy-coded bytes, ri=restart interval
+    in MCUs (0: none), starts=[byte offset in stream of every restart interval])."""
     if data[:2] != b"\xff\xd8":
         raise Unsupported("no SOI")
     i, n = 2, len(data)
-    qt, huff, comps, scan, width, height = {}, {}, None, None, 0, 0
+    qt, huff, comps, scan, width, height, ri = {}, {}, None, None, 0, 0, 0
     jfif = adobe = False
     adobe_tf = 0
     while True:
@@ -71,8 +72,7 @@ def parse(data):
                 huff[(seg[k] >> 4, seg[k] & 15)] = (bits, list(seg[k + 17:k + 17 + cnt]))
                 k += 17 + cnt
         elif m == 0xDD:
-            if int.from_bytes(seg[:2], "big"):
-                raise Unsupported("restart interval")
+            ri = int.from_bytes(seg[:2], "big")
         elif m == 0xE0 and seg[:5] == b"JFIF\0":
             jfif = True
         elif m == 0xEE and seg[:5] == b"Adobe" and len(seg) >= 12:
@@ -97,23 +97,30 @@ def parse(data):
             raise Unsupported("RGB-coded JPEG")
         if (comps[1][1], comps[1][2], comps[2][1], comps[2][2]) != (1, 1, 1, 1) or (comps[0][1], comps[0][2]) not in ((1, 1), (2, 1), (2, 2)):
             raise Unsupported("sampling factors")
-    # entropy-coded segment: up to the first marker that is not a stuffed 0xFF00
-    j = i
+    # entropy-coded segment: up to the first marker that is not a stuffed 0xFF00; RSTn markers (jdmarker.c read_restart_marker:
+    # numbered 0..7 in turn) separate the restart intervals and are dropped
+    parts, j, count = [], i, 0
     while True:
         j = data.find(b"\xff", j)
         if j < 0 or j + 1 >= n:
             raise Unsupported("no EOI")
-        if data[j + 1] == 0:
+        nxt = data[j + 1]
+        if nxt == 0:
             j += 2
             continue
-        if data[j + 1] == 0xFF:
-            j += 1
+        if ri and nxt == 0xD0 + (count & 7):
+            parts.append(data[i:j].replace(b"\xff\x00", b"\xff"))
+            count += 1
+            i = j = j + 2
             continue
+        if nxt != 0xD9:
+            raise Unsupported("marker inside the scan")
+        parts.append(data[i:j].replace(b"\xff\x00", b"\xff"))
         break
-    if 0xD0 <= data[j + 1] <= 0xD7:
-        raise Unsupported("restart marker")
-    stream = data[i:j].replace(b"\xff\x00", b"\xff")
-    return dict(width=width, height=height, comps=comps, qt=qt, huff=huff, scan=scan, stream=stream)
+    starts = [0]
+    for part in parts[:-1]:
+        starts.append(starts[-1] + len(part))
+    return dict(width=width, height=height, comps=comps, qt=qt, huff=huff, scan=scan, stream=b"".join(parts), ri=ri, starts=starts)
 
 
 def _huff_lut(bits, vals):
@@ -152,7 +159,13 @@ def decode_coefficients(info):
     pred = [0] * len(comps)
     p = 0
     nat = NATURAL.tolist()
+    ri, starts = info.get("ri", 0), info.get("starts", [0])
+    if ri and len(starts) != -(-(mx * my) // ri):
+        raise Unsupported("restart intervals")
     for b in range(nblk):
+        if ri and b % (ri * len(order)) == 0:            # jdhuff.c process_restart: byte-aligned start, DC predictions reset
+            p = 8 * starts[b // (ri * len(order))]
+            pred = [0] * len(comps)
         ci = order[b % len(order)]
         dl, ds = luts[(0, scan[ci][1])]
         al, as_ = luts[(1, scan[ci][2])]

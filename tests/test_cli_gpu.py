@@ -241,6 +241,7 @@ def _jpeg_pipeline_worker(tmp):
         a = smooth(rng, h, w) if i % 2 else rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         put(f"a{i:02d}.jpg", Image.fromarray(a), quality=q, subsampling=sub)
     put("b_grey.jpg", Image.fromarray(smooth(rng, 300, 260)[..., 0]), quality=85, optimize=True)
+    put("b_rst.jpg", Image.fromarray(smooth(rng, 360, 480)), quality=88, restart_marker_rows=1)
     put("c_prog.jpg", Image.fromarray(smooth(rng, 400, 300)), quality=85, progressive=True)
     put("d.png", Image.fromarray(smooth(rng, 250, 350)))
     put("e_cmyk.jpg", Image.fromarray(smooth(rng, 240, 320)).convert("CMYK"), quality=85)

@@ -51,6 +51,11 @@ def test_oracle_equals_pillow_live():
     blob = encode(smooth(rng, 50, 70)[..., 1], quality=80, optimize=True)
     assert np.array_equal(jpeg_oracle.decode(blob), np.asarray(Image.open(io.BytesIO(blob)).convert("RGB")))
     assert n == 48
+    for sub in (0, 1, 2):                                  # restart intervals (DRI + RSTn markers)
+        for kw in (dict(restart_marker_blocks=1), dict(restart_marker_blocks=5), dict(restart_marker_rows=1)):
+            blob = encode(smooth(rng, 70, 100), quality=85, subsampling=sub, **kw)
+            assert b"\xff\xdd" in blob
+            assert np.array_equal(jpeg_oracle.decode(blob), np.asarray(Image.open(io.BytesIO(blob)).convert("RGB")))
 
 
 def test_parser_reads_what_pillow_reads():
@@ -89,13 +94,12 @@ def test_parser_leaves_everything_else_to_pillow():
         jpeg_parse.parse(encode(a[:, :4], quality=80, subsampling=2))      # 2 chroma columns: libjpeg upsamples without the filter
     with pytest.raises(jpeg_parse.Unsupported):
         jpeg_parse.parse(b"")
-    try:
-        blob = encode(a, quality=80, restart_marker_blocks=4)
-    except TypeError:
-        blob = None
-    if blob is not None and b"\xff\xdd" in blob:
-        with pytest.raises(jpeg_parse.Unsupported):
-            jpeg_parse.parse(blob)
+    blob = encode(a, quality=80, restart_marker_blocks=4)            # restart intervals are taken ...
+    p = jpeg_parse.parse(blob)
+    assert p.ri == 4 and len(p.starts) == -(-p.mcus() // 4) and p.starts[0] == 0 and b"\xff\xd0" not in p.stream[:int(p.starts[1]) + 2]
+    k = blob.index(b"\xff\xd1")
+    with pytest.raises(jpeg_parse.Unsupported):                       # ... unless their markers are out of turn
+        jpeg_parse.parse(blob[:k + 1] + b"\xd3" + blob[k + 2:])
 
 
 def test_pack_lays_out_aligned_streams_and_shares_tables():

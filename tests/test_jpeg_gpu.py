@@ -40,6 +40,12 @@ def test_device_decode_equals_pillow_live():
     blobs.append(encode(smooth(rng, 300, 200)[..., 0], quality=85, optimize=True))
     blobs.append(encode(smooth(rng, 300, 200), quality=85, optimize=True))
     blobs.append(encode(np.zeros((16, 16, 3), np.uint8), quality=50))
+    for (h, w) in [(64, 96), (37, 53), (480, 640), (224, 224)]:         # restart intervals: 1 MCU, a few, a row of MCUs, many rows
+        for sub in (0, 1, 2):
+            for kw in (dict(restart_marker_blocks=1), dict(restart_marker_blocks=7), dict(restart_marker_rows=1), dict(restart_marker_rows=3)):
+                a = smooth(rng, h, w) if (h + sub) % 2 else rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+                blobs.append(encode(a, quality=88, subsampling=sub, **kw))
+                assert jpeg_parse.parse(blobs[-1]).ri > 0
     got = jpeg.decode_files(blobs, DEV)
     for b, g in zip(blobs, got):
         assert g is not None
@@ -88,6 +94,19 @@ def test_corrupt_entropy_data_is_reported_or_decoded_as_pillow_does():
         if np.array_equal(g, ref):
             n_checked += 1
     assert n_checked >= 4
+
+
+def test_restart_interval_that_ends_early_is_reported():
+    rng = np.random.default_rng(25)
+    blob = encode(smooth(rng, 96, 128), quality=85, restart_marker_rows=1)
+    p = jpeg_parse.parse(blob)
+    q = jpeg_parse.parse(blob)
+    cut = int(q.starts[2])
+    q.stream = q.stream[:cut - 40] + q.stream[cut:]                 # the second interval loses its last 40 bytes
+    q.starts = np.concatenate([q.starts[:2], q.starts[2:] - 40]).astype(np.uint32)
+    out, recs, status = jpeg.decode_device([p, q], DEV)
+    st = status.cpu().tolist()
+    assert st[0] == 0 and st[1] != 0
 
 
 def test_decoded_pixels_feed_the_resize_kernel():
