@@ -38,6 +38,7 @@ struct JpegImage {             // mirrors clipmi_jpeg_image (include/clipmi.h)
     int hs, vs;
     int dc_tbl[3], ac_tbl[3];
     int restart_interval, n_intervals;
+    int stuffed, reserved;
     unsigned char quant[3][64];
 };
 
@@ -76,6 +77,76 @@ static_assert(sizeof(JpLut) % 16 == 0, "tables are copied as 16-byte pieces");
 __device__ const unsigned char jp_natural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                                  41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                                  30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// Byte stuffing (a 0x00 behind every 0xFF of entropy-coded data) removed on the device, in place: the host then only slices the
+// file (removing it there is 1.5 ms per MB of Python in a decode worker - the bound for photo-sized files). A workgroup per image
+// walks the segment in 8-KB tiles: 32 bytes per thread in registers, kept bytes counted, an exclusive scan over the workgroup, the
+// bytes written back at their compacted positions (never in front of a byte still to be read: the tile is in registers, and the
+// output only falls behind the input). Any 0xFF followed by something else than 0x00 is a marker inside the scan: the record is
+// tagged (stuffed = 2) and jpeg_huffman_kernel reports the file (status 3: Pillow decides).
+__global__ void __launch_bounds__(256) jpeg_unstuff_kernel(unsigned char* __restrict__ streams, JpegImage* __restrict__ images) {
+    JpegImage& im = images[blockIdx.x];
+    if (im.stuffed != 1) return;
+    __shared__ int wsum[4];
+    __shared__ unsigned char lastb[256];
+    __shared__ int s_marker;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char* s = streams + im.stream_off;
+    const int nraw = im.stream_bytes;
+    if (tid == 0) s_marker = 0;
+    int outpos = 0;
+    unsigned char tile_prev = 0;
+    for (int t0 = 0; t0 < nraw; t0 += 8192) {
+        const int b0 = t0 + tid * 32;
+        uint4 v[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        if (b0 < nraw) v[0] = *reinterpret_cast<const uint4*>(s + b0);                 // (the segment is 16-byte aligned and padded)
+        if (b0 + 16 < nraw) v[1] = *reinterpret_cast<const uint4*>(s + b0 + 16);
+        const unsigned char* b = reinterpret_cast<const unsigned char*>(v);
+        lastb[tid] = b[31];
+        __syncthreads();
+        unsigned char prev = tid ? lastb[tid - 1] : tile_prev;
+        const unsigned char next_prev = lastb[255];
+        int nk = 0, mk = 0;
+        unsigned dropmask = 0;                              // bit k: byte k is a stuffed 0x00 (or lies behind the segment)
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const unsigned char cur = b[k];
+            const bool in = b0 + k < nraw;
+            const bool drop = !in || (prev == 0xFF && cur == 0);
+            if (in && prev == 0xFF && cur != 0) mk = 1;
+            if (in && b0 + k == nraw - 1 && cur == 0xFF) mk = 1;         // a 0xFF with nothing behind it
+            dropmask |= (drop ? 1u : 0u) << k;
+            nk += drop ? 0 : 1;
+            prev = cur;
+        }
+        // exclusive scan of nk over the workgroup: within the wave by shuffles, across the four waves through LDS
+        int inc = nk;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int base = outpos;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        unsigned char* o = s + base + inc - nk;
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (!((dropmask >> k) & 1)) *o++ = b[k];
+        if (mk) s_marker = 1;
+        outpos += total;
+        tile_prev = next_prev;
+        __syncthreads();                                    // wsum / lastb are rewritten by the next tile
+    }
+    if (tid < 16) s[outpos + tid] = 0;                      // a zero tail for the last word (>= 16 bytes of padding follow the segment)
+    __syncthreads();
+    if (tid == 0) {
+        im.stream_bytes = outpos;
+        im.stuffed = s_marker ? 2 : 0;
+    }
+}
 
 __global__ void __launch_bounds__(256) jpeg_build_luts_kernel(const unsigned char* __restrict__ raw, JpLut* __restrict__ luts) {
     __shared__ int first_code[18], first_idx[18];
@@ -305,6 +376,10 @@ __global__ void __launch_bounds__(JP_T) jpeg_huffman_kernel(const unsigned char*
     if (tid == 0) {
         sh.end_p = -1;
         sh.bad = 0;
+    }
+    if (im.stuffed == 2) {                              // jpeg_unstuff_kernel found a marker inside the scan
+        if (tid == 0) status[blockIdx.x] = 3;
+        return;
     }
     if (im.restart_interval > 0) {
         // Restart intervals: every interval starts on a byte the host knows, with fresh DC predictions, and its first block is
@@ -619,10 +694,10 @@ extern "C" int64_t clipmi_jpeg_workspace_bytes(int64_t total_blocks, int ntables
            (int64_t)align_up((size_t)total_blocks * 64, 256);
 }
 
-extern "C" int clipmi_jpeg_decode_rgb8(const void* streams_dev, const void* images_dev, int n, const void* tables_dev, int ntables,
+extern "C" int clipmi_jpeg_decode_rgb8(void* streams_dev, void* images_dev, int n, const void* tables_dev, int ntables,
                                        int64_t total_blocks, int64_t max_blocks, int64_t max_pixels, void* out_dev, int32_t* status_dev,
                                        void* ws_dev, int64_t ws_bytes, void* stream) {
-    static_assert(sizeof(JpegImage) == sizeof(clipmi_jpeg_image) && sizeof(JpegImage) == 280, "clipmi_jpeg_image layout");
+    static_assert(sizeof(JpegImage) == sizeof(clipmi_jpeg_image) && sizeof(JpegImage) == 288, "clipmi_jpeg_image layout");
     if (n == 0) return 0;
     if (!streams_dev || !images_dev || !tables_dev || !out_dev || !status_dev || !ws_dev || n < 0 || ntables < 1 || total_blocks < 1 ||
         max_blocks < 1 || max_blocks > total_blocks || max_pixels < 1)
@@ -637,7 +712,9 @@ extern "C" int clipmi_jpeg_decode_rgb8(const void* streams_dev, const void* imag
     JpLut* luts = ar.take<JpLut>((size_t)ntables);
     short* coef = ar.take<short>((size_t)total_blocks * 64);
     unsigned char* planes = ar.take<unsigned char>((size_t)total_blocks * 64);
-    const JpegImage* images = static_cast<const JpegImage*>(images_dev);
+    JpegImage* images = static_cast<JpegImage*>(images_dev);
+    hipLaunchKernelGGL(jpeg_unstuff_kernel, dim3((unsigned)n), dim3(256), 0, st, static_cast<unsigned char*>(streams_dev), images);
+    CLIPMI_CHECK_LAUNCH("jpeg_unstuff_kernel");
     if (hipMemsetAsync(coef, 0, (size_t)total_blocks * 128, st) != hipSuccess) return set_err(CLIPMI_EHIP, "jpeg_decode_rgb8: memset");
     hipLaunchKernelGGL(jpeg_build_luts_kernel, dim3((unsigned)ntables), dim3(256), 0, st, static_cast<const unsigned char*>(tables_dev), luts);
     CLIPMI_CHECK_LAUNCH("jpeg_build_luts_kernel");

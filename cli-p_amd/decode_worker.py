@@ -134,7 +134,7 @@ def decode_full(path, n_px, region):
 
 JPEG_HDR_INTS = 32        # header of a JPEG region (stage_jpeg): 3 w h ncomp hs vs stream_bytes blocks | r0 nrows need_h need_v left top hk vk
                           # n_hcoef n_vcoef | stream offset, coefficient offset (bytes from the region's start) | restart interval,
-                          # number of intervals, offset of their uint32 byte offsets into the segment
+                          # number of intervals, offset of their uint32 byte offsets into the segment | 1: the segment keeps its stuffing
 JPEG_QUANT_OFF = 128      # 3 x 64 quantisation steps, natural order
 JPEG_TABLES_OFF = 320     # six raw Huffman tables (jpeg_parse.TABLE_BYTES each): DC, AC per component
 JPEG_COEF_OFF = 2048      # the resize plan's coefficient blocks (int32), then the entropy-coded segment (16-byte aligned)
@@ -152,7 +152,7 @@ def stage_jpeg(path, n_px, region):
         import jpeg_parse
     with open(path, "rb") as f:
         data = f.read()
-    p = jpeg_parse.parse(data)
+    p = jpeg_parse.parse(data, keep_stuffing=True)     # (a plain slice where the file allows: the device removes the byte stuffing)
     key = (p.width, p.height, n_px)
     plan = _plans.get(key)
     if plan is None:
@@ -168,7 +168,7 @@ def stage_jpeg(path, n_px, region):
         return p.width, p.height, -total
     ints = np.frombuffer(region, dtype=np.int32, count=JPEG_HDR_INTS)
     ints[:] = [3, p.width, p.height, p.ncomp, p.hs, p.vs, len(p.stream), p.blocks(), plan["r0"], plan["nrows"], plan["need_h"],
-               plan["need_v"], plan["left"], plan["top"], plan["hk"], plan["vk"], nh, nv, o_stream, JPEG_COEF_OFF, p.ri, n_int, o_int] + [0] * 9
+               plan["need_v"], plan["left"], plan["top"], plan["hk"], plan["vk"], nh, nv, o_stream, JPEG_COEF_OFF, p.ri, n_int, o_int, p.stuffed] + [0] * 8
     region[JPEG_QUANT_OFF:JPEG_QUANT_OFF + 192] = p.quant.reshape(-1)
     region[JPEG_TABLES_OFF:JPEG_TABLES_OFF + 6 * jpeg_parse.TABLE_BYTES] = np.frombuffer(b"".join(p.tables), np.uint8)
     if nh + nv:

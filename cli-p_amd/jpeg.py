@@ -1,7 +1,7 @@
 """`Image.open(tfn)` for baseline JPEG files on the device (reference build-index.py:47).
 
-The host walks the markers and removes the 0xFF00 byte stuffing; csrc/jpeg.hip does the rest (Huffman decode in
-self-synchronising subsequences, DC prediction, jpeg_idct_islow, fancy upsampling, YCbCr -> RGB) and leaves Pillow's
+The host walks the markers (and removes the 0xFF00 byte stuffing, unless it leaves that to the device too); csrc/jpeg.hip does the
+rest (Huffman decode in self-synchronising subsequences, DC prediction, jpeg_idct_islow, fancy upsampling, YCbCr -> RGB) and leaves Pillow's
 bytes in HBM: rows of width*3 RGB bytes per image, the layout `clipmi_resize_crop_rgb8` takes (resize.py). Files this
 parser does not let through (progressive, CMYK / RGB-coded, 12-bit, odd sampling, anything that is not a
 JPEG) raise `Unsupported` and stay with Pillow in the decode workers - that is a choice of decoder per file format, made
@@ -16,8 +16,9 @@ from .jpeg_parse import TABLE_BYTES, Parsed, Unsupported, parse  # noqa: F401
 
 IMAGE = np.dtype([("stream_off", "<i8"), ("coef_off", "<i8"), ("out_off", "<i8"), ("intervals_off", "<i8"), ("stream_bytes", "<i4"),
                   ("width", "<i4"), ("height", "<i4"), ("ncomp", "<i4"), ("hs", "<i4"), ("vs", "<i4"), ("dc_tbl", "<i4", 3),
-                  ("ac_tbl", "<i4", 3), ("restart_interval", "<i4"), ("n_intervals", "<i4"), ("quant", "u1", (3, 64))], align=True)
-assert IMAGE.itemsize == 280
+                  ("ac_tbl", "<i4", 3), ("restart_interval", "<i4"), ("n_intervals", "<i4"), ("stuffed", "<i4"), ("reserved", "<i4"),
+                  ("quant", "u1", (3, 64))], align=True)
+assert IMAGE.itemsize == 288
 
 
 def pack(items):
@@ -34,6 +35,7 @@ def pack(items):
         idx = [pool.setdefault(t, len(pool)) for t in it.tables]
         r["dc_tbl"], r["ac_tbl"] = idx[0::2], idx[1::2]
         r["quant"] = it.quant
+        r["stuffed"] = it.stuffed
         pad = (-len(it.stream)) % 16 + 16
         pieces.append(it.stream)
         pieces.append(b"\0" * pad)
@@ -85,13 +87,14 @@ def decode_device(items, device, stream=None):
     return out, recs, status
 
 
-def decode_files(blobs, device):
+def decode_files(blobs, device, keep_stuffing=False):
     """JPEG file contents -> list of uint8 [H,W,3] numpy arrays (None where the file is not for the device decoder or the
-    device reported it corrupt). Synchronises; a convenience for tests and tools - the pipeline keeps the pixels in HBM."""
+    device reported it corrupt). Synchronises; a convenience for tests and tools - the pipeline keeps the pixels in HBM.
+    keep_stuffing: hand the segments over as they are in the file and let the device remove the byte stuffing (the pipeline's form)."""
     items, where = [], []
     for k, b in enumerate(blobs):
         try:
-            items.append(parse(b))
+            items.append(parse(b, keep_stuffing=keep_stuffing))
             where.append(k)
         except Unsupported:
             pass

@@ -27,8 +27,9 @@ class Unsupported(Exception):
 
 
 class Parsed:
-    __slots__ = ("width", "height", "ncomp", "hs", "vs", "quant", "tables", "stream", "ri", "starts")
-    # ri: restart interval in MCUs (0: none); starts: uint32 byte offsets into `stream` of the restart intervals (None without)
+    __slots__ = ("width", "height", "ncomp", "hs", "vs", "quant", "tables", "stream", "ri", "starts", "stuffed")
+    # ri: restart interval in MCUs (0: none); starts: uint32 byte offsets into `stream` of the restart intervals (None without);
+    # stuffed: 1 = `stream` is the file's segment as it is, 0xFF00 stuffing included (parse(keep_stuffing=True))
 
     def mcus(self):
         hs, vs = (self.hs, self.vs) if self.ncomp == 3 else (1, 1)
@@ -38,9 +39,12 @@ class Parsed:
         return self.mcus() * (self.hs * self.vs + 2 if self.ncomp == 3 else 1)
 
 
-def parse(data):
+def parse(data, keep_stuffing=False):
     """JPEG file bytes -> Parsed (header fields, quantisation steps in natural order, the six Huffman tables a scan can
-    name as raw 288-byte records, the entropy-coded segment without byte stuffing). Raises Unsupported."""
+    name as raw 288-byte records, the entropy-coded segment without byte stuffing). Raises Unsupported.
+    keep_stuffing: a file without restart intervals that ends with its EOI marker is only SLICED - the segment keeps its stuffing
+    (Parsed.stuffed = 1) and the device removes it and looks for markers inside (csrc/jpeg.hip jpeg_unstuff_kernel): no pass over
+    the data on the host at all."""
     if len(data) < 4 or data[0] != 0xFF or data[1] != 0xD8:
         raise Unsupported("not a JPEG file")
     n = len(data)
@@ -148,8 +152,11 @@ def parse(data):
     # the entropy-coded segment ends at the first marker that is not a stuffed 0xFF00 (C-speed searches: a photo's segment
     # holds thousands of stuffed bytes)
     i += 2 + L
-    out.ri, out.starts = ri, None
-    if ri:
+    out.ri, out.starts, out.stuffed = ri, None, 0
+    if keep_stuffing and not ri and n - i >= 2 and data[n - 2] == 0xFF and data[n - 1] == 0xD9:
+        out.stream = data[i:n - 2]
+        out.stuffed = 1
+    elif ri:
         # restart intervals: RSTn markers, numbered 0..7 in turn (jdmarker.c read_restart_marker), separate them; every
         # interval starts on a byte with fresh DC predictions - an independent chain for the device. The markers are dropped.
         want = -(-out.mcus() // ri)

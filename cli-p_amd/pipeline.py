@@ -391,6 +391,7 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
                 recs["stream_bytes"], recs["width"], recs["height"] = H[:, 6], w, h
                 recs["ncomp"], recs["hs"], recs["vs"] = H[:, 3], H[:, 4], H[:, 5]
                 recs["restart_interval"], recs["n_intervals"], recs["intervals_off"] = H[:, 20], H[:, 21], e3 * cap + H[:, 22]
+                recs["stuffed"] = H[:, 23]
                 recs["quant"] = st(bigview[JPEG_QUANT_OFF:], shape=(n, 192), strides=(cap, 1))[e3].reshape(n3, 3, 64)
                 # the Huffman tables: distinct six-table sets first (files of one encoder share theirs), then distinct tables
                 tabs = st(bigview[JPEG_TABLES_OFF:], shape=(n, 6 * J.TABLE_BYTES), strides=(cap, 1))[e3]

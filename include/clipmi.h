@@ -261,7 +261,7 @@ int clipmi_resize_crop_rgb8(const void* raw_dev, const void* jobs_dev, int njobs
  * then the table class - 0 DC, 1 AC - and 15 zero bytes).
  * out_dev: per image height rows of width*3 RGB bytes at out_off (grey files replicated, as Image.convert("RGB") does) - the
  * layout clipmi_resize_crop_rgb8 takes. status_dev[i]: 0 decoded; 1 invalid Huffman code; 2 the data ended early or ran
- * over - such a file goes back to Pillow, whose error handling is the reference's. total_blocks = sum of the images' 8x8 blocks
+ * over; 3 a marker inside a segment handed over with its stuffing - such a file goes back to Pillow, whose error handling is the reference's. total_blocks = sum of the images' 8x8 blocks
  * (coef_off counts in blocks), max_blocks / max_pixels = the largest image's. */
 typedef struct clipmi_jpeg_image {
     int64_t stream_off;           /* bytes from streams_dev */
@@ -275,10 +275,13 @@ typedef struct clipmi_jpeg_image {
     int32_t dc_tbl[3], ac_tbl[3]; /* per component: index into tables_dev */
     int32_t restart_interval;     /* MCUs per restart interval (DRI), 0 = none */
     int32_t n_intervals;          /* ceil(MCUs / restart_interval); the RSTn markers themselves are removed from the segment */
+    int32_t stuffed;              /* 1: the segment still holds the 0xFF00 byte stuffing (no restart intervals then) - the device
+                                     removes it IN PLACE and rewrites stream_bytes and this field (0 done, 2 marker inside the scan) */
+    int32_t reserved;
     uint8_t quant[3][64];         /* per component: quantisation steps, natural (row-major) order */
 } clipmi_jpeg_image;
 int64_t clipmi_jpeg_workspace_bytes(int64_t total_blocks, int ntables);
-int clipmi_jpeg_decode_rgb8(const void* streams_dev, const void* images_dev, int n, const void* tables_dev, int ntables,
+int clipmi_jpeg_decode_rgb8(void* streams_dev, void* images_dev, int n, const void* tables_dev, int ntables,
                             int64_t total_blocks, int64_t max_blocks, int64_t max_pixels, void* out_dev, int32_t* status_dev,
                             void* ws_dev, int64_t ws_bytes, void* stream);
 

@@ -70,6 +70,10 @@ def test_parser_reads_what_pillow_reads():
             assert p.quant[c].tolist() == list(im.quantization[tq])
         assert len(p.tables) == 6 and all(len(t) == jpeg_parse.TABLE_BYTES for t in p.tables)
         assert p.blocks() == -(-67 // (8 * hs)) * -(-41 // (8 * vs)) * (hs * vs + 2)
+    blob = encode(smooth(rng, 60, 90), quality=90)
+    a, b = jpeg_parse.parse(blob), jpeg_parse.parse(blob, keep_stuffing=True)
+    assert (a.stuffed, b.stuffed) == (0, 1) and b.stream.replace(b"\xff\x00", b"\xff") == a.stream
+    assert jpeg_parse.parse(blob + b"trailing bytes", keep_stuffing=True).stuffed == 0      # no EOI at the end: the host looks for it
     g = jpeg_parse.parse(encode(smooth(rng, 20, 30)[..., 0], quality=70))
     assert (g.ncomp, g.hs, g.vs, g.blocks()) == (1, 1, 1, 3 * 4)
 

@@ -47,9 +47,12 @@ def test_device_decode_equals_pillow_live():
                 blobs.append(encode(a, quality=88, subsampling=sub, **kw))
                 assert jpeg_parse.parse(blobs[-1]).ri > 0
     got = jpeg.decode_files(blobs, DEV)
-    for b, g in zip(blobs, got):
-        assert g is not None
-        assert np.array_equal(g, pillow(b))
+    raw = jpeg.decode_files(blobs, DEV, keep_stuffing=True)          # the pipeline's form: byte stuffing removed on the device
+    assert sum(jpeg_parse.parse(b, keep_stuffing=True).stuffed for b in blobs) >= 140          # (not the restart-interval files)
+    for b, g, r in zip(blobs, got, raw):
+        assert g is not None and r is not None
+        ref = pillow(b)
+        assert np.array_equal(g, ref) and np.array_equal(r, ref)
 
 
 def test_noise_image_of_many_subsequences_converges():
@@ -94,6 +97,25 @@ def test_corrupt_entropy_data_is_reported_or_decoded_as_pillow_does():
         if np.array_equal(g, ref):
             n_checked += 1
     assert n_checked >= 4
+
+
+def test_marker_inside_a_stuffed_segment_is_reported():
+    """A segment handed over with its stuffing is searched for markers on the device: 0xFF followed by anything but 0x00."""
+    rng = np.random.default_rng(26)
+    blob = encode(smooth(rng, 120, 160), quality=85)
+    p = jpeg_parse.parse(blob, keep_stuffing=True)
+    assert p.stuffed == 1 and p.stream.count(b"\xff\x00") > 0
+    q = jpeg_parse.parse(blob, keep_stuffing=True)
+    k = len(q.stream) // 2
+    while q.stream[k - 1] == 0xFF or q.stream[k] == 0xFF:
+        k += 1
+    q.stream = q.stream[:k] + b"\xff\xd3" + q.stream[k + 2:]
+    r = jpeg_parse.parse(blob, keep_stuffing=True)
+    r.stream = r.stream[:-1] + b"\xff"                                  # a 0xFF with nothing behind it
+    out, recs, status = jpeg.decode_device([p, q, r], DEV)
+    assert status.cpu().tolist() == [0, 3, 3]
+    (g,) = jpeg.decode_files([blob], DEV, keep_stuffing=True)
+    assert np.array_equal(g, pillow(blob))
 
 
 def test_restart_interval_that_ends_early_is_reported():

@@ -23,7 +23,7 @@ def main():
                 base = np.stack([127 + 100 * np.sin(xx / (5.0 + i % 7) + yy / 17.0), 127 + 100 * np.cos(xx / 13.0 - yy / (4.0 + i % 5)), (xx * 3 + yy * 2 + i) % 256], -1)
                 a = np.clip(base + rng.normal(0, 12, side + (3,)), 0, 255).astype(np.uint8)
             Image.fromarray(a).save(os.path.join(d, f"img_{i:05d}.jpg"), quality=95 if kind == "noise" else 85)
-        paths = sorted(os.path.join(d, f) for f in os.listdir(d)) * (5 if kind != "photo2k" else 3)
+        paths = sorted(os.path.join(d, f) for f in os.listdir(d)) * (5 if kind != "photo2k" else 10)
         print("shm free MB", pool.shm_room() >> 20, "workers", pool.n, "file KB", os.path.getsize(paths[0]) >> 10, flush=True)
         model = clipmi.CLIP(clipmi.weights.random_state_dict("ViT-B/32", seed=0), device="cuda:0")
         for batch in ((435, 870) if kind != "photo2k" else (435,)):
