@@ -1,7 +1,7 @@
 #!/bin/bash
 # The JPEG decode's kernels under rocprofv3 (kernel trace) on 870 files of the bench's kind and of photo-like content, on 435 files of
 # 2000 x 1500, and the files -> vectors pipeline with and without the device decoder: writes gpurun_out/jpeg_kernels.txt
-# (kept as profiles/r05_jpeg_kernels.txt). usage: bash tools/gpu_jpeg_profile.sh
+# and the traces tools/jpeg_profile_report.py turns into profiles/r05_jpeg_kernels.txt. usage: bash tools/gpu_jpeg_profile.sh
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd /tmp; export TMPDIR=/tmp; cd "$ROOT"; mkdir -p gpurun_out
 out=gpurun_out/jpeg_kernels.txt; : > $out
 summarise() {   # $1 = rocprof directory, $2 = label
