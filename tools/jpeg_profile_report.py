@@ -19,7 +19,7 @@ def main():
     txt = ["# Round 5: csrc/jpeg.hip under rocprofv3 --kernel-trace (tools/gpu_jpeg_profile.sh), one MI355X; microseconds per launch", ""]
     txt += [l for l in lines if "jpeg_probe" in l]
     by = rows("gpurun_out/jpeg_prof_870")
-    txt.append("# 870 files of 224 x 224 per launch. Launch 0 is the ~200-file parity batch, launches 1-7 the noise files (quality 95, ~58 KB each: the")
+    txt.append("# 870 files of 224 x 224 per launch. Launch 0 is the 146-file parity batch, launches 1-7 the noise files (quality 95, ~58 KB each: the")
     txt.append("# bench's kind - no end-of-block symbols, the serial case), launches 8-14 the photo-like files (quality 85, ~19 KB): median us")
     txt.append("# (tools/jpeg_probe.py removes the byte stuffing on the host: jpeg_unstuff_kernel returns at once here)")
     txt.append(f"{'kernel':28s} {'noise':>10s} {'photo-like':>12s}")
