@@ -202,9 +202,10 @@ struct JpShared {
     JpLut lut[6];                              // [component][DC, AC]
     unsigned words[JP_T * 33 + 40];            // the chunk's big-endian words, word i at i + i / 32 (subsequence i at 33 i: bank spread)
     JpState exit_state[JP_T];
+    JpState start_state[JP_T];
     int blocks[JP_T];
     unsigned char nat[64];
-    int first[2];
+    int first[2];                              // (restart intervals: [0] = an interval ended early)
     int end_p;
     int bad;
 };
@@ -304,21 +305,32 @@ __device__ __forceinline__ int jp_decode(JpShared& sh, unsigned cw0, int bpm, in
 // lanes look up the entries of the 64 bit offsets behind p at once, and the chain that is left is a scalar walk over registers:
 // v_readlane of the entry at the current offset, add its bit count, step the coefficient index. A window ends after 64 bits or
 // with its block (the next block may use other tables).
+constexpr int JP_WIN = 4;          // 64-bit pieces of a wave's window: the look-ups of all pieces are in flight together, so the
+                                   // two LDS round trips in front of a walk are paid once per JP_WIN * 64 bits
 __device__ __forceinline__ int jp_decode_wave(JpShared& sh, unsigned cw0, int bpm, int hv, unsigned& p_, unsigned& bz_, unsigned end) {
     const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     unsigned p = p_, blk = bz_ >> 8, z = bz_ & 255;
     int done = 0;
     while (p < end) {
         const int c = jp_comp(blk, hv);
-        const unsigned q = p + lane;
-        const unsigned r = (q >> 5) - cw0;
-        const unsigned w0 = sh.words[r + (r >> 5)], w1 = sh.words[r + 1 + ((r + 1) >> 5)];        // (word i sits at i + i / 32)
-        const unsigned x = (unsigned)(((((unsigned long long)w0) << 32) | w1) << (q & 31) >> 32);
-        const unsigned a = jp_lookup(sh.lut[2 * c + 1], x, true);
-        const unsigned room = end - p < 64u ? end - p : 64u;
+        unsigned x[JP_WIN], a[JP_WIN];
+#pragma unroll
+        for (int h = 0; h < JP_WIN; ++h) {
+            const unsigned q = p + 64u * h + lane;
+            unsigned r = (q >> 5) - cw0;
+            r = r < JP_T * 32u + 6u ? r : JP_T * 32u + 6u;                            // (behind the staged words: never walked)
+            const unsigned w0 = sh.words[r + (r >> 5)], w1 = sh.words[r + 1 + ((r + 1) >> 5)];    // (word i sits at i + i / 32)
+            x[h] = (unsigned)(((((unsigned long long)w0) << 32) | w1) << (q & 31) >> 32);
+        }
+#pragma unroll
+        for (int h = 0; h < JP_WIN; ++h) {
+            const unsigned e = jp_lookup(sh.lut[2 * c + 1], x[h], true);
+            a[h] = e ? e : 1u;                           // (no such code: one bit on, no step - as jp_decode)
+        }
+        const unsigned room = end - p < 64u * JP_WIN ? end - p : 64u * JP_WIN;
         unsigned o = 0;
         if (z == 0) {                                    // the block's DC symbol starts the window
-            const unsigned e = __builtin_amdgcn_readfirstlane(jp_lookup(sh.lut[2 * c], x, false));
+            const unsigned e = __builtin_amdgcn_readfirstlane(jp_lookup(sh.lut[2 * c], x[0], false));
             if (!e) {
                 p += 1;
                 continue;
@@ -326,13 +338,16 @@ __device__ __forceinline__ int jp_decode_wave(JpShared& sh, unsigned cw0, int bp
             o = JP_ADV(e);
             z = 1;
         }
-        if (o < room) {                                  // AC symbols up to the window's or the block's end
-            const unsigned a1 = a ? a : 1u;              // (no such code: one bit on, no step - as jp_decode)
-            do {
-                const unsigned e = __builtin_amdgcn_readlane(a1, o);
-                o += JP_ADV(e);
-                z += JP_DZ(e);
-            } while ((o < room) & (z < 64));
+#pragma unroll
+        for (int h = 0; h < JP_WIN; ++h) {               // AC symbols up to the window's or the block's end, piece by piece
+            const unsigned lim = room < 64u * (h + 1) ? room : 64u * (h + 1);
+            if ((o < lim) & (z < 64)) {
+                do {
+                    const unsigned e = __builtin_amdgcn_readlane(a[h], o - 64u * h);
+                    o += JP_ADV(e);
+                    z += JP_DZ(e);
+                } while ((o < lim) & (z < 64));
+            }
         }
         if (z >= 64) {
             z = 0;
@@ -420,22 +435,19 @@ __global__ void __launch_bounds__(JP_T) jpeg_huffman_kernel(const unsigned char*
         __syncthreads();
         if (act) nb = jp_decode<false>(sh, cw0, bpm, hv, ex.p, ex.bz, end, nullptr, 0, 0);
         sh.exit_state[tid] = ex;
-        // Rounds. The first JP_SPEC are speculative: every thread whose predecessor's exit state moved decodes again - on
-        // photographs that is all it takes. When states still move after that (noise: nothing re-synchronises), only the FIRST
-        // such thread decodes per round - everything in front of it is final, everything behind it would decode garbage, and one
-        // active lane runs the chain at twice the speed of a wave of diverging ones. Either way the fixed point is the
-        // sequential decode: thread 0 is exact, and a thread that decodes from a final predecessor is final.
-        if (tid == 0) sh.first[0] = sh.first[1] = JP_T;
-        for (int round = 0; round < JP_SPEC + JP_T; ++round) {
+        // Rounds. JP_SPEC speculative ones: every thread whose predecessor's exit state moved decodes again - on photographs that
+        // is all it takes. When states still move after that (noise: nothing re-synchronises), wave 0 walks the rest of the chunk
+        // ALONE, one subsequence after the other from the first thread whose predecessor moved (jp_decode_wave; a subsequence whose
+        // start did not move is skipped): no barrier, no exchange per subsequence - everything in front of that thread is final,
+        // everything behind it would decode garbage, and a round per subsequence cost more than its walk. Either way the fixed
+        // point is the sequential decode: thread 0 is exact, and a thread that decodes from a final predecessor is final.
+        bool moving = true;
+        for (int round = 0; round < JP_SPEC && moving; ++round) {
             __syncthreads();
             const JpState prev = tid ? sh.exit_state[tid - 1] : carry;
-            bool ch = act && tid && (prev.p != start.p || prev.bz != start.bz);
-            if (round >= JP_SPEC && ch) atomicMin(&sh.first[round & 1], tid);
-            if (!__syncthreads_or(ch)) break;
-            if (round >= JP_SPEC) {
-                ch = ch && tid == sh.first[round & 1];
-                if (tid == 0) sh.first[(round + 1) & 1] = JP_T;
-            }
+            const bool ch = act && tid && (prev.p != start.p || prev.bz != start.bz);
+            moving = __syncthreads_or(ch);
+            if (!moving) break;
             const unsigned long long m = __ballot(ch);
             if (__popcll(m) <= 2) {                        // (wave-uniform) the whole wave walks each of them: jp_decode_wave
                 unsigned long long mm = m;
@@ -458,6 +470,38 @@ __global__ void __launch_bounds__(JP_T) jpeg_huffman_kernel(const unsigned char*
                 nb = jp_decode<false>(sh, cw0, bpm, hv, ex.p, ex.bz, end, nullptr, 0, 0);
                 sh.exit_state[tid] = ex;
             }
+        }
+        if (moving) {
+            sh.start_state[tid] = start;
+            sh.blocks[tid] = nb;
+            __syncthreads();
+            if (tid < 64) {
+                const unsigned nact = nsub - c0 < (unsigned)JP_T ? nsub - c0 : (unsigned)JP_T;
+                JpState run = carry;
+                bool fresh = false;                       // `run` comes from a subsequence this walk decoded
+                for (unsigned i = 1; i < nact; ++i) {
+                    const JpState pe = fresh ? run : sh.exit_state[i - 1], st = sh.start_state[i];
+                    if (pe.p == st.p && pe.bz == st.bz) {  // consistent with its predecessor: its exit state stands
+                        fresh = false;
+                        continue;
+                    }
+                    unsigned sp = __builtin_amdgcn_readfirstlane(pe.p), sbz = __builtin_amdgcn_readfirstlane(pe.bz);    // (wave-uniform)
+                    const unsigned se = (c0 + i + 1) * JP_SUB_BITS < nbits ? (c0 + i + 1) * JP_SUB_BITS : nbits;
+                    const int d = jp_decode_wave(sh, cw0, bpm, hv, sp, sbz, se);
+                    if (tid == 0) {
+                        sh.start_state[i] = pe;
+                        sh.exit_state[i] = JpState{sp, sbz};
+                        sh.blocks[i] = d;
+                    }
+                    run = JpState{sp, sbz};
+                    fresh = true;
+                }
+            }
+            __syncthreads();
+            start = sh.start_state[tid];
+            ex = sh.exit_state[tid];
+            nb = sh.blocks[tid];
+            __syncthreads();                               // sh.blocks is rewritten below
         }
         // first block of every subsequence: exclusive scan of the blocks completed
         sh.blocks[tid] = act ? nb : 0;
