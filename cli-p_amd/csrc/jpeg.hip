@@ -325,7 +325,7 @@ __device__ __forceinline__ int jp_decode_wave(JpShared& sh, unsigned cw0, int bp
 #pragma unroll
         for (int h = 0; h < JP_WIN; ++h) {
             const unsigned e = jp_lookup(sh.lut[2 * c + 1], x[h], true);
-            a[h] = e ? e : 1u;                           // (no such code: one bit on, no step - as jp_decode)
+            a[h] = e ? JP_ADV(e) | (JP_DZ(e) << 16) : 1u;                // (no such code: one bit on, no step - as jp_decode)
         }
         const unsigned room = end - p < 64u * JP_WIN ? end - p : 64u * JP_WIN;
         unsigned o = 0;
@@ -338,15 +338,20 @@ __device__ __forceinline__ int jp_decode_wave(JpShared& sh, unsigned cw0, int bp
             o = JP_ADV(e);
             z = 1;
         }
+        // AC symbols up to the window's or the block's end, piece by piece. The walk's state is ONE register - the offset, biased
+        // so that bit 15 comes up at the piece's limit, and the coefficient index from bit 16, where 64 is bit 22 - and an entry is
+        // (bits to skip | index step << 16): a symbol is a v_readlane, an add and a test.
 #pragma unroll
-        for (int h = 0; h < JP_WIN; ++h) {               // AC symbols up to the window's or the block's end, piece by piece
+        for (int h = 0; h < JP_WIN; ++h) {
             const unsigned lim = room < 64u * (h + 1) ? room : 64u * (h + 1);
             if ((o < lim) & (z < 64)) {
+                const unsigned bias = 0x8000u - lim;
+                unsigned st = (o + bias) | (z << 16);
                 do {
-                    const unsigned e = __builtin_amdgcn_readlane(a[h], o - 64u * h);
-                    o += JP_ADV(e);
-                    z += JP_DZ(e);
-                } while ((o < lim) & (z < 64));
+                    st += __builtin_amdgcn_readlane(a[h], (st & 0x7fffu) - bias - 64u * h);
+                } while (!(st & 0x00c08000u));
+                o = (st & 0xffffu) - bias;
+                z = st >> 16;
             }
         }
         if (z >= 64) {
