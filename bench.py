@@ -174,7 +174,7 @@ def make_jpegs(n):
 
 
 def files_to_vectors_leg(model, pool):
-    """build-index.py's loop end to end: JPEG FILES -> vectors on the host, 435 images per batch, in the
+    """build-index.py's loop end to end: JPEG FILES -> vectors on the host, 870 images per batch (the CLI's default), in the
     product's default form - the decode workers read and parse the files, csrc/jpeg.hip decodes them on the device
     (clipmi_jpeg_decode_rgb8: Pillow's bytes), clipmi_resize_crop_rgb8, HIP encode - and, beside it, with Pillow decoding in the
     worker processes (device_jpeg_kb = 0: rounds 1-4's path, bound by the box's CPU share). Reported beside the headline, never as
@@ -182,32 +182,32 @@ def files_to_vectors_leg(model, pool):
     subsequences never re-synchronise: a serial chain per image)."""
     import shutil
     import tempfile
-    n = 5 * 435
+    n = 3 * 870
     d = tempfile.mkdtemp(prefix="clipmi_bench_")
     try:
         for i, blob in enumerate(make_jpegs(n)):
             with open(os.path.join(d, f"img_{i:05d}.jpg"), "wb") as f:
                 f.write(blob)
-        paths = sorted(os.path.join(d, f) for f in os.listdir(d)) * 4      # 20 batches: every file is decoded four times
+        paths = sorted(os.path.join(d, f) for f in os.listdir(d)) * 4      # 12 batches: every file is decoded four times
         res = {}
         for name, kb in (("device_decode", None), ("pillow_decode", 0)):
-            for _ in clipmi.pipeline.encode_files(model, paths[:435], batch=435, pool=pool, device_jpeg_kb=kb):
+            for _ in clipmi.pipeline.encode_files(model, paths[:870], batch=870, pool=pool, device_jpeg_kb=kb):
                 pass
             st = {}
             t0 = time.perf_counter()
             got = 0
-            for ok, feats, bad in clipmi.pipeline.encode_files(model, paths, batch=435, pool=pool, device_jpeg_kb=kb, stats=st):
+            for ok, feats, bad in clipmi.pipeline.encode_files(model, paths, batch=870, pool=pool, device_jpeg_kb=kb, stats=st):
                 got += len(ok)
             dt = time.perf_counter() - t0
-            nb = len(paths) / 435
+            nb = len(paths) / 870
             res[name] = {"images_per_s": got / dt, "images": got, "device_decoded": int(st.get("jpeg_files", 0)),
                          "stage_ms_per_batch": {"workers": 1e3 * st.get("decode_s", 0.0) / nb, "to_device": 1e3 * st.get("copy_s", 0.0) / nb,
                                                 "gpu": 1e3 * st.get("encode_s", 0.0) / nb}}
     finally:
         shutil.rmtree(d, ignore_errors=True)
     dd = res["device_decode"]
-    return {"value": dd["images_per_s"], "unit": "images/s", "images": dd["images"], "decode_processes": pool.n, "batch": 435,
-            "data": "synthetic 224x224 JPEG files (uniform noise, quality 95: ~58 KB each) on local disk, 2175 files x 4",
+    return {"value": dd["images_per_s"], "unit": "images/s", "images": dd["images"], "decode_processes": pool.n, "batch": 870,
+            "data": "synthetic 224x224 JPEG files (uniform noise, quality 95: ~58 KB each) on local disk, 2610 files x 4",
             "decode": "device (clipmi_jpeg_decode_rgb8) for %d of %d files" % (dd["device_decoded"], dd["images"]),
             "stage_ms_per_batch": dd["stage_ms_per_batch"],
             "bound": "gpu: the Huffman chains of noise files + the encode step",

@@ -20,7 +20,8 @@ store, assembles the matrix and writes `images.index` ("each ran
 ingest of shard outputs"). Shards left behind by a run that died are ingested at the next start.
 
 Weights: $CLIPMI_WEIGHTS (a local ViT-B-32.pt / state-dict), or CLIPMI_RANDOM_WEIGHTS=<seed> for a
-synthetic model. Knobs: CLIPMI_BATCH (default 435 = whole rounds of GEMM tiles on 256 CUs),
+synthetic model. Knobs: CLIPMI_BATCH (default 870 = two kernel sequences of 435 images, whole rounds of GEMM tiles on 256 CUs, and a
+JPEG decode launch whose serial chains are paid once per 870 files),
 CLIPMI_WORKERS (decode workers per rank, default min(16, CPUs / ranks on the node)), CLIPMI_DECODE (`procs`, the default: worker processes started before
 the GPU is touched — 23 k images/s end to end from 224 x 224 JPEGs on 16 workers against 4 k on threads, which the GIL
 binds; `threads`: the old form).
@@ -277,7 +278,7 @@ def main(argv):
         model, _ = load(os.environ.get("CLIPMI_WEIGHTS", "ViT-B/32"), device=device, jit=False)
         model.eval()
         db = vstore.VectorStore("vectors.lmdb", dim=model.embed_dim) if ranks.leader else None
-        batch = int(os.environ.get("CLIPMI_BATCH", "435"))
+        batch = int(os.environ.get("CLIPMI_BATCH", "870"))
         if ranks.world > 1:
             # Ctrl-C reaches every rank of the launcher's process group at its own moment: the flag + the loop's per-round
             # agreement make all of them stop in the same round; rank 0 still finalises (build-index.py:63-64)
