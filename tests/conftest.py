@@ -34,9 +34,29 @@ class TopkOracle:
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
         self.lib = C.CDLL(so)
         self.lib.topk_oracle.restype = C.c_int
+        self.lib.topk_oracle_mt.restype = C.c_int
+        try:
+            self.threads = max(1, min(16, len(os.sched_getaffinity(0))))
+        except AttributeError:
+            self.threads = 4
         self.lib.topk_oracle_merge.restype = C.c_int
 
     def topk(self, db, q, K, id_base=0):
+        db = np.ascontiguousarray(db, dtype=np.float32)
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        N, E = db.shape if db.ndim == 2 else (0, q.shape[1])
+        Q = q.shape[0]
+        out_s = np.empty((Q, K), dtype=np.float32)
+        out_i = np.empty((Q, K), dtype=np.int64)
+        # (the queries dealt over the host's cores: independent, so the same results as the one-thread entry point -
+        # test_oracle_topk.py::test_threaded_oracle_equals_the_plain_one)
+        rc = self.lib.topk_oracle_mt(db.ctypes.data_as(C.c_void_p), C.c_int64(N), C.c_int(E),
+                                     q.ctypes.data_as(C.c_void_p), C.c_int(Q), C.c_int(K), C.c_int64(id_base),
+                                     out_s.ctypes.data_as(C.c_void_p), out_i.ctypes.data_as(C.c_void_p), C.c_int(self.threads))
+        assert rc == 0
+        return out_s, out_i
+
+    def topk_one_thread(self, db, q, K, id_base=0):
         db = np.ascontiguousarray(db, dtype=np.float32)
         q = np.ascontiguousarray(q, dtype=np.float32)
         N, E = db.shape if db.ndim == 2 else (0, q.shape[1])

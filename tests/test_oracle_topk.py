@@ -86,3 +86,19 @@ def test_oracle_padding_and_merge(topk_oracle, clipmi):
     assert np.array_equal(Im, Iw) and np.array_equal(Dm, Dw)
     Dh, Ih = clipmi.merge_lists_host(S, Ii, K)
     assert np.array_equal(Ih, Iw) and np.array_equal(Dh, Dw)
+
+
+def test_threaded_oracle_equals_the_plain_one(topk_oracle):
+    """The suites check through topk_oracle_mt (the queries dealt over the host's cores); queries are independent, so its
+    results are those of the one-thread entry point, NaN rows, ties and padding included."""
+    rng = np.random.default_rng(9)
+    db = rng.standard_normal((5000, 64)).astype(np.float32)
+    db[17] = db[4711]
+    db[100, 3] = np.nan
+    q = rng.standard_normal((37, 64)).astype(np.float32)
+    a = topk_oracle.topk(db, q, 51, id_base=1000)
+    b = topk_oracle.topk_one_thread(db, q, 51, id_base=1000)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    a = topk_oracle.topk(db[:20], q[:3], 51)
+    b = topk_oracle.topk_one_thread(db[:20], q[:3], 51)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
