@@ -242,6 +242,51 @@ def _load_safe(args):
         return None
 
 
+def jpeg_records(bigview, n, cap, slots, comp, n_px):
+    """The device decoder's records out of a batch's regions of the big segment (decode_worker.stage_jpeg wrote them): every field
+    comes out of the regions' headers as one strided numpy gather - no Python per image except the table-set look-up.
+    bigview: the segment (uint8, n regions of cap bytes); slots: the regions that hold a parsed JPEG file; comp: slot -> row of the
+    batch's tensor. -> (clipmi_jpeg_image records with offsets into the segment, distinct raw Huffman tables uint8, clipmi_resize_job
+    records whose sources are the decoder's outputs laid out back to back, output bytes per image, blocks per image, number of tables)"""
+    from . import jpeg as J
+    from .decode_worker import JPEG_COEF_OFF, JPEG_HDR_INTS, JPEG_QUANT_OFF, JPEG_TABLES_OFF
+    from .resize import JOB
+    slots = np.asarray(slots, dtype=np.int64)
+    n3 = len(slots)
+    st = np.lib.stride_tricks.as_strided
+    H = st(bigview[:4 * JPEG_HDR_INTS].view(np.int32), shape=(n, JPEG_HDR_INTS), strides=(cap, 4))[slots].astype(np.int64)
+    w, h, blocks, nrows = H[:, 1], H[:, 2], H[:, 7], H[:, 9]
+    recs = np.zeros(n3, dtype=J.IMAGE)
+    out_sz = (w * h * 3 + 15) // 16 * 16
+    out_off = np.cumsum(out_sz) - out_sz
+    recs["stream_off"], recs["coef_off"], recs["out_off"] = slots * cap + H[:, 18], np.cumsum(blocks) - blocks, out_off
+    recs["stream_bytes"], recs["width"], recs["height"] = H[:, 6], w, h
+    recs["ncomp"], recs["hs"], recs["vs"] = H[:, 3], H[:, 4], H[:, 5]
+    recs["restart_interval"], recs["n_intervals"], recs["intervals_off"] = H[:, 20], H[:, 21], slots * cap + H[:, 22]
+    recs["stuffed"] = H[:, 23]
+    recs["quant"] = st(bigview[JPEG_QUANT_OFF:], shape=(n, 192), strides=(cap, 1))[slots].reshape(n3, 3, 64)
+    # the Huffman tables: distinct six-table sets first (files of one encoder share theirs), then distinct tables
+    tabs = st(bigview[JPEG_TABLES_OFF:], shape=(n, 6 * J.TABLE_BYTES), strides=(cap, 1))[slots]
+    sets, pool_t, set_idx = {}, {}, np.zeros((n3, 6), np.int32)
+    for k in range(n3):
+        key = tabs[k].tobytes()
+        idx = sets.get(key)
+        if idx is None:
+            idx = sets[key] = [pool_t.setdefault(key[t * J.TABLE_BYTES:(t + 1) * J.TABLE_BYTES], len(pool_t)) for t in range(6)]
+        set_idx[k] = idx
+    recs["dc_tbl"], recs["ac_tbl"] = set_idx[:, 0::2], set_idx[:, 1::2]
+    tables = np.frombuffer(b"".join(pool_t), np.uint8)
+    jobs = np.zeros(n3, dtype=JOB)
+    jobs["src_off"], jobs["w"], jobs["h"], jobs["r0"], jobs["nrows"], jobs["out_index"] = out_off, w, h, H[:, 8], nrows, np.asarray(comp)[slots]
+    jobs["need_h"], jobs["need_v"], jobs["left"], jobs["top"], jobs["hk"], jobs["vk"] = (H[:, 10], H[:, 11], H[:, 12], H[:, 13],
+                                                                                      H[:, 14], H[:, 15])
+    jobs["hcoef_off"] = (slots * cap + JPEG_COEF_OFF) // 4
+    jobs["vcoef_off"] = jobs["hcoef_off"] + H[:, 16]
+    tmp = nrows * n_px * 3
+    jobs["tmp_off"] = np.cumsum(tmp) - tmp
+    return recs, tables, jobs, out_sz, blocks, len(pool_t)
+
+
 def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb=None, device_jpeg_kb=None, stats=None):
     """Generator over batches: yields (ok_paths, features f32 [n,E] numpy normalised, failed_paths).
     Decode runs in the worker processes of `pool` (a DecodePool) when given, else on `workers` threads (Pillow
@@ -379,39 +424,10 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
 
                 pending["launch"].append(resize_full)
             if len(e3):
-                # every field of the records comes out of the regions' headers as one strided numpy gather: no Python per image
                 n3 = len(e3)
-                st = np.lib.stride_tricks.as_strided
-                H = st(bigview[:4 * JPEG_HDR_INTS].view(np.int32), shape=(n, JPEG_HDR_INTS), strides=(cap, 4))[e3].astype(np.int64)
-                w, h, blocks, nrows = H[:, 1], H[:, 2], H[:, 7], H[:, 9]
-                recs = np.zeros(n3, dtype=J.IMAGE)
-                out_sz = (w * h * 3 + 15) // 16 * 16
-                out_off = np.cumsum(out_sz) - out_sz
-                recs["stream_off"], recs["coef_off"], recs["out_off"] = e3 * cap + H[:, 18], np.cumsum(blocks) - blocks, out_off
-                recs["stream_bytes"], recs["width"], recs["height"] = H[:, 6], w, h
-                recs["ncomp"], recs["hs"], recs["vs"] = H[:, 3], H[:, 4], H[:, 5]
-                recs["restart_interval"], recs["n_intervals"], recs["intervals_off"] = H[:, 20], H[:, 21], e3 * cap + H[:, 22]
-                recs["stuffed"] = H[:, 23]
-                recs["quant"] = st(bigview[JPEG_QUANT_OFF:], shape=(n, 192), strides=(cap, 1))[e3].reshape(n3, 3, 64)
-                # the Huffman tables: distinct six-table sets first (files of one encoder share theirs), then distinct tables
-                tabs = st(bigview[JPEG_TABLES_OFF:], shape=(n, 6 * J.TABLE_BYTES), strides=(cap, 1))[e3]
-                sets, pool_t, set_idx = {}, {}, np.zeros((n3, 6), np.int32)
-                for k in range(n3):
-                    key = tabs[k].tobytes()
-                    idx = sets.get(key)
-                    if idx is None:
-                        idx = sets[key] = [pool_t.setdefault(key[t * J.TABLE_BYTES:(t + 1) * J.TABLE_BYTES], len(pool_t)) for t in range(6)]
-                    set_idx[k] = idx
-                recs["dc_tbl"], recs["ac_tbl"] = set_idx[:, 0::2], set_idx[:, 1::2]
-                tables = np.frombuffer(b"".join(pool_t), np.uint8)
-                jobs = np.zeros(n3, dtype=JOB)
-                jobs["src_off"], jobs["w"], jobs["h"], jobs["r0"], jobs["nrows"], jobs["out_index"] = out_off, w, h, H[:, 8], nrows, comp[e3]
-                jobs["need_h"], jobs["need_v"], jobs["left"], jobs["top"], jobs["hk"], jobs["vk"] = (H[:, 10], H[:, 11], H[:, 12], H[:, 13],
-                                                                                                  H[:, 14], H[:, 15])
-                jobs["hcoef_off"] = (e3 * cap + JPEG_COEF_OFF) // 4
-                jobs["vcoef_off"] = jobs["hcoef_off"] + H[:, 16]
+                recs, tables, jobs, out_sz, blocks, nt = jpeg_records(bigview, n, cap, e3, comp, n_px)
+                w, h, nrows = recs["width"].astype(np.int64), recs["height"].astype(np.int64), jobs["nrows"].astype(np.int64)
                 tmp = nrows * n_px * 3
-                jobs["tmp_off"] = np.cumsum(tmp) - tmp
                 o_tab = (recs.nbytes + 15) // 16 * 16
                 o_job = (o_tab + tables.nbytes + 15) // 16 * 16
                 small = np.zeros(o_job + jobs.nbytes, np.uint8)
@@ -420,12 +436,12 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
                 small[o_job:] = jobs.view(np.uint8).reshape(-1)
                 dsmall = torch.from_numpy(small).to(dev)
                 total_blocks = int(blocks.sum())
-                ws_bytes = int(L.clipmi_jpeg_workspace_bytes(total_blocks, len(pool_t)))
+                ws_bytes = int(L.clipmi_jpeg_workspace_bytes(total_blocks, nt))
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
                 rgb = torch.empty(int(out_sz.sum()), dtype=torch.uint8, device=dev)
                 status = torch.empty(n3, dtype=torch.int32, device=dev)
                 scratch3 = torch.empty(max(int(tmp.sum()), 1), dtype=torch.uint8, device=dev)
-                nt, mb, mp, mr = len(pool_t), int(blocks.max()), int((w * h).max()), int(nrows.max())
+                mb, mp, mr = int(blocks.max()), int((w * h).max()), int(nrows.max())
 
                 def decode_jpeg():
                     sb = dsmall.data_ptr()

@@ -118,3 +118,59 @@ def test_pack_lays_out_aligned_streams_and_shares_tables():
         assert o % 16 == 0 and streams[o:o + n].tobytes() == it.stream and not streams[o + n:o + n + 16].any()
         assert int(r["out_off"]) % 16 == 0
     assert out_bytes >= sum(it.width * it.height * 3 for it in items)
+
+
+def test_worker_regions_and_the_records_built_from_them(tmp_path):
+    """What a decode worker lays out for a JPEG file (decode_worker.stage_jpeg) and what the parent builds out of a batch's
+    regions (pipeline.jpeg_records) is, field for field, what jpeg.pack builds from the parsed files: sizes, sampling,
+    quantisation steps, table indices into the distinct tables, the segment's bytes, restart intervals, the resize plan."""
+    from clipmi import jpeg, pipeline
+    from clipmi import decode_worker as dw
+    rng = np.random.default_rng(12)
+    specs = [(224, 224, dict(quality=95, subsampling=2)), (300, 500, dict(quality=85, subsampling=1)),
+             (120, 90, dict(quality=70, subsampling=0, optimize=True)), (260, 340, dict(quality=88, restart_marker_rows=1)),
+             (96, 64, dict(quality=80))]
+    n, cap, n_px = len(specs) + 2, 256 << 10, 224
+    big = np.zeros(n * cap, np.uint8)
+    slots, items = [], []
+    for k, (h, w, kw) in enumerate(specs):
+        a = smooth(rng, h, w) if k != 4 else smooth(rng, h, w)[..., 0]
+        path = str(tmp_path / f"f{k}.jpg")
+        Image.fromarray(a).save(path, format="JPEG", **kw)
+        slot = k + (1 if k >= 2 else 0)                       # slot 2 holds no JPEG file (a PNG, say): a gap in the batch
+        got = dw.stage_jpeg(path, n_px, big[slot * cap:(slot + 1) * cap])
+        assert got[:2] == (w, h) and 0 < got[2] <= cap
+        slots.append(slot)
+        items.append(jpeg_parse.parse(open(path, "rb").read(), keep_stuffing=True))
+    assert dw.stage_jpeg(str(tmp_path / "f1.jpg"), n_px, big[6 * cap:6 * cap + 4096])[2] < 0          # too small a region: says what it needs
+    with pytest.raises(jpeg_parse.Unsupported):
+        Image.fromarray(smooth(rng, 50, 50)).save(str(tmp_path / "p.jpg"), format="JPEG", progressive=True)
+        dw.stage_jpeg(str(tmp_path / "p.jpg"), n_px, big[6 * cap:7 * cap])
+    comp = np.arange(n)
+    recs, tables, jobs, out_sz, blocks, nt = pipeline.jpeg_records(big, n, cap, slots, comp, n_px)
+    ref, rtab, rstreams, _, total_blocks, _, _ = jpeg.pack(items)
+    assert nt == len(rtab) and int(blocks.sum()) == total_blocks
+    tables = tables.reshape(nt, jpeg_parse.TABLE_BYTES)
+    for k, (r, q, it, slot) in enumerate(zip(recs, ref, items, slots)):
+        for f in ("stream_bytes", "width", "height", "ncomp", "hs", "vs", "restart_interval", "n_intervals", "stuffed", "coef_off", "out_off"):
+            assert int(r[f]) == int(q[f]), f
+        assert np.array_equal(r["quant"], q["quant"])
+        for c in range(3):                                  # the same tables, whatever their numbering
+            assert tables[r["dc_tbl"][c]].tobytes() == rtab[q["dc_tbl"][c]].tobytes()
+            assert tables[r["ac_tbl"][c]].tobytes() == rtab[q["ac_tbl"][c]].tobytes()
+        o, nb = int(r["stream_off"]), int(r["stream_bytes"])
+        assert slot * cap <= o and o + nb + 16 <= (slot + 1) * cap and o % 16 == 0
+        assert big[o:o + nb].tobytes() == it.stream and not big[o + nb:o + nb + 16].any()
+        if it.ri:
+            io_ = int(r["intervals_off"])
+            assert np.array_equal(np.frombuffer(big, np.uint32, count=len(it.starts), offset=io_), it.starts)
+        plan = dw.resize_plan(it.width, it.height, n_px)
+        j = jobs[k]
+        assert (int(j["w"]), int(j["h"]), int(j["r0"]), int(j["nrows"]), int(j["need_h"]), int(j["need_v"]), int(j["left"]), int(j["top"]),
+                int(j["hk"]), int(j["vk"])) == (it.width, it.height, plan["r0"], plan["nrows"], plan["need_h"], plan["need_v"], plan["left"],
+                                                plan["top"], plan["hk"], plan["vk"])
+        assert int(j["src_off"]) == int(r["out_off"]) and int(j["out_index"]) == slot
+        hc = np.frombuffer(big, np.int32, count=plan["hcoef"].size, offset=4 * int(j["hcoef_off"]))
+        vc = np.frombuffer(big, np.int32, count=plan["vcoef"].size, offset=4 * int(j["vcoef_off"]))
+        assert np.array_equal(hc, plan["hcoef"]) and np.array_equal(vc, plan["vcoef"])
+    assert np.array_equal(jobs["tmp_off"], np.cumsum(jobs["nrows"].astype(np.int64) * n_px * 3) - jobs["nrows"].astype(np.int64) * n_px * 3)
