@@ -210,7 +210,8 @@ def files_to_vectors_leg(model, pool):
             "data": "synthetic 224x224 JPEG files (uniform noise, quality 95: ~58 KB each) on local disk, 2610 files x 4",
             "decode": "device (clipmi_jpeg_decode_rgb8) for %d of %d files" % (dd["device_decoded"], dd["images"]),
             "stage_ms_per_batch": dd["stage_ms_per_batch"],
-            "bound": "gpu: the Huffman chains of noise files + the encode step",
+            "bound": ("gpu: the Huffman chains of noise files + the encode step" if dd["device_decoded"] * 2 > dd["images"] else
+                      "host decode (the files did not take the device decoder: shared memory too small, or not baseline JPEG)"),
             "pillow_decode_in_workers": {"value": res["pillow_decode"]["images_per_s"], "bound": "host decode",
                                          "stage_ms_per_batch": res["pillow_decode"]["stage_ms_per_batch"]}}
 
