@@ -22,7 +22,7 @@ ingest of shard outputs"). Shards left behind by a run that died are ingested at
 Weights: $CLIPMI_WEIGHTS (a local ViT-B-32.pt / state-dict), or CLIPMI_RANDOM_WEIGHTS=<seed> for a
 synthetic model. Knobs: CLIPMI_BATCH (default 870 = two kernel sequences of 435 images, whole rounds of GEMM tiles on 256 CUs, and a
 JPEG decode launch whose serial chains are paid once per 870 files),
-CLIPMI_DEVICE_JPEG_KB (default 1024: baseline JPEG files of up to that size are decoded on the device - csrc/jpeg.hip, Pillow's bytes -
+CLIPMI_DEVICE_JPEG_KB (default 8192: baseline JPEG files of up to that size are decoded on the device - csrc/jpeg.hip, Pillow's bytes -
 instead of by Pillow in the workers; 0 = off),
 CLIPMI_WORKERS (decode workers per rank, default min(16, CPUs / ranks on the node)), CLIPMI_DECODE (`procs`, the default: worker processes started before
 the GPU is touched — 23 k images/s end to end from 224 x 224 JPEGs on 16 workers against 4 k on threads, which the GIL

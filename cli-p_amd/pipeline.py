@@ -287,18 +287,21 @@ def jpeg_records(bigview, n, cap, slots, comp, n_px):
     return recs, tables, jobs, out_sz, blocks, len(pool_t)
 
 
-def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb=None, device_jpeg_kb=None, stats=None):
+def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb=None, device_jpeg_kb=None, stats=None,
+                 jpeg_group_mb=32768):
     """Generator over batches: yields (ok_paths, features f32 [n,E] numpy normalised, failed_paths).
     Decode runs in the worker processes of `pool` (a DecodePool) when given, else on `workers` threads (Pillow
     releases the GIL while decoding, which is enough for large photos and not for small images).
     device_resize_mb (default $CLIPMI_DEVICE_RESIZE_MB, 0 = off; needs `pool` and a GPU): 8-bit RGB images of up to that
     many MB decoded travel at full size and are resized + cropped by clipmi_resize_crop_rgb8 - the same pixels, with the
     workers left to decode only (Pillow's bicubic resize is half of a photo-sized file's host time).
-    device_jpeg_kb (default $CLIPMI_DEVICE_JPEG_KB, else 1024; 0 = off; needs `pool` and a GPU): baseline JPEG files of up to that
+    device_jpeg_kb (default $CLIPMI_DEVICE_JPEG_KB, else 8192; 0 = off; needs `pool` and a GPU): baseline JPEG files of up to that
     many KB are not decoded on the host at all - a worker reads the file, walks its markers and removes the byte stuffing
     (jpeg_parse.py), and clipmi_jpeg_decode_rgb8 + clipmi_resize_crop_rgb8 produce the transform's pixels in HBM, the same
     bytes as Pillow's. Every other file (progressive, PNG, CMYK ...) and every file the device reports corrupt takes the
     Pillow path as before.
+    jpeg_group_mb: the device decodes a batch's JPEG files in groups whose decoded form (~22 bytes per pixel) stays under that
+    many MB of HBM - one group for a batch of thumbnails, several for a batch of photos.
     stats: a dict that receives the seconds each of the three pipelined stages was busy (decode_s: worker processes, copy_s:
     shared memory -> device incl. the decode / resize kernels, encode_s) and the files that took the device decoder (jpeg_files)."""
     import os
@@ -317,18 +320,26 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
               f"decoding on {workers} threads)")
         pool = None
     if device_jpeg_kb is None:
-        device_jpeg_kb = float(os.environ.get("CLIPMI_DEVICE_JPEG_KB", "1024"))
+        device_jpeg_kb = float(os.environ.get("CLIPMI_DEVICE_JPEG_KB", "8192"))
     on_device = use_gpu and pool is not None
     resize_cap = int(device_resize_mb * (1 << 20)) if on_device else 0
     jpeg_cap = int(device_jpeg_kb * 1024) if on_device else 0
+    jpeg_group_bytes = int(jpeg_group_mb) << 20
 
     def room_for(cap):
         return pool.shm_room() >= 2 * batch * (3 * n_px * n_px + cap) + (256 << 20)
 
-    if resize_cap and not room_for(max(resize_cap, jpeg_cap)):
+    if resize_cap and not room_for(resize_cap):
         resize_cap = 0
-    if jpeg_cap and not room_for(jpeg_cap):
-        jpeg_cap = 0
+    if jpeg_cap:
+        # the largest region /dev/shm has room for (two segments of `batch` regions beside the n_px slots), found once per pool:
+        # regions start small and grow with the files, so a large configured size costs nothing until files of that size come
+        if not getattr(pool, "jpeg_fit_cap", 0):
+            room = pool.shm_room() - 2 * batch * 3 * n_px * n_px - (256 << 20)
+            pool.jpeg_fit_cap = max(1, room // (2 * batch) // 65536 * 65536)
+        jpeg_cap = min(jpeg_cap, pool.jpeg_fit_cap)
+        if jpeg_cap < (64 << 10):
+            jpeg_cap = 0
     # regions are copied to the device whole, so JPEG regions start small (or where the pool's last call ended) and follow the
     # files: a file that does not fit is decoded by Pillow this once and says what it would have needed (DecodePool.jpeg_wanted)
     jpeg_now = min(jpeg_cap, pool.jpeg_cap_hint or (128 << 10)) if jpeg_cap else 0
@@ -424,36 +435,54 @@ def encode_files(model, paths, batch=256, workers=8, pool=None, device_resize_mb
 
                 pending["launch"].append(resize_full)
             if len(e3):
-                n3 = len(e3)
-                recs, tables, jobs, out_sz, blocks, nt = jpeg_records(bigview, n, cap, e3, comp, n_px)
-                w, h, nrows = recs["width"].astype(np.int64), recs["height"].astype(np.int64), jobs["nrows"].astype(np.int64)
-                tmp = nrows * n_px * 3
-                o_tab = (recs.nbytes + 15) // 16 * 16
-                o_job = (o_tab + tables.nbytes + 15) // 16 * 16
-                small = np.zeros(o_job + jobs.nbytes, np.uint8)
-                small[:recs.nbytes] = recs.view(np.uint8).reshape(-1)
-                small[o_tab:o_tab + tables.nbytes] = tables
-                small[o_job:] = jobs.view(np.uint8).reshape(-1)
-                dsmall = torch.from_numpy(small).to(dev)
-                total_blocks = int(blocks.sum())
-                ws_bytes = int(L.clipmi_jpeg_workspace_bytes(total_blocks, nt))
-                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-                rgb = torch.empty(int(out_sz.sum()), dtype=torch.uint8, device=dev)
-                status = torch.empty(n3, dtype=torch.int32, device=dev)
-                scratch3 = torch.empty(max(int(tmp.sum()), 1), dtype=torch.uint8, device=dev)
-                mb, mp, mr = int(blocks.max()), int((w * h).max()), int(nrows.max())
+                # groups of files whose decoded form (coefficients, sample planes, RGB rows: ~22 bytes per pixel) fits a budget: a
+                # batch of thumbnails is one group, a batch of 12-megapixel photos many - they run one after the other through
+                # ONE workspace (the side stream is in order), so that HBM holds a group, not a batch, of decoded photos
+                st_ = np.lib.stride_tricks.as_strided
+                H3 = st_(bigview[:4 * JPEG_HDR_INTS].view(np.int32), shape=(n, JPEG_HDR_INTS), strides=(cap, 4))[e3].astype(np.int64)
+                need = H3[:, 7] * 192 + (H3[:, 1] * H3[:, 2] * 3 + 15) // 16 * 16 + H3[:, 9] * n_px * 3
+                groups, lo, acc = [], 0, 0
+                for k in range(len(e3)):
+                    if k > lo and acc + need[k] > jpeg_group_bytes:
+                        groups.append((lo, k))
+                        lo, acc = k, 0
+                    acc += int(need[k])
+                groups.append((lo, len(e3)))
+                status = torch.empty(len(e3), dtype=torch.int32, device=dev)
+                calls, ws_max, rgb_max, tmp_max = [], 0, 0, 0
+                for lo, hi in groups:
+                    recs, tables, jobs, out_sz, blocks, nt = jpeg_records(bigview, n, cap, e3[lo:hi], comp, n_px)
+                    w, h, nrows = recs["width"].astype(np.int64), recs["height"].astype(np.int64), jobs["nrows"].astype(np.int64)
+                    o_tab = (recs.nbytes + 15) // 16 * 16
+                    o_job = (o_tab + tables.nbytes + 15) // 16 * 16
+                    small = np.zeros(o_job + jobs.nbytes, np.uint8)
+                    small[:recs.nbytes] = recs.view(np.uint8).reshape(-1)
+                    small[o_tab:o_tab + tables.nbytes] = tables
+                    small[o_job:] = jobs.view(np.uint8).reshape(-1)
+                    dsmall = torch.from_numpy(small).to(dev)
+                    total_blocks = int(blocks.sum())
+                    ws_bytes = int(L.clipmi_jpeg_workspace_bytes(total_blocks, nt))
+                    ws_max, rgb_max = max(ws_max, ws_bytes), max(rgb_max, int(out_sz.sum()))
+                    tmp_max = max(tmp_max, int((nrows * n_px * 3).sum()))
+                    calls.append((dsmall, o_tab, o_job, hi - lo, nt, total_blocks, int(blocks.max()), int((w * h).max()), int(nrows.max()),
+                                  ws_bytes, lo))
+                    pending["keep"].append(dsmall)
+                ws = torch.empty(ws_max, dtype=torch.uint8, device=dev)
+                rgb = torch.empty(max(rgb_max, 16), dtype=torch.uint8, device=dev)
+                scratch3 = torch.empty(max(tmp_max, 1), dtype=torch.uint8, device=dev)
 
                 def decode_jpeg():
-                    sb = dsmall.data_ptr()
-                    rc = L.clipmi_jpeg_decode_rgb8(base, sb, n3, sb + o_tab, nt, total_blocks, mb, mp, rgb.data_ptr(), status.data_ptr(),
-                                                   ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
-                    _lib.check(rc, "clipmi_jpeg_decode_rgb8")
-                    rc = L.clipmi_resize_crop_rgb8(rgb.data_ptr(), sb + o_job, n3, mr, base, n_px, devt.data_ptr(), scratch3.data_ptr(),
-                                                   _lib.stream_ptr(dev))
-                    _lib.check(rc, "clipmi_resize_crop_rgb8")
+                    for dsmall, o_tab, o_job, n3, nt, total_blocks, mb, mp, mr, ws_bytes, lo in calls:
+                        sb = dsmall.data_ptr()
+                        rc = L.clipmi_jpeg_decode_rgb8(base, sb, n3, sb + o_tab, nt, total_blocks, mb, mp, rgb.data_ptr(),
+                                                       status.data_ptr() + 4 * lo, ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
+                        _lib.check(rc, "clipmi_jpeg_decode_rgb8")
+                        rc = L.clipmi_resize_crop_rgb8(rgb.data_ptr(), sb + o_job, n3, mr, base, n_px, devt.data_ptr(), scratch3.data_ptr(),
+                                                       _lib.stream_ptr(dev))
+                        _lib.check(rc, "clipmi_resize_crop_rgb8")
 
                 pending["launch"].append(decode_jpeg)
-                pending["keep"] += [dsmall, ws, rgb, scratch3]
+                pending["keep"] += [ws, rgb, scratch3]
                 pending["status"], pending["slots"] = status, e3
             ev_copy = torch.cuda.Event()
             ev_copy.record(copy_stream)

@@ -261,9 +261,10 @@ def _jpeg_pipeline_worker(tmp):
         host = list(clipmi.pipeline.encode_files(model, files, batch=5, pool=pool, device_resize_mb=0, device_jpeg_kb=0))
         devj = list(clipmi.pipeline.encode_files(model, files, batch=5, pool=pool, device_resize_mb=0, device_jpeg_kb=256))
         both = list(clipmi.pipeline.encode_files(model, files, batch=5, pool=pool, device_resize_mb=8, device_jpeg_kb=256))
+        grps = list(clipmi.pipeline.encode_files(model, files, batch=5, pool=pool, device_resize_mb=0, device_jpeg_kb=256, jpeg_group_mb=1))   # a decode launch per file or two
         (_, _, _, full), _, _ = pool.decode(files[:5], 224, copy=False, full_cap=256 << 10, full_mode=2)
         assert {0, 2, 3} <= set(full) and all(v[0] == 3 for v in full.values())      # (files over the size cap stay with Pillow)
-    for other in (devj, both):
+    for other in (devj, both, grps):
         assert [h[0] for h in host] == [d[0] for d in other] and [h[2] for h in host] == [d[2] for d in other]
         for h, d in zip(host, other):
             assert (h[1] is None and d[1] is None) or np.array_equal(h[1], d[1])

@@ -27,7 +27,7 @@ def main():
         print("shm free MB", pool.shm_room() >> 20, "workers", pool.n, "file KB", os.path.getsize(paths[0]) >> 10, flush=True)
         model = clipmi.CLIP(clipmi.weights.random_state_dict("ViT-B/32", seed=0), device="cuda:0")
         for batch in ((435, 870) if kind != "photo2k" else (435,)):
-            for kb in ((0, 1024) if kind != "photo2k" else (4096,)):
+            for kb in ((0, 8192) if kind != "photo2k" else (8192,)):
                 for _ in clipmi.pipeline.encode_files(model, paths[:batch], batch=batch, pool=pool, device_jpeg_kb=kb):
                     pass
                 t0 = time.perf_counter(); got = 0; st = {}
