@@ -1,6 +1,6 @@
 """Differential test of the JPEG decode on the device against Pillow on many random files (sizes 1..400, qualities 1..100, every
 sampling, optimised tables, restart intervals, grey; smooth / noise / flat / sparse content), both with the byte stuffing removed on
-the host and on the device: tools/jpeg_fuzz.py [n_files] [seed]"""
+the host and on the device: tools/jpeg_fuzz.py [n_files] [seed] [largest side, default 400]"""
 import io, sys
 import numpy as np, torch
 from PIL import Image
@@ -8,8 +8,11 @@ sys.path.insert(0, ".")
 import clipmi
 from clipmi import jpeg, jpeg_parse
 
+MAXSIDE = 400
+
+
 def make(rng):
-    h, w = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+    h, w = int(rng.integers(1, MAXSIDE)), int(rng.integers(1, MAXSIDE))
     kind = rng.integers(0, 5)
     if kind == 0:
         a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
@@ -42,12 +45,15 @@ def make(rng):
     return buf.getvalue(), (h, w, kw, int(kind), grey)
 
 def main():
+    global MAXSIDE
+    if len(sys.argv) > 3:
+        MAXSIDE = int(sys.argv[3])
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     dev = torch.device("cuda:0")
     bad = unsup = done = 0
     while done < n:
-        files = [make(rng) for _ in range(min(500, n - done))]
+        files = [make(rng) for _ in range(min(500 if MAXSIDE <= 400 else 100, n - done))]
         blobs = [f[0] for f in files]
         for keep in (False, True):
             got = jpeg.decode_files(blobs, dev, keep_stuffing=keep)
